@@ -1,0 +1,123 @@
+/* libeffdet_hip.so - C ABI of the MI355X (gfx950) EfficientDet inference + OOD-scoring hot path.
+ *
+ * The reference (DavidPetrus/ood_object_detection, a fork of rwightman/efficientdet-pytorch 0.2.3) is
+ * pure Python with no FFI layer: its "operator API" for this path is a handful of Python callables and
+ * the PyTorch ops under them.  Each entry point below names the reference call site (file:line under
+ * the reference tree) whose arithmetic it replaces; INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless it is an array-of-parameters argument documented as
+ *     host memory ("host:" below); buffers are caller-owned; nothing is allocated internally;
+ *   - `stream` is a hipStream_t; all work is enqueued on it; no call synchronises (graph-capturable);
+ *   - activations are NHWC, channels a multiple of 8; `dtype` 0 = float32 (parity mode),
+ *     1 = bfloat16 (throughput mode, fp32 accumulate); weights of the MFMA GEMMs use the same dtype,
+ *     every per-channel vector (scale/shift/bias/depthwise taps/SE weights) is float32;
+ *   - return value: 0 on success, -22 (EINVAL) for a rejected argument, -5 (EIO) if the launch failed;
+ *   - thread-safe per stream, no global mutable state.
+ */
+#ifndef EFFDET_HIP_H
+#define EFFDET_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EFFDET_F32 0
+#define EFFDET_BF16 1
+
+/* ABI version of this header (bumped on any signature change). */
+int effdet_abi_version(void);
+
+/* ---- backbone (timm EfficientNet; timm call sites effdet/efficientdet.py:17-18,837) ---------------- */
+
+/* conv_stem 3x3/s2 TF-SAME + bn1 + SiLU.  X: NCHW [B,3,H,W] (in_dtype), Wt: [27][Cout] tap-major
+ * (ky,kx,ci), Y: NHWC [B,ceil(H/2),ceil(W/2),Cout] (out_dtype). */
+int effdet_stem_conv(void* stream, int in_dtype, int out_dtype, const void* X, const float* Wt,
+                     const float* scale, const float* shift, void* Y, int B, int H, int W, int Cout);
+
+/* 1x1 conv as GEMM with folded BN / bias, optional SiLU (act=1), optional SE gate on A
+ * (gate [B,K] fp32, rows_per_image = H*W), optional residual [M,N].  A: [M,K], W: [N,K].
+ * Output row m goes to C + (m / rows_per_image) * c_image_stride + (m % rows_per_image) * ldc
+ * (pass 0 for rows_per_image / c_image_stride / ldc to get a plain [M,N] matrix).
+ * Replaces conv_pw / conv_pwl + BatchNorm2d (+Swish) of timm's MBConv blocks and the BiFPN lateral
+ * ConvBnAct2d (effdet/efficientdet.py:42-57, :155-158). */
+int effdet_pw_gemm_bn_act(void* stream, int dtype, const void* A, long long M, int K, const void* W, int N,
+                          const float* scale, const float* shift, int act, const void* residual,
+                          const float* gate, int rows_per_image,
+                          void* C, long long c_image_stride, long long ldc);
+
+/* depthwise k x k (k = 3|5, stride 1|2, TF-SAME) + folded BN + SiLU.  Wt: [k*k][C] fp32.
+ * If pool_partial != NULL it receives [B][effdet_dwconv_blocks_per_image(Ho,Wo,C)][C] partial sums of
+ * the output for the squeeze-excite average. */
+int effdet_dwconv_bn_act(void* stream, int dtype, const void* X, void* Y, const float* Wt,
+                         const float* scale, const float* shift, int act, float* pool_partial,
+                         int B, int H, int W, int C, int k, int stride);
+int effdet_dwconv_blocks_per_image(int Ho, int Wo, int C);
+
+/* SqueezeExcite gate: mean -> fc(C->R)+SiLU -> fc(R->C) -> sigmoid.  W1: [R][C], W2: [C][R]. */
+int effdet_se_gate(void* stream, const float* partial, int nblk, int hw, const float* W1, const float* b1,
+                   const float* W2, const float* b2, float* gate, int B, int C, int R);
+
+/* ---- BiFPN + heads (effdet/efficientdet.py:140-469) ---------------------------------------------- */
+
+/* create_pool2d('max', 3, 2, 'same') (effdet/efficientdet.py:165-166): P6, P7.  image strides in
+ * elements (0 = dense). */
+int effdet_maxpool_same(void* stream, int dtype, const void* X, long long x_image_stride,
+                        void* Y, long long y_image_stride, int B, int H, int W, int C);
+
+/* Fused FpnCombine -> Swish -> SeparableConv2d -> BN for one BiFPN node (nlevels = 1,
+ * effdet/efficientdet.py:224-245, :281-292), or one HeadNet layer over all pyramid levels
+ * (nlevels <= 5, effdet/efficientdet.py:438-452) with the per-anchor OOD energy / max-logit epilogue
+ * when ood_classes > 0.  All array arguments are host: memory.
+ *   level_hw[l] = {H,W};  per (level, input): pointer, image stride (elements), {H,W}, mode
+ *   (0 same size, 1 nearest x2 upsample, 2 max-pool 3x3/s2 SAME);
+ *   fuse_mode 0: single input, 1: sum_i (x_i*w_i)/den ('fastattn'), 2: sum_i x_i*w_i ('attn','sum');
+ *   dw_w [9][F] fp32; pw_w [N][F] (dtype); scale/shift [rows][N] fp32 indexed by affine_row[l]
+ *   (scale may be NULL); out_ptr[l] + b*out_image_stride[l] + (y*W+x)*N. */
+int effdet_sepconv_fused(void* stream, int dtype, int B, int nlevels, const int* level_hw, int n_in,
+                         const void* const* in_ptr, const long long* in_image_stride, const int* in_hw,
+                         const int* in_mode, int fuse_mode, const float* fuse_w, float fuse_den, int pre_act,
+                         const float* dw_w, const void* pw_w, const float* scale, const float* shift,
+                         const int* affine_row, int post_act, int F, int N,
+                         void* const* out_ptr, const long long* out_image_stride,
+                         int ood_classes, int num_anchors, float* ood_energy, float* ood_maxlogit,
+                         long long ood_image_stride, const long long* ood_level_off);
+
+/* ---- post-processing ------------------------------------------------------------------------------ */
+
+/* _post_process (effdet/bench.py:12-56).  cls_all [B, n_anchors, C], box_all [B, n_anchors, 4] (dtype);
+ * outputs out_cls [B,k], out_box [B,k,4] (dtype), out_indices / out_classes [B,k] int64.
+ * Descending by logit, ties by lower flat index.  k <= 16384. */
+long long effdet_topk_workspace_bytes(int B);
+int effdet_topk_select(void* stream, int dtype, const void* cls_all, int B, long long n_anchors, int C,
+                       const void* box_all, int k, void* out_cls, void* out_box,
+                       long long* out_indices, long long* out_classes, void* workspace, long long workspace_bytes);
+
+/* generate_detections, first half (effdet/anchors.py:132-144): decode, clip (when img_scale and img_size
+ * are given), sigmoid, keep score > 0.01 (order kept).  Outputs are [B,k(,4)] with count[b] valid rows. */
+int effdet_decode_threshold(void* stream, int dtype, const void* cls_topk, const void* box_topk,
+                            const float* anchors, const long long* indices, const long long* classes,
+                            const float* img_scale, const float* img_size, int B, int k,
+                            float* boxes, float* scores, int* classes_out, int* src, int* count, float* maxcoord);
+
+/* generate_detections, second half (effdet/anchors.py:145-166).  det [B,max_det,6] zero padded rows
+ * x1,y1,x2,y2,score,class+1; det_count [B]; keep_src [B,max_det] = position in the top-k list or -1.
+ * Hard: torchvision batched_nms semantics (anchors.py:150).  Soft: effdet/soft_nms.py:42-169. */
+int effdet_nms_hard(void* stream, const float* boxes, const float* scores, const int* classes, const int* src,
+                    const int* count, const float* maxcoord, int B, int k, double iou_threshold, int max_det,
+                    const float* img_scale, float* det, int* det_count, int* keep_src);
+int effdet_nms_soft(void* stream, const float* boxes, const float* scores, const int* classes, const int* src,
+                    const int* count, const float* maxcoord, int B, int k, int method_gaussian, float sigma,
+                    float iou_threshold, float score_threshold, int max_det,
+                    const float* img_scale, float* det, int* det_count, int* keep_src);
+
+/* OOD scores of the kept detections: energy/maxlogit [B,n_anchors] -> [B,max_det] (0 where padded). */
+int effdet_gather_ood(void* stream, const int* keep_src, const long long* indices, const float* energy,
+                      const float* maxlogit, long long n_anchors, int B, int k, int max_det,
+                      float* out_energy, float* out_maxlogit);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EFFDET_HIP_H */

@@ -1,0 +1,80 @@
+"""ctypes loader for libeffdet_hip.so (the C ABI declared in include/effdet_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libeffdet_hip.so')
+CSRC = os.path.join(_HERE, 'csrc')
+
+_lib = None
+
+c_void_p, c_int, c_ll, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_double
+P = ctypes.POINTER
+
+# name -> (restype, argtypes); must list every symbol include/effdet_hip.h declares
+SIGNATURES = {
+    'effdet_abi_version': (c_int, []),
+    'effdet_stem_conv': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_int, c_int, c_int, c_int]),
+    'effdet_pw_gemm_bn_act': (c_int, [c_void_p, c_int, c_void_p, c_ll, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                      c_int, c_void_p, c_void_p, c_int, c_void_p, c_ll, c_ll]),
+    'effdet_dwconv_bn_act': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                     c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
+    'effdet_dwconv_blocks_per_image': (c_int, [c_int, c_int, c_int]),
+    'effdet_se_gate': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_int, c_int, c_int]),
+    'effdet_maxpool_same': (c_int, [c_void_p, c_int, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int]),
+    'effdet_sepconv_fused': (c_int, [c_void_p, c_int, c_int, c_int, P(c_int), c_int,
+                                     P(c_void_p), P(c_ll), P(c_int), P(c_int), c_int, P(c_float), c_float, c_int,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, P(c_int), c_int, c_int, c_int,
+                                     P(c_void_p), P(c_ll), c_int, c_int, c_void_p, c_void_p, c_ll, P(c_ll)]),
+    'effdet_topk_workspace_bytes': (c_ll, [c_int]),
+    'effdet_topk_select': (c_int, [c_void_p, c_int, c_void_p, c_int, c_ll, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_ll]),
+    'effdet_decode_threshold': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p]),
+    'effdet_nms_hard': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'effdet_nms_soft': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                c_int, c_float, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'effdet_gather_ood': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_int, c_int, c_int,
+                                  c_void_p, c_void_p]),
+}
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into libeffdet_hip.so (in-tree)."""
+    jobs = str(min(8, os.cpu_count() or 1))
+    r = subprocess.run(['make', '-C', CSRC, '-j', jobs], capture_output=not verbose, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('building libeffdet_hip.so failed:\n%s\n%s' % (r.stdout, r.stderr))
+    return LIB_PATH
+
+
+def load():
+    """Load the shared library; RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('%s is missing - run `python -c "import __graft_entry__ as g; g.build()"` '
+                           '(there is no CPU fallback for the HIP path)' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.effdet_abi_version() != 1:
+        raise RuntimeError('libeffdet_hip.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError('%s failed with code %d' % (what, rc))

@@ -1,0 +1,123 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) EfficientDet kernels.
+// Wave = 64 lanes. Activations are NHWC; T is float (parity mode) or __bf16 (throughput mode).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/effdet_hip.h"
+
+#define EFFDET_OK 0
+#define EFFDET_EINVAL (-22)
+#define EFFDET_ELAUNCH (-5)
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define DEV __device__ __forceinline__
+
+static inline int effdet_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? EFFDET_OK : EFFDET_ELAUNCH;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scalar math (fp32 everywhere inside a kernel; T only at the HBM / LDS-image boundary)
+// ---------------------------------------------------------------------------------------------
+DEV float silu_f(float x) { return x / (1.0f + expf(-x)); }
+DEV float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <typename T> struct VecTraits;
+// 16-byte chunk = 4 floats or 8 bf16
+template <> struct VecTraits<float> { static constexpr int EPC = 4; };    // elements per 16-B chunk
+template <> struct VecTraits<bf16_t> { static constexpr int EPC = 8; };
+
+// A group of 8 consecutive channels held as fp32 in registers.
+struct F8 { float v[8]; };
+
+template <typename T> DEV F8 load8(const T* p);
+template <> DEV F8 load8<float>(const float* p) {
+    F8 r;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r.v[i] = a[i]; r.v[4 + i] = b[i]; }
+    return r;
+}
+template <> DEV F8 load8<bf16_t>(const bf16_t* p) {
+    F8 r;
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = (float)a[i];
+    return r;
+}
+template <typename T> DEV void store8(T* p, const F8& r);
+template <> DEV void store8<float>(float* p, const F8& r) {
+    f32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = r.v[i]; b[i] = r.v[4 + i]; }
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+template <> DEV void store8<bf16_t>(bf16_t* p, const F8& r) {
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (bf16_t)r.v[i];
+    *reinterpret_cast<bf16x8*>(p) = a;
+}
+DEV F8 f8_zero() { F8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = 0.f;
+    return r; }
+DEV F8 f8_fill(float x) { F8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = x;
+    return r; }
+
+template <typename T> DEV float to_f(T x) { return (float)x; }
+template <typename T> DEV T from_f(float x) { return (T)x; }
+
+// ---------------------------------------------------------------------------------------------
+// MFMA on a "64-byte K-chunk": every lane holds one 16-byte piece of A and of B.
+//   bf16: 8 elements/lane  -> one v_mfma_f32_16x16x32_bf16  (K = 32)
+//   f32 : 4 elements/lane  -> four v_mfma_f32_16x16x4_f32   (K = 16), exact fp32 fma chain
+// Lane l supplies row/col (l & 15) and 16-byte piece (l >> 4) of the chunk for both operands, so
+// the same LDS image (rows of 64-byte K-chunks) serves both dtypes.
+// C/D: col = l & 15, row = 4 * (l >> 4) + reg.
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { bf16x8 v; };
+template <> struct Frag<float> { f32x4 v; };
+
+template <typename T> DEV Frag<T> ld_frag(const void* p) {
+    Frag<T> f;
+    f.v = *reinterpret_cast<const decltype(f.v)*>(p);
+    return f;
+}
+DEV void mma_chunk(const Frag<bf16_t>& a, const Frag<bf16_t>& b, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+DEV void mma_chunk(const Frag<float>& a, const Frag<float>& b, f32x4& acc) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[s], b.v[s], acc, 0, 0, 0);
+}
+
+// TF "SAME" padding: amount in front (reference semantics live in timm)
+static inline int same_pad_before(int size, int k, int s) {
+    int out = (size + s - 1) / s;
+    int total = (out - 1) * s + k - size;
+    if (total < 0) total = 0;
+    return total / 2;
+}
+static inline int same_out(int size, int s) { return (size + s - 1) / s; }
+
+DEV float wave_reduce_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+DEV float wave_reduce_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

@@ -1,0 +1,572 @@
+// Post-processing kernels (compiled with -ffp-contract=off: the box arithmetic must round exactly
+// like the reference's separate fp32 multiply / add ops).
+//
+//   effdet_topk_select       _post_process (effdet/bench.py:35-56): top-k over the N*C class logits of
+//                            every image, descending, ties by lower flat index; then index // C,
+//                            index % C and the box / logit gathers.
+//   effdet_decode_threshold  generate_detections part 1 (effdet/anchors.py:132-144): anchor gather,
+//                            decode_box_outputs (:51-85), clip_boxes_xyxy (:88-92), sigmoid,
+//                            `score > 0.01` order-preserving compaction, boxes.max().
+//   effdet_nms_hard          torchvision batched_nms semantics (call site effdet/anchors.py:150).
+//   effdet_nms_soft          batched_soft_nms / soft_nms (effdet/soft_nms.py:42-169).
+//                            Both stop after max_det picks (anchors.py:153 keeps only those) and emit
+//                            [B, max_det, 6] rows x1,y1,x2,y2,score,class+1 (anchors.py:154-166).
+//   effdet_gather_ood        energy / max-logit of the anchors behind the kept detections.
+//
+// Top-k is an MSB-first radix select on 64-bit composite keys (order-preserving float key << 32 |
+// ~index), 11 bits per pass.  After each pass the per-image state knows how many elements lie in and
+// above the bin that holds the k-th key; as soon as that candidate set fits the 16384-entry LDS sort
+// buffer the remaining passes return at once, the candidates are compacted and one workgroup per
+// image bitonic-sorts them.  For ordinary logit distributions this is one histogram read + one
+// compaction read of the logits.
+#include "common.h"
+
+namespace {
+
+constexpr int TOPK_CAP = 16384;
+constexpr int HIST_BINS = 2048;
+constexpr int NPASS = 6;
+__constant__ int kPassShift[NPASS] = {53, 42, 32, 21, 10, 0};
+__constant__ int kPassBits[NPASS] = {11, 11, 10, 11, 11, 10};
+
+struct TopkState {            // one per image, 64 bytes
+    unsigned long long prefix;   // bits fixed so far (right-aligned)
+    int bits_done;
+    int done;
+    unsigned int c_hi;           // elements strictly above the prefix range
+    unsigned int cand_total;     // candidates = c_hi + |bin|
+    unsigned int cand_count;     // compaction cursor
+    unsigned int pad[9];
+};
+
+DEV unsigned int float_key(float f) {
+    const unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+DEV float key_float(unsigned int k) {
+    const unsigned int u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+DEV unsigned long long comp_key(float f, unsigned int idx) {
+    return ((unsigned long long)float_key(f) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+}
+
+// Iterate the elements [seg0, seg1) of one image row, 16 bytes at a time where aligned.
+template <typename T, typename Fn>
+DEV void for_each_element(const T* row, long long seg0, long long seg1, int tid, int nthreads, Fn fn) {
+    constexpr int EPC = VecTraits<T>::EPC;
+    // first element index >= seg0 whose address is 16-byte aligned
+    const uintptr_t addr0 = reinterpret_cast<uintptr_t>(row + seg0);
+    long long head = ((16 - (addr0 & 15)) & 15) / (long long)sizeof(T);
+    if (head > seg1 - seg0) head = seg1 - seg0;
+    for (long long i = seg0 + tid; i < seg0 + head; i += nthreads) fn(to_f<T>(row[i]), (unsigned int)i);
+    const long long v0 = seg0 + head;
+    const long long nvec = (seg1 - v0) / EPC;
+    for (long long v = tid; v < nvec; v += nthreads) {
+        const long long i = v0 + v * EPC;
+        if constexpr (sizeof(T) == 4) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(row + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fn(x[e], (unsigned int)(i + e));
+        } else {
+            const bf16x8 x = *reinterpret_cast<const bf16x8*>(row + i);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fn((float)x[e], (unsigned int)(i + e));
+        }
+    }
+    for (long long i = v0 + nvec * EPC + tid; i < seg1; i += nthreads) fn(to_f<T>(row[i]), (unsigned int)i);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void topk_hist_kernel(const T* X, long long L, int pass,
+                                                        TopkState* state, unsigned int* hist) {
+    const int b = blockIdx.y;
+    const TopkState st = state[b];
+    if (st.done) return;
+    __shared__ unsigned int h[HIST_BINS];
+    for (int i = threadIdx.x; i < HIST_BINS; i += 256) h[i] = 0;
+    __syncthreads();
+    const long long per = (L + gridDim.x - 1) / gridDim.x;
+    const long long seg0 = per * blockIdx.x;
+    long long seg1 = seg0 + per; if (seg1 > L) seg1 = L;
+    const int shift = kPassShift[pass];
+    const unsigned int mask = (1u << kPassBits[pass]) - 1u;
+    const int pshift = 64 - st.bits_done;
+    const unsigned long long prefix = st.prefix;
+    if (seg0 < seg1) {
+        for_each_element<T>(X + (long long)b * L, seg0, seg1, threadIdx.x, 256, [&](float f, unsigned int idx) {
+            const unsigned long long key = comp_key(f, idx);
+            if (pass == 0 || (key >> pshift) == prefix)
+                atomicAdd(&h[(unsigned int)(key >> shift) & mask], 1u);
+        });
+    }
+    __syncthreads();
+    unsigned int* gh = hist + (long long)b * HIST_BINS;
+    for (int i = threadIdx.x; i < HIST_BINS; i += 256) if (h[i]) atomicAdd(&gh[i], h[i]);
+}
+
+__global__ __launch_bounds__(256) void topk_find_kernel(int pass, int k, TopkState* state, unsigned int* hist) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    TopkState st = state[b];
+    if (st.done) return;
+    unsigned int* gh = hist + (long long)b * HIST_BINS;
+    __shared__ unsigned int part[256];
+    __shared__ unsigned int sel[3];      // bin, elements above it (inside this prefix), elements in it
+    // thread t owns bins [8t, 8t+8); suffix sums from the top
+    unsigned int loc[8], s = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { loc[e] = gh[tid * 8 + e]; s += loc[e]; gh[tid * 8 + e] = 0; }
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {                      // 256-entry suffix scan, serial: trivial work
+        unsigned int run = 0;
+        for (int t = 255; t >= 0; --t) { const unsigned int v = part[t]; part[t] = run; run += v; }
+    }
+    __syncthreads();
+    const unsigned int need = (unsigned int)k - st.c_hi;
+    unsigned int above = part[tid];      // elements in bins owned by higher threads
+    if (above < need && above + s >= need) {
+        for (int e = 7; e >= 0; --e) {
+            if (above + loc[e] >= need) { sel[0] = tid * 8 + e; sel[1] = above; sel[2] = loc[e]; break; }
+            above += loc[e];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int bits = kPassBits[pass];
+        st.prefix = (st.prefix << bits) | (unsigned long long)sel[0];
+        st.bits_done += bits;
+        st.c_hi += sel[1];
+        st.cand_total = st.c_hi + sel[2];
+        if (st.cand_total <= (unsigned int)TOPK_CAP || pass == NPASS - 1) st.done = 1;
+        state[b] = st;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void topk_collect_kernel(const T* X, long long L, TopkState* state,
+                                                           unsigned long long* cand) {
+    const int b = blockIdx.y;
+    TopkState* sp = state + b;
+    const int pshift = 64 - sp->bits_done;
+    const unsigned long long prefix = sp->prefix;
+    const long long per = (L + gridDim.x - 1) / gridDim.x;
+    const long long seg0 = per * blockIdx.x;
+    long long seg1 = seg0 + per; if (seg1 > L) seg1 = L;
+    if (seg0 >= seg1) return;
+    unsigned long long* out = cand + (long long)b * TOPK_CAP;
+    for_each_element<T>(X + (long long)b * L, seg0, seg1, threadIdx.x, 256, [&](float f, unsigned int idx) {
+        const unsigned long long key = comp_key(f, idx);
+        if ((key >> pshift) >= prefix) {
+            const unsigned int pos = atomicAdd(&sp->cand_count, 1u);
+            if (pos < (unsigned int)TOPK_CAP) out[pos] = key;
+        }
+    });
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void topk_sort_kernel(const TopkState* state, const unsigned long long* cand,
+                                                         int k, int C, const T* cls_all, const T* box_all,
+                                                         long long L, long long n_anchors,
+                                                         T* out_cls, T* out_box, long long* out_idx, long long* out_cls_id) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    unsigned int n = state[b].cand_total;
+    if (n > (unsigned int)TOPK_CAP) n = TOPK_CAP;
+    int P = 1024;
+    while (P < (int)n) P <<= 1;
+    const unsigned long long* src = cand + (long long)b * TOPK_CAP;
+    for (int i = tid; i < P; i += 1024) keys[i] = i < (int)n ? src[i] : 0ull;
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < (P >> 1); i += 1024) {
+                const int pos = 2 * i - (i & (stride - 1));
+                const unsigned long long a = keys[pos], c = keys[pos + stride];
+                const bool desc = (pos & size) == 0;          // final order: descending
+                if ((a < c) == desc) { keys[pos] = c; keys[pos + stride] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < k; i += 1024) {
+        const unsigned long long key = keys[i];
+        const unsigned int flat = 0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull);
+        const long long o = (long long)b * k + i;
+        const long long anchor = flat / (unsigned int)C;
+        out_idx[o] = anchor;
+        out_cls_id[o] = flat % (unsigned int)C;
+        out_cls[o] = cls_all[(long long)b * L + flat];
+        if (box_all != nullptr) {
+            const T* bs = box_all + ((long long)b * n_anchors + anchor) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out_box[o * 4 + e] = bs[e];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct DecodeArgs {
+    const void* cls; const void* box; int dtype;
+    const float* anchors;
+    const long long* indices; const long long* classes;
+    const float* img_scale; const float* img_size;
+    int k;
+    float* boxes; float* scores; int* cls_out; int* src; int* count; float* maxcoord;
+};
+
+DEV float ld_as_float(const void* p, int dtype, long long i) {
+    return dtype == 0 ? reinterpret_cast<const float*>(p)[i] : (float)reinterpret_cast<const bf16_t*>(p)[i];
+}
+
+__global__ __launch_bounds__(256) void decode_threshold_kernel(DecodeArgs p) {
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int wcount[4];
+    __shared__ float wmax[4];
+    __shared__ int base_s;
+    if (tid == 0) base_s = 0;
+    float mx = -INFINITY;
+    const bool clip = p.img_scale != nullptr && p.img_size != nullptr;
+    float cw = 0.f, chh = 0.f;
+    if (clip) { const float s = p.img_scale[b]; cw = p.img_size[b * 2] / s; chh = p.img_size[b * 2 + 1] / s; }
+    __syncthreads();
+    for (int i0 = 0; i0 < p.k; i0 += 256) {
+        const int i = i0 + tid;
+        bool keep = false;
+        float x1 = 0, y1 = 0, x2 = 0, y2 = 0, sc = 0;
+        if (i < p.k) {
+            const long long o = (long long)b * p.k + i;
+            const float* a = p.anchors + p.indices[o] * 4;
+            const float ya = (a[0] + a[2]) / 2, xa = (a[1] + a[3]) / 2;
+            const float ha = a[2] - a[0], wa = a[3] - a[1];
+            const float ty = ld_as_float(p.box, p.dtype, o * 4 + 0), tx = ld_as_float(p.box, p.dtype, o * 4 + 1);
+            const float th = ld_as_float(p.box, p.dtype, o * 4 + 2), tw = ld_as_float(p.box, p.dtype, o * 4 + 3);
+            const float w = expf(tw) * wa, h = expf(th) * ha;
+            const float yc = ty * ha + ya, xc = tx * wa + xa;
+            y1 = yc - h / 2.f; x1 = xc - w / 2.f; y2 = yc + h / 2.f; x2 = xc + w / 2.f;
+            if (clip) {
+                x1 = fminf(fmaxf(x1, 0.f), cw); y1 = fminf(fmaxf(y1, 0.f), chh);
+                x2 = fminf(fmaxf(x2, 0.f), cw); y2 = fminf(fmaxf(y2, 0.f), chh);
+            }
+            sc = 1.0f / (1.0f + expf(-ld_as_float(p.cls, p.dtype, o)));
+            keep = sc > 0.01f;
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wcount[wave] = __popcll(m);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; ++w) off += wcount[w];
+        const int total = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        if (keep) {
+            const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+            const long long o = (long long)b * p.k + pos;
+            p.boxes[o * 4 + 0] = x1; p.boxes[o * 4 + 1] = y1; p.boxes[o * 4 + 2] = x2; p.boxes[o * 4 + 3] = y2;
+            p.scores[o] = sc;
+            p.cls_out[o] = (int)p.classes[(long long)b * p.k + i];
+            p.src[o] = i;
+            mx = fmaxf(mx, fmaxf(fmaxf(x1, y1), fmaxf(x2, y2)));
+        }
+        __syncthreads();
+        if (tid == 0) base_s += total;
+        __syncthreads();
+    }
+    mx = wave_reduce_max(mx);
+    if (lane == 0) wmax[wave] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        p.count[b] = base_s;
+        p.maxcoord[b] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct NmsArgs {
+    const float* boxes; const float* scores; const int* classes; const int* src; const int* count;
+    const float* maxcoord; int k;
+    double iou_thr; int max_det;
+    const float* img_scale;
+    float* det; int* det_count; int* keep_src;
+    int gaussian; float sigma; float soft_iou_thr; float score_thr;
+};
+
+DEV void write_det(const NmsArgs& p, int b, int slot, int pos, float score) {
+    const long long o = (long long)b * p.k + pos;
+    const float s = p.img_scale ? p.img_scale[b] : 1.0f;
+    float* d = p.det + ((long long)b * p.max_det + slot) * 6;
+    if (p.img_scale) { d[0] = p.boxes[o * 4] * s; d[1] = p.boxes[o * 4 + 1] * s; d[2] = p.boxes[o * 4 + 2] * s; d[3] = p.boxes[o * 4 + 3] * s; }
+    else { d[0] = p.boxes[o * 4]; d[1] = p.boxes[o * 4 + 1]; d[2] = p.boxes[o * 4 + 2]; d[3] = p.boxes[o * 4 + 3]; }
+    d[4] = score;
+    d[5] = (float)(p.classes[o] + 1);
+    p.keep_src[(long long)b * p.max_det + slot] = p.src[o];
+}
+
+// torchvision-CPU IoU test: suppress when (float IoU, widened) > double threshold
+DEV bool nms_suppresses(float ix1, float iy1, float ix2, float iy2, float iarea,
+                        float jx1, float jy1, float jx2, float jy2, float jarea, double thr) {
+    const float xx1 = fmaxf(ix1, jx1), yy1 = fmaxf(iy1, jy1);
+    const float xx2 = fminf(ix2, jx2), yy2 = fminf(iy2, jy2);
+    const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+    const float inter = w * h;
+    const float ovr = inter / (iarea + jarea - inter);
+    return (double)ovr > thr;
+}
+
+constexpr int NMS_MAX_DET = 512;
+
+__global__ __launch_bounds__(256) void nms_hard_kernel(NmsArgs p) {
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float kx1[NMS_MAX_DET], ky1[NMS_MAX_DET], kx2[NMS_MAX_DET], ky2[NMS_MAX_DET], kar[NMS_MAX_DET];
+    __shared__ float cx1[256], cy1[256], cx2[256], cy2[256], car[256];
+    __shared__ unsigned long long alive_mask[4];
+    __shared__ int nkept_s;
+    const int n = p.count[b];
+    const float off1 = p.maxcoord[b] + 1.0f;
+    if (tid == 0) nkept_s = 0;
+    // zero-fill outputs
+    for (int i = tid; i < p.max_det * 6; i += 256) p.det[(long long)b * p.max_det * 6 + i] = 0.f;
+    for (int i = tid; i < p.max_det; i += 256) p.keep_src[(long long)b * p.max_det + i] = -1;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int nk = nkept_s;
+        if (nk >= p.max_det) break;
+        const int i = c0 + tid;
+        bool alive = i < n;
+        float x1 = 0, y1 = 0, x2 = 0, y2 = 0, ar = 0;
+        if (alive) {
+            const long long o = (long long)b * p.k + i;
+            const float offs = (float)p.classes[o] * off1;
+            x1 = p.boxes[o * 4] + offs; y1 = p.boxes[o * 4 + 1] + offs;
+            x2 = p.boxes[o * 4 + 2] + offs; y2 = p.boxes[o * 4 + 3] + offs;
+            ar = (x2 - x1) * (y2 - y1);
+            for (int j = 0; j < nk; ++j)
+                if (nms_suppresses(kx1[j], ky1[j], kx2[j], ky2[j], kar[j], x1, y1, x2, y2, ar, p.iou_thr)) { alive = false; break; }
+        }
+        cx1[tid] = x1; cy1[tid] = y1; cx2[tid] = x2; cy2[tid] = y2; car[tid] = ar;
+        // sequential resolution inside the chunk
+        for (;;) {
+            const unsigned long long m = __ballot(alive);
+            if (lane == 0) alive_mask[wave] = m;
+            __syncthreads();
+            int pivot = -1;
+#pragma unroll
+            for (int w = 3; w >= 0; --w) if (alive_mask[w]) pivot = w * 64 + __ffsll((long long)alive_mask[w]) - 1;
+            const int nk2 = nkept_s;
+            if (pivot < 0 || nk2 >= p.max_det) { __syncthreads(); break; }
+            if (tid == pivot) {
+                kx1[nk2] = x1; ky1[nk2] = y1; kx2[nk2] = x2; ky2[nk2] = y2; kar[nk2] = ar;
+                write_det(p, b, nk2, c0 + pivot, p.scores[(long long)b * p.k + c0 + pivot]);
+                nkept_s = nk2 + 1;
+                alive = false;
+            } else if (alive && tid > pivot) {
+                if (nms_suppresses(cx1[pivot], cy1[pivot], cx2[pivot], cy2[pivot], car[pivot], x1, y1, x2, y2, ar, p.iou_thr))
+                    alive = false;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    if (tid == 0) p.det_count[b] = nkept_s;
+}
+
+// Soft-NMS: every thread keeps its candidates (index i = tid + 1024*q) in registers.
+constexpr int SOFT_Q = 8;         // supports k <= 8192
+
+__global__ __launch_bounds__(1024) void nms_soft_kernel(NmsArgs p) {
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ unsigned long long wbest[16];
+    __shared__ float top[5];
+    __shared__ unsigned long long best_s;
+    const int n = p.count[b];
+    const float off1 = p.maxcoord[b] + 1.0f;
+    for (int i = tid; i < p.max_det * 6; i += 1024) p.det[(long long)b * p.max_det * 6 + i] = 0.f;
+    for (int i = tid; i < p.max_det; i += 1024) p.keep_src[(long long)b * p.max_det + i] = -1;
+    float x1[SOFT_Q], y1[SOFT_Q], x2[SOFT_Q], y2[SOFT_Q], sc[SOFT_Q];
+    const int nq = (n + 1023) / 1024;
+#pragma unroll
+    for (int q = 0; q < SOFT_Q; ++q) {
+        sc[q] = -1.f; x1[q] = y1[q] = x2[q] = y2[q] = 0.f;
+        const int i = tid + 1024 * q;
+        if (q < nq && i < n) {
+            const long long o = (long long)b * p.k + i;
+            const float offs = (float)p.classes[o] * off1;
+            x1[q] = p.boxes[o * 4] + offs; y1[q] = p.boxes[o * 4 + 1] + offs;
+            x2[q] = p.boxes[o * 4 + 2] + offs; y2[q] = p.boxes[o * 4 + 3] + offs;
+            sc[q] = p.scores[o];
+        }
+    }
+    int count = 0;
+    for (; count < p.max_det; ++count) {
+        // argmax over alive scores, ties -> lowest index
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int q = 0; q < SOFT_Q; ++q) if (q < nq && sc[q] >= 0.f) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(sc[q]) << 32) |
+                                           (unsigned long long)(0xFFFFFFFFu - (unsigned int)(tid + 1024 * q));
+            // +1 in the top word so that a live score of 0.0 still beats "nothing"
+            const unsigned long long k1 = key + (1ull << 32);
+            best = k1 > best ? k1 : best;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(best, o, 64);
+            best = other > best ? other : best;
+        }
+        if (lane == 0) wbest[wave] = best;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long m = 0ull;
+            for (int w = 0; w < 16; ++w) m = wbest[w] > m ? wbest[w] : m;
+            best_s = m;
+        }
+        __syncthreads();
+        const unsigned long long bsel = best_s;
+        if (bsel == 0ull) break;
+        const int ti = (int)(0xFFFFFFFFu - (unsigned int)(bsel & 0xFFFFFFFFull));
+        if (tid == (ti & 1023)) {
+            const int q = ti >> 10;
+            float tx1 = 0, ty1 = 0, tx2 = 0, ty2 = 0, ts = 0;
+#pragma unroll
+            for (int qq = 0; qq < SOFT_Q; ++qq) if (qq == q) { tx1 = x1[qq]; ty1 = y1[qq]; tx2 = x2[qq]; ty2 = y2[qq]; ts = sc[qq]; }
+            top[0] = tx1; top[1] = ty1; top[2] = tx2; top[3] = ty2; top[4] = ts;
+            write_det(p, b, count, ti, ts);
+        }
+        __syncthreads();
+        const float tx1 = top[0], ty1 = top[1], tx2 = top[2], ty2 = top[3];
+        const float tarea = (tx2 - tx1) * (ty2 - ty1);
+#pragma unroll
+        for (int q = 0; q < SOFT_Q; ++q) if (q < nq && sc[q] >= 0.f) {
+            const float area2 = (x2[q] - x1[q]) * (y2[q] - y1[q]);
+            const float w = fmaxf(fminf(tx2, x2[q]) - fmaxf(tx1, x1[q]), 0.f);
+            const float h = fmaxf(fminf(ty2, y2[q]) - fmaxf(ty1, y1[q]), 0.f);
+            const float inter = w * h;
+            const float iou = inter > 0.f ? inter / (tarea + area2 - inter) : 0.f;
+            float decay;
+            if (p.gaussian) decay = expf(-(iou * iou) / p.sigma);
+            else decay = iou > p.soft_iou_thr ? 1.0f - iou : 1.0f;
+            const float ns = sc[q] * decay;
+            const bool keep = (ns > p.score_thr) && ((tid + 1024 * q) != ti);
+            sc[q] = keep ? ns : -1.f;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) p.det_count[b] = count;
+}
+
+__global__ void gather_ood_kernel(const int* keep_src, const long long* indices, const float* energy,
+                                  const float* maxlogit, long long n_anchors, int k, int max_det, int B,
+                                  float* out_energy, float* out_maxlogit) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * max_det) return;
+    const int b = i / max_det;
+    const int s = keep_src[i];
+    float e = 0.f, m = 0.f;
+    if (s >= 0) {
+        const long long a = indices[(long long)b * k + s];
+        e = energy[(long long)b * n_anchors + a];
+        m = maxlogit[(long long)b * n_anchors + a];
+    }
+    out_energy[i] = e; out_maxlogit[i] = m;
+}
+
+inline int topk_segments(int B, long long L) {
+    long long s = 2048 / (B > 0 ? B : 1);
+    const long long by_work = (L + 16383) / 16384;
+    if (s > by_work) s = by_work;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+}  // namespace
+
+extern "C" long long effdet_topk_workspace_bytes(int B) {
+    if (B <= 0) return EFFDET_EINVAL;
+    return (long long)B * (sizeof(TopkState) + HIST_BINS * 4 + (long long)TOPK_CAP * 8);
+}
+
+extern "C" int effdet_topk_select(void* stream, int dtype, const void* cls_all, int B, long long n_anchors, int C,
+                                  const void* box_all, int k,
+                                  void* out_cls, void* out_box, long long* out_indices, long long* out_classes,
+                                  void* workspace, long long workspace_bytes) {
+    const long long L = n_anchors * (long long)C;
+    if (!cls_all || !out_cls || !out_indices || !out_classes || !workspace || B <= 0 || C <= 0 || n_anchors <= 0) return EFFDET_EINVAL;
+    if (k <= 0 || k > TOPK_CAP || k > L || L > 0x7fffffffLL || (dtype & ~1)) return EFFDET_EINVAL;
+    if (box_all && !out_box) return EFFDET_EINVAL;
+    if (workspace_bytes < effdet_topk_workspace_bytes(B)) return EFFDET_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char* ws = reinterpret_cast<char*>(workspace);
+    TopkState* state = reinterpret_cast<TopkState*>(ws);
+    unsigned int* hist = reinterpret_cast<unsigned int*>(ws + (size_t)B * sizeof(TopkState));
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(ws + (size_t)B * (sizeof(TopkState) + HIST_BINS * 4));
+    if (hipMemsetAsync(ws, 0, (size_t)B * (sizeof(TopkState) + HIST_BINS * 4), st) != hipSuccess) return EFFDET_ELAUNCH;
+    const int S = topk_segments(B, L);
+    for (int pass = 0; pass < NPASS; ++pass) {
+        if (dtype == 0) hipLaunchKernelGGL(topk_hist_kernel<float>, dim3(S, B), dim3(256), 0, st, (const float*)cls_all, L, pass, state, hist);
+        else hipLaunchKernelGGL(topk_hist_kernel<bf16_t>, dim3(S, B), dim3(256), 0, st, (const bf16_t*)cls_all, L, pass, state, hist);
+        hipLaunchKernelGGL(topk_find_kernel, dim3(B), dim3(256), 0, st, pass, k, state, hist);
+    }
+    const size_t sort_lds = (size_t)TOPK_CAP * 8;
+    if (dtype == 0) {
+        static bool attr_done = false;
+        if (!attr_done) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(topk_sort_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds) != hipSuccess) return EFFDET_ELAUNCH; attr_done = true; }
+        hipLaunchKernelGGL(topk_collect_kernel<float>, dim3(S, B), dim3(256), 0, st, (const float*)cls_all, L, state, cand);
+        hipLaunchKernelGGL(topk_sort_kernel<float>, dim3(B), dim3(1024), sort_lds, st, state, cand, k, C,
+                           (const float*)cls_all, (const float*)box_all, L, n_anchors,
+                           (float*)out_cls, (float*)out_box, out_indices, out_classes);
+    } else {
+        static bool attr_done = false;
+        if (!attr_done) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(topk_sort_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds) != hipSuccess) return EFFDET_ELAUNCH; attr_done = true; }
+        hipLaunchKernelGGL(topk_collect_kernel<bf16_t>, dim3(S, B), dim3(256), 0, st, (const bf16_t*)cls_all, L, state, cand);
+        hipLaunchKernelGGL(topk_sort_kernel<bf16_t>, dim3(B), dim3(1024), sort_lds, st, state, cand, k, C,
+                           (const bf16_t*)cls_all, (const bf16_t*)box_all, L, n_anchors,
+                           (bf16_t*)out_cls, (bf16_t*)out_box, out_indices, out_classes);
+    }
+    return effdet_check_launch();
+}
+
+extern "C" int effdet_decode_threshold(void* stream, int dtype, const void* cls_topk, const void* box_topk,
+                                       const float* anchors, const long long* indices, const long long* classes,
+                                       const float* img_scale, const float* img_size, int B, int k,
+                                       float* boxes, float* scores, int* classes_out, int* src, int* count, float* maxcoord) {
+    if (!cls_topk || !box_topk || !anchors || !indices || !classes || !boxes || !scores || !classes_out || !src || !count || !maxcoord) return EFFDET_EINVAL;
+    if (B <= 0 || k <= 0 || (dtype & ~1)) return EFFDET_EINVAL;
+    DecodeArgs a{cls_topk, box_topk, dtype, anchors, indices, classes, img_scale, img_size, k, boxes, scores, classes_out, src, count, maxcoord};
+    hipLaunchKernelGGL(decode_threshold_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return effdet_check_launch();
+}
+
+static int nms_common(NmsArgs& a, int B, bool soft, void* stream) {
+    if (!a.boxes || !a.scores || !a.classes || !a.src || !a.count || !a.maxcoord || !a.det || !a.det_count || !a.keep_src) return EFFDET_EINVAL;
+    if (B <= 0 || a.k <= 0 || a.max_det <= 0 || a.max_det > NMS_MAX_DET) return EFFDET_EINVAL;
+    if (soft && a.k > 1024 * SOFT_Q) return EFFDET_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (soft) hipLaunchKernelGGL(nms_soft_kernel, dim3(B), dim3(1024), 0, st, a);
+    else hipLaunchKernelGGL(nms_hard_kernel, dim3(B), dim3(256), 0, st, a);
+    return effdet_check_launch();
+}
+
+extern "C" int effdet_nms_hard(void* stream, const float* boxes, const float* scores, const int* classes, const int* src,
+                               const int* count, const float* maxcoord, int B, int k, double iou_threshold, int max_det,
+                               const float* img_scale, float* det, int* det_count, int* keep_src) {
+    NmsArgs a{boxes, scores, classes, src, count, maxcoord, k, iou_threshold, max_det, img_scale, det, det_count, keep_src, 1, 0.5f, 0.3f, 0.001f};
+    return nms_common(a, B, false, stream);
+}
+
+extern "C" int effdet_nms_soft(void* stream, const float* boxes, const float* scores, const int* classes, const int* src,
+                               const int* count, const float* maxcoord, int B, int k,
+                               int method_gaussian, float sigma, float iou_threshold, float score_threshold, int max_det,
+                               const float* img_scale, float* det, int* det_count, int* keep_src) {
+    if (!(sigma > 0.f)) return EFFDET_EINVAL;
+    NmsArgs a{boxes, scores, classes, src, count, maxcoord, k, (double)iou_threshold, max_det, img_scale, det, det_count, keep_src,
+              method_gaussian ? 1 : 0, sigma, iou_threshold, score_threshold};
+    return nms_common(a, B, true, stream);
+}
+
+extern "C" int effdet_gather_ood(void* stream, const int* keep_src, const long long* indices, const float* energy,
+                                 const float* maxlogit, long long n_anchors, int B, int k, int max_det,
+                                 float* out_energy, float* out_maxlogit) {
+    if (!keep_src || !indices || !energy || !maxlogit || !out_energy || !out_maxlogit || B <= 0 || k <= 0 || max_det <= 0) return EFFDET_EINVAL;
+    const int total = B * max_det;
+    hipLaunchKernelGGL(gather_ood_kernel, dim3((total + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       keep_src, indices, energy, maxlogit, n_anchors, k, max_det, B, out_energy, out_maxlogit);
+    return effdet_check_launch();
+}

@@ -1,0 +1,124 @@
+"""Task wrappers `_post_process`, `DetBenchPredict`, `DetBenchTrain` (reference: effdet/bench.py).
+
+`DetBenchPredict.forward` = EfficientDet forward -> top-k -> decode -> (soft-)NMS, all in HIP, plus the
+per-anchor OOD scores gathered to the kept detections.  The fork's `generate_detections` returns ragged
+per-image rows and then `torch.stack`s them (bench.py:76), which only works when every image yields the
+same count; here the batch result is the zero-padded [B, max_det, 6] tensor and `last_count` holds the
+number of valid rows per image (`ragged()` gives the reference's per-image views).
+"""
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .anchors import Anchors, batched_detections
+
+
+def _post_process(cls_outputs: List[torch.Tensor], box_outputs: List[torch.Tensor], num_levels: int,
+                  num_classes: int, max_detection_points: int = 5000):
+    """Top-k over all class logits (effdet/bench.py:12-56); ties go to the lower flat index.
+
+    Accepts the per-level [B, A*C, H, W] / [B, A*4, H, W] lists.  When they are the engine's own
+    NHWC-backed views the concatenation is free; other tensors are packed with one copy.
+    Returns (cls [B,k,1], box [B,k,4], indices [B,k] int64, classes [B,k] int64)."""
+    lib = _lib.load()
+    c0 = cls_outputs[0]
+    if c0.device.type != 'cuda':
+        raise RuntimeError('_post_process runs on the GPU only (no CPU fallback)')
+    B = c0.shape[0]
+    cls_all = _packed(cls_outputs, num_levels, num_classes)
+    box_all = _packed(box_outputs, num_levels, 4)
+    n_anchors = cls_all.shape[1]
+    k = max_detection_points
+    dt = 0 if cls_all.dtype == torch.float32 else 1
+    out_cls = torch.empty(B, k, 1, dtype=cls_all.dtype, device=c0.device)
+    out_box = torch.empty(B, k, 4, dtype=cls_all.dtype, device=c0.device)
+    idx = torch.empty(B, k, dtype=torch.int64, device=c0.device)
+    cls_id = torch.empty(B, k, dtype=torch.int64, device=c0.device)
+    ws_bytes = lib.effdet_topk_workspace_bytes(B)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=c0.device)
+    st = torch.cuda.current_stream(c0.device).cuda_stream
+    _lib.check(lib.effdet_topk_select(st, dt, cls_all.data_ptr(), B, n_anchors, num_classes, box_all.data_ptr(), k,
+                                      out_cls.data_ptr(), out_box.data_ptr(), idx.data_ptr(), cls_id.data_ptr(),
+                                      ws.data_ptr(), ws_bytes), 'effdet_topk_select')
+    return out_cls, out_box, idx, cls_id
+
+
+def _packed(outs, num_levels, width):
+    """[B, A*width, H, W] per level -> one contiguous [B, N, width] tensor (a view when possible)."""
+    B = outs[0].shape[0]
+    base = outs[0]._base if outs[0]._base is not None else None
+    if base is not None and base.dim() == 3 and base.shape[0] == B and base.shape[2] == width and base.is_contiguous():
+        n = sum(o.shape[1] * o.shape[2] * o.shape[3] for o in outs[:num_levels]) // width
+        if base.shape[1] == n and all(o._base is base for o in outs[:num_levels]) and outs[0].data_ptr() == base.data_ptr():
+            return base
+    if outs[0].dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError('head outputs must be float32 or bfloat16')
+    return torch.cat([outs[l].permute(0, 2, 3, 1).reshape(B, -1, width) for l in range(num_levels)], 1).contiguous()
+
+
+class DetBenchPredict(nn.Module):
+    def __init__(self, model):
+        super().__init__()
+        self.model = model
+        self.config = model.config
+        self.num_levels = model.config.num_levels
+        self.num_classes = model.config.num_classes
+        self.anchors = Anchors.from_config(model.config)
+        self.max_detection_points = model.config.max_detection_points
+        self.max_det_per_image = model.config.max_det_per_image
+        self.soft_nms = model.config.soft_nms
+        self.last_count = None
+        self.last_ood = None
+
+    def forward(self, x, img_info: Optional[Dict[str, torch.Tensor]] = None):
+        lib = _lib.load()
+        if tuple(x.shape[2:]) != tuple(self.anchors.image_size):
+            # the anchors follow the actual input size (the reference needs config.image_size == input size)
+            self.anchors = Anchors(self.config.min_level, self.config.max_level, self.config.num_scales,
+                                   self.config.aspect_ratios, self.config.anchor_scale, tuple(x.shape[2:])).to(x.device)
+        class_out, box_out = self.model(x)
+        cls_topk, box_topk, indices, classes = _post_process(
+            class_out, box_out, num_levels=self.num_levels, num_classes=self.num_classes,
+            max_detection_points=self.max_detection_points)
+        if img_info is None:
+            img_scale, img_size = None, None
+        else:
+            img_scale, img_size = img_info['img_scale'], img_info['img_size']
+        B, k = indices.shape
+        det, count, keep_src = batched_detections(
+            cls_topk.reshape(B, k), box_topk, self.anchors.boxes, indices, classes, img_scale, img_size,
+            max_det_per_image=self.max_det_per_image, soft_nms=self.soft_nms)
+        self.last_count = count
+        energy = torch.empty(B, self.max_det_per_image, dtype=torch.float32, device=x.device)
+        maxlogit = torch.empty_like(energy)
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(lib.effdet_gather_ood(st, keep_src.data_ptr(), indices.data_ptr(), self.model.ood_energy.data_ptr(),
+                                         self.model.ood_max_logit.data_ptr(), self.model.ood_energy.shape[1], B, k,
+                                         self.max_det_per_image, energy.data_ptr(), maxlogit.data_ptr()), 'effdet_gather_ood')
+        self.last_ood = {'energy': energy, 'max_logit': maxlogit, 'anchor_energy': self.model.ood_energy,
+                         'anchor_max_logit': self.model.ood_max_logit}
+        return det
+
+    def ragged(self, det):
+        """Per-image [n_i, 6] views, the shape the reference's generate_detections returns."""
+        counts = self.last_count.tolist()
+        return [det[i, :n] for i, n in enumerate(counts)]
+
+
+class DetBenchTrain(nn.Module):
+    """Training bench (effdet/bench.py:106-145): loss + anchor labelling are the pretrain path, which is
+    scheduled after the inference path (DESIGN.md 'next'); constructing it fails loudly."""
+
+    def __init__(self, model, create_labeler=True):
+        super().__init__()
+        raise NotImplementedError('DetBenchTrain (DetectionLoss / AnchorLabeler on HIP) is not built yet - see DESIGN.md')
+
+
+def unwrap_bench(model):
+    if hasattr(model, 'module'):
+        return unwrap_bench(model.module)
+    elif hasattr(model, 'model'):
+        return unwrap_bench(model.model)
+    return model

@@ -1,0 +1,442 @@
+"""Launch plan for the EfficientDet forward pass on libeffdet_hip.so.
+
+`Engine(model, B, image_size)` reads the model's parameters once, folds every BatchNorm into a
+per-channel (scale, shift) pair, repacks conv weights into the kernel layouts and records, for the
+three stages backbone / BiFPN / heads, a flat list of C-ABI calls on preallocated NHWC buffers.
+Running a stage replays that list on torch's current HIP stream (so a stage can be captured into a
+hipGraph with torch.cuda.graph).  PyTorch is used for device memory and streams only.
+
+Data layout in HBM
+  activations        NHWC, dtype = the model's parameter dtype (float32 parity / bfloat16 throughput)
+  pyramid features   one packed tensor [B, P, F] (P = sum_l H_l*W_l), level l at pixel offset off_l
+  class / box heads  [B, N, C] and [B, N, 4] with N = 9*P: exactly the concatenated layout that
+                     `_post_process` builds with permute/reshape/cat (effdet/bench.py:36-42)
+  OOD scores         energy, max_logit: [B, N] float32
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def _same_out(n, s):
+    return (n + s - 1) // s
+
+
+def _arr(ctype, values):
+    return (ctype * len(values))(*values)
+
+
+class Engine(object):
+    def __init__(self, model, B, image_size):
+        cfg = model.config
+        p0 = model.backbone.conv_stem.weight
+        if p0.device.type != 'cuda':
+            raise RuntimeError('the EfficientDet HIP path needs the model on a GPU (cuda:N); there is no CPU fallback')
+        if p0.dtype not in _DT:
+            raise RuntimeError('supported parameter dtypes: float32, bfloat16 (got %s)' % p0.dtype)
+        self.lib = _lib.load()
+        self.device, self.dtype, self.dt = p0.device, p0.dtype, _DT[p0.dtype]
+        self.B, self.image_size = B, tuple(image_size)
+        self.cfg = cfg
+        self.F = cfg.fpn_channels
+        self.C = cfg.num_classes
+        self.A = model.num_anchors
+        self.L = cfg.num_levels
+        self._keep = []          # tensors / ctypes arrays referenced by the launch lists
+        H, W = self.image_size
+        if H % (2 ** cfg.max_level) or W % (2 ** cfg.max_level):
+            raise ValueError('image size must be divisible by 2**max_level (reference: effdet/anchors.py:229-230)')
+        with torch.no_grad():
+            self._build_backbone(model.backbone, H, W)
+            self._build_fpn(model.fpn)
+            self._build_heads(model)
+
+    def matches(self, model):
+        p0 = model.backbone.conv_stem.weight
+        return p0.device == self.device and p0.dtype == self.dtype and model.config.num_classes == self.C
+
+    # ------------------------------------------------------------------------------------ utils
+    def _new(self, *shape, dtype=None):
+        t = torch.empty(*shape, dtype=dtype or self.dtype, device=self.device)
+        self._keep.append(t)
+        return t
+
+    def _f32(self, t):
+        t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        self._keep.append(t)
+        return t
+
+    def _w(self, t):
+        t = t.detach().to(device=self.device, dtype=self.dtype).contiguous()
+        self._keep.append(t)
+        return t
+
+    def _fold(self, bn, conv_bias=None):
+        """BatchNorm (eval) -> scale, shift with an optional preceding conv bias folded in."""
+        w, b = bn.weight.detach().float(), bn.bias.detach().float()
+        m, v = bn.running_mean.detach().float(), bn.running_var.detach().float()
+        scale = w / torch.sqrt(v + bn.eps)
+        shift = b - m * scale
+        if conv_bias is not None:
+            shift = shift + conv_bias.detach().float() * scale
+        return scale, shift
+
+    @staticmethod
+    def _dw_taps(w):          # [C,1,k,k] -> [k*k, C]
+        k = w.shape[-1]
+        return w.detach().float().permute(2, 3, 0, 1).reshape(k * k, w.shape[0])
+
+    def _run(self, plan):
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        for fn, args, what in plan:
+            rc = fn(st, *args)
+            if rc != 0:
+                raise RuntimeError('%s failed with code %d' % (what, rc))
+
+    # --------------------------------------------------------------------------------- backbone
+    def _build_backbone(self, bb, H, W):
+        lib, B, dt = self.lib, self.B, self.dt
+        stem_c, stages = bb.arch
+        plan = []
+        Hs, Ws = _same_out(H, 2), _same_out(W, 2)
+        # geometry pass: buffer sizes
+        io_max, mid_max, part_max = B * Hs * Ws * stem_c, 0, 0
+        h, w = Hs, Ws
+        for blocks in stages:
+            for b in blocks:
+                ho, wo = _same_out(h, b['s']), _same_out(w, b['s'])
+                if b['type'] == 'ir':
+                    mid_max = max(mid_max, B * h * w * b['mid'])
+                mid_max = max(mid_max, B * ho * wo * b['mid'])
+                nblk = lib.effdet_dwconv_blocks_per_image(ho, wo, b['mid'])
+                if nblk <= 0:
+                    raise NotImplementedError('depthwise width %d is outside the built range' % b['mid'])
+                part_max = max(part_max, B * nblk * b['mid'])
+                io_max = max(io_max, B * ho * wo * b['cout'])
+                h, w = ho, wo
+        ping = [self._new(io_max), self._new(io_max)]
+        ebuf, dbuf = self._new(max(mid_max, 1)), self._new(max(mid_max, 1))
+        partial = self._new(part_max, dtype=torch.float32)
+        gate_max = B * max(b['mid'] for blocks in stages for b in blocks)
+        gate = self._new(gate_max, dtype=torch.float32)
+
+        self.x_shape = (B, 3, H, W)
+        s, t = self._fold(bb.bn1)
+        wt = self._f32(bb.conv_stem.weight.detach().float().permute(2, 3, 1, 0).reshape(27, stem_c))
+        s, t = self._f32(s), self._f32(t)
+        self._stem = (wt, s, t, ping[0], H, W, stem_c)
+        cur = ping[0]
+        h, w = Hs, Ws
+        self.feats = []
+        for si, blocks in enumerate(stages):
+            for bi, b in enumerate(blocks):
+                m = bb.blocks[si][bi]
+                ho, wo = _same_out(h, b['s']), _same_out(w, b['s'])
+                last_of_feature_stage = (bi == len(blocks) - 1) and (si in (2, 4, 6))
+                if last_of_feature_stage:
+                    out = self._new(B, ho, wo, b['cout'])
+                    self.feats.append(out)
+                else:
+                    out = ping[1] if cur.data_ptr() == ping[0].data_ptr() else ping[0]
+                what = 'backbone.blocks.%d.%d' % (si, bi)
+                if b['type'] == 'ir':
+                    s1, t1 = self._fold(m.bn1)
+                    w1 = self._w(m.conv_pw.weight.reshape(b['mid'], b['cin']))
+                    s1, t1 = self._f32(s1), self._f32(t1)
+                    plan.append((lib.effdet_pw_gemm_bn_act,
+                                 (dt, cur.data_ptr(), B * h * w, b['cin'], w1.data_ptr(), b['mid'], s1.data_ptr(),
+                                  t1.data_ptr(), 1, None, None, 0, ebuf.data_ptr(), 0, 0), what + '.conv_pw'))
+                    dw_in, bn_dw, pw_out, bn_out = ebuf, m.bn2, m.conv_pwl, m.bn3
+                else:
+                    dw_in, bn_dw, pw_out, bn_out = cur, m.bn1, m.conv_pw, m.bn2
+                s2, t2 = self._fold(bn_dw)
+                taps = self._f32(self._dw_taps(m.conv_dw.weight))
+                s2, t2 = self._f32(s2), self._f32(t2)
+                nblk = lib.effdet_dwconv_blocks_per_image(ho, wo, b['mid'])
+                plan.append((lib.effdet_dwconv_bn_act,
+                             (dt, dw_in.data_ptr(), dbuf.data_ptr(), taps.data_ptr(), s2.data_ptr(), t2.data_ptr(), 1,
+                              partial.data_ptr(), B, h, w, b['mid'], b['k'], b['s']), what + '.conv_dw'))
+                W1 = self._f32(m.se.conv_reduce.weight.reshape(b['se'], b['mid']))
+                b1 = self._f32(m.se.conv_reduce.bias)
+                W2 = self._f32(m.se.conv_expand.weight.reshape(b['mid'], b['se']))
+                b2 = self._f32(m.se.conv_expand.bias)
+                plan.append((lib.effdet_se_gate,
+                             (partial.data_ptr(), nblk, ho * wo, W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(),
+                              gate.data_ptr(), B, b['mid'], b['se']), what + '.se'))
+                s3, t3 = self._fold(bn_out)
+                w3 = self._w(pw_out.weight.reshape(b['cout'], b['mid']))
+                s3, t3 = self._f32(s3), self._f32(t3)
+                plan.append((lib.effdet_pw_gemm_bn_act,
+                             (dt, dbuf.data_ptr(), B * ho * wo, b['mid'], w3.data_ptr(), b['cout'], s3.data_ptr(),
+                              t3.data_ptr(), 0, cur.data_ptr() if b['residual'] else None, gate.data_ptr(), ho * wo,
+                              out.data_ptr(), 0, 0), what + '.conv_pwl'))
+                cur, h, w = out, ho, wo
+        self._bb_plan = plan
+        self.feat_hw = [(f.shape[1], f.shape[2]) for f in self.feats]
+
+    def run_backbone(self, x):
+        if tuple(x.shape) != self.x_shape:
+            raise ValueError('engine was prepared for input %s, got %s' % (self.x_shape, tuple(x.shape)))
+        if x.device != self.device or x.dtype not in _DT:
+            raise RuntimeError('input must be a float32/bfloat16 tensor on %s' % (self.device,))
+        x = x.contiguous()
+        wt, s, t, out, H, W, c = self._stem
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self.lib.effdet_stem_conv(st, _DT[x.dtype], self.dt, x.data_ptr(), wt.data_ptr(), s.data_ptr(),
+                                             t.data_ptr(), out.data_ptr(), self.B, H, W, c), 'backbone.conv_stem')
+        self._run(self._bb_plan)
+        return [f.permute(0, 3, 1, 2) for f in self.feats]
+
+    # ------------------------------------------------------------------------------------- BiFPN
+    def _build_fpn(self, fpn):
+        lib, B, dt, F, cfg = self.lib, self.B, self.dt, self.F, self.cfg
+        plan = []
+        in_info = fpn.in_feature_info
+        nbb = len(in_info)
+        # level geometry
+        hw = list(self.feat_hw)
+        while len(hw) < self.L:
+            hw.append((_same_out(hw[-1][0], 2), _same_out(hw[-1][1], 2)))
+        self.level_hw = hw
+        offs, P = [], 0
+        for (h, w) in hw:
+            offs.append(P)
+            P += h * w
+        self.level_off, self.P = offs, P
+        self.pyr = self._new(B, P, F)
+
+        def dense(level):
+            h, w = hw[level]
+            return self._new(B, h, w, F)
+
+        # inputs of cell 0: backbone features (raw channels) + extra levels by conv+BN+maxpool / maxpool
+        self.fpn_in = list(self.feats)          # raw backbone maps, [B,h,w,c]
+        level_src = [None] * self.L             # (tensor, image_stride) of F-channel maps for levels >= nbb
+        prev_c = in_info[-1]['num_chs']
+        prev = self.feats[-1]
+        for level in range(nbb, self.L):
+            rs = fpn.resample[str(level)]
+            ph, pw_ = hw[level - 1]
+            src = prev
+            if prev_c != F:
+                conv = rs.conv
+                tmp = dense(level - 1)
+                wq = self._w(conv.conv.weight.reshape(F, prev_c))
+                if conv.bn is not None:
+                    s, t = self._fold(conv.bn, conv.conv.bias)
+                    s, t = self._f32(s), self._f32(t)
+                    sp = s.data_ptr()
+                else:
+                    t = self._f32(conv.conv.bias)
+                    sp = None
+                plan.append((lib.effdet_pw_gemm_bn_act,
+                             (dt, prev.data_ptr(), B * ph * pw_, prev_c, wq.data_ptr(), F, sp, t.data_ptr(), 0, None, None, 0,
+                              tmp.data_ptr(), 0, 0), 'fpn.resample.%d.conv' % level))
+                src = tmp
+            out = dense(level)
+            plan.append((lib.effdet_maxpool_same, (dt, src.data_ptr(), 0, out.data_ptr(), 0, B, ph, pw_, F),
+                         'fpn.resample.%d.downsample' % level))
+            level_src[level] = out
+            prev, prev_c = out, F
+
+        nodes = fpn.fpn_config.nodes
+        node_red = [n['reduction'] for n in nodes]
+        n_cells = len(fpn.cell)
+        red0 = in_info[0]['reduction']
+
+        def level_of(reduction):
+            return int(round(math.log2(reduction / red0)))
+
+        x = []
+        for i in range(nbb):
+            x.append(dict(raw=True, t=self.feats[i], chs=in_info[i]['num_chs'], level=i))
+        for level in range(nbb, self.L):
+            x.append(dict(raw=False, ptr=level_src[level].data_ptr(), stride=hw[level][0] * hw[level][1] * F, level=level))
+
+        for ci in range(n_cells):
+            layer = fpn.cell[ci]
+            last_cell = ci == n_cells - 1
+            for ni, node in enumerate(nodes):
+                fn = layer.fnode[ni]
+                lvl = level_of(node['reduction'])
+                h, w = hw[lvl]
+                ins = []
+                for off in node['inputs_offsets']:
+                    src = x[off]
+                    if src.get('raw'):
+                        # lateral 1x1 conv + BN of a backbone feature (own weights per use)
+                        rs = fn.combine.resample[str(off)]
+                        conv = rs.conv
+                        lat = dense(src['level'])
+                        sh, sw = hw[src['level']]
+                        wq = self._w(conv.conv.weight.reshape(F, src['chs']))
+                        if conv.bn is not None:
+                            s, t = self._fold(conv.bn, conv.conv.bias)
+                            s, t = self._f32(s), self._f32(t)
+                            sp = s.data_ptr()
+                        else:
+                            t = self._f32(conv.conv.bias)
+                            sp = None
+                        plan.append((lib.effdet_pw_gemm_bn_act,
+                                     (dt, src['t'].data_ptr(), B * sh * sw, src['chs'], wq.data_ptr(), F, sp, t.data_ptr(), 0,
+                                      None, None, 0, lat.data_ptr(), 0, 0),
+                                     'fpn.cell.%d.fnode.%d.combine.resample.%d.conv' % (ci, ni, off)))
+                        src = dict(raw=False, ptr=lat.data_ptr(), stride=sh * sw * F, level=src['level'])
+                    d = src['level'] - lvl
+                    mode = 0 if d == 0 else (1 if d == 1 else (2 if d == -1 else None))
+                    if mode is None:
+                        raise NotImplementedError('BiFPN edge spanning %d levels' % d)
+                    ins.append((src['ptr'], src['stride'], hw[src['level']], mode))
+                # fusion weights, computed like FpnCombine.forward (efficientdet.py:232-244)
+                method = node['weight_method']
+                if method == 'fastattn':
+                    ew = torch.relu(fn.combine.edge_weights.detach().float())
+                    den = float((ew.sum() + 0.0001).item())
+                    fuse_mode, fw = 1, [float(v) for v in ew.tolist()]
+                elif method == 'attn':
+                    ew = torch.softmax(fn.combine.edge_weights.detach().float(), dim=0)
+                    fuse_mode, fw, den = 2, [float(v) for v in ew.tolist()], 1.0
+                else:
+                    fuse_mode, fw, den = 2, [1.0] * len(ins), 1.0
+                sc = fn.after_combine.conv
+                taps = self._f32(self._dw_taps(sc.conv_dw.weight))
+                wq = self._w(sc.conv_pw.weight.reshape(F, F))
+                s, t = self._fold(sc.bn, sc.conv_pw.bias)
+                s, t = self._f32(s), self._f32(t)
+                if last_cell and ni >= len(nodes) - self.L:
+                    out_ptr = self.pyr.data_ptr() + self.level_off[lvl] * F * self.pyr.element_size()
+                    out_stride = P * F
+                else:
+                    o = dense(lvl)
+                    out_ptr, out_stride = o.data_ptr(), h * w * F
+                plan.append(self._sepconv_call(
+                    [(h, w)], [ins], fuse_mode, fw, den, 1, taps, wq, s, t, [0], 0, F, F,
+                    [out_ptr], [out_stride], 'fpn.cell.%d.fnode.%d' % (ci, ni)))
+                x.append(dict(raw=False, ptr=out_ptr, stride=out_stride, level=lvl))
+            x = x[-self.L:]
+        self._fpn_plan = plan
+
+    def _sepconv_call(self, level_hw, level_inputs, fuse_mode, fw, den, pre_act, taps, wq, scale, shift, affine_rows,
+                      post_act, F, N, out_ptrs, out_strides, what, ood=None):
+        nl, n_in = len(level_hw), len(level_inputs[0])
+        c_hw = _arr(ctypes.c_int, [v for hw in level_hw for v in hw])
+        c_ptr = _arr(ctypes.c_void_p, [i[0] for lv in level_inputs for i in lv])
+        c_str = _arr(ctypes.c_longlong, [i[1] for lv in level_inputs for i in lv])
+        c_ihw = _arr(ctypes.c_int, [v for lv in level_inputs for i in lv for v in i[2]])
+        c_mode = _arr(ctypes.c_int, [i[3] for lv in level_inputs for i in lv])
+        c_fw = _arr(ctypes.c_float, list(fw) + [0.0] * (3 - len(fw)))
+        c_aff = _arr(ctypes.c_int, affine_rows)
+        c_out = _arr(ctypes.c_void_p, out_ptrs)
+        c_ostr = _arr(ctypes.c_longlong, out_strides)
+        if ood is None:
+            ood_args = (0, self.A, None, None, 0, None)
+        else:
+            c_ooff = _arr(ctypes.c_longlong, ood['level_off'])
+            self._keep.append(c_ooff)
+            ood_args = (ood['classes'], self.A, ood['energy'].data_ptr(), ood['maxlogit'].data_ptr(), ood['stride'], c_ooff)
+        self._keep += [c_hw, c_ptr, c_str, c_ihw, c_mode, c_fw, c_aff, c_out, c_ostr]
+        args = (self.dt, self.B, nl, c_hw, n_in, c_ptr, c_str, c_ihw, c_mode, fuse_mode, c_fw, ctypes.c_float(den), pre_act,
+                taps.data_ptr(), wq.data_ptr(), scale.data_ptr() if scale is not None else None, shift.data_ptr(),
+                c_aff, post_act, F, N, c_out, c_ostr) + ood_args
+        return (self.lib.effdet_sepconv_fused, args, what)
+
+    def _load_feature_list(self, xs, dst_tensors):
+        for src, dst in zip(xs, dst_tensors):
+            if src.device != self.device:
+                raise RuntimeError('feature maps must live on %s' % (self.device,))
+            dst.copy_(src.permute(0, 2, 3, 1))
+
+    def pyramid_views(self):
+        out = []
+        for (h, w), off in zip(self.level_hw, self.level_off):
+            out.append(self.pyr[:, off:off + h * w, :].unflatten(1, (h, w)).permute(0, 3, 1, 2))
+        return out
+
+    def run_fpn(self, feats):
+        if feats is not None:
+            if len(feats) != len(self.feats):
+                raise ValueError('expected %d backbone feature maps' % len(self.feats))
+            self._load_feature_list(feats, self.feats)
+        self._run(self._fpn_plan)
+        return self.pyramid_views()
+
+    # ------------------------------------------------------------------------------------- heads
+    def _build_heads(self, model):
+        lib, B, dt, F, cfg = self.lib, self.B, self.dt, self.F, self.cfg
+        A, C, L, P = self.A, self.C, self.L, self.P
+        N = A * P
+        self.N = N
+        self.cls_all = self._new(B, N, C)
+        self.box_all = self._new(B, N, 4)
+        self.ood_energy = self._new(B, N, dtype=torch.float32)
+        self.ood_max_logit = self._new(B, N, dtype=torch.float32)
+        t1, t2 = self._new(B, P, F), self._new(B, P, F)
+        es = self.pyr.element_size()
+
+        def level_ptrs(t, width):
+            return [t.data_ptr() + off * width * es for off in self.level_off]
+
+        def plan_for(head, name, out_t, K, ood):
+            plan = []
+            src = self.pyr
+            bufs = [t1, t2]
+            for r in range(cfg.box_class_repeats):
+                conv = head.conv_rep[r]
+                taps = self._f32(self._dw_taps(conv.conv_dw.weight))
+                wq = self._w(conv.conv_pw.weight.reshape(F, F))
+                ss, ts = [], []
+                for l in range(L):
+                    s, t = self._fold(head.bn_rep[r][l].bn, conv.conv_pw.bias)
+                    ss.append(s)
+                    ts.append(t)
+                s, t = self._f32(torch.stack(ss)), self._f32(torch.stack(ts))
+                dst = bufs[r % 2]
+                ins = [[(p, P * F, hw, 0)] for p, hw in zip(level_ptrs(src, F), self.level_hw)]
+                plan.append(self._sepconv_call(self.level_hw, ins, 0, [], 1.0, 0, taps, wq, s, t, list(range(L)), 1, F, F,
+                                               level_ptrs(dst, F), [P * F] * L, '%s.conv_rep.%d' % (name, r)))
+                src = dst
+            conv = head.predict
+            NO = A * K
+            taps = self._f32(self._dw_taps(conv.conv_dw.weight))
+            wq = self._w(conv.conv_pw.weight.reshape(NO, F))
+            t = self._f32(conv.conv_pw.bias.detach().float().reshape(1, NO))
+            ins = [[(p, P * F, hw, 0)] for p, hw in zip(level_ptrs(src, F), self.level_hw)]
+            outs = [out_t.data_ptr() + off * NO * es for off in self.level_off]
+            oodd = None
+            if ood:
+                oodd = dict(classes=K, energy=self.ood_energy, maxlogit=self.ood_max_logit, stride=N,
+                            level_off=[off * A for off in self.level_off])
+            plan.append(self._sepconv_call(self.level_hw, ins, 0, [], 1.0, 0, taps, wq, None, t, [0] * L, 0, F, NO,
+                                           outs, [P * NO] * L, '%s.predict' % name, ood=oodd))
+            return plan
+
+        self._cls_plan = plan_for(model.class_net, 'class_net', self.cls_all, C, True)
+        self._box_plan = plan_for(model.box_net, 'box_net', self.box_all, 4, False)
+
+    def head_views(self, t, K):
+        out = []
+        A = self.A
+        for (h, w), off in zip(self.level_hw, self.level_off):
+            v = t[:, off * A:(off + h * w) * A, :].reshape(self.B, h, w, A * K)
+            out.append(v.permute(0, 3, 1, 2))
+        return out
+
+    def run_heads(self, activs, want_cls, want_box):
+        if activs is not None:
+            if len(activs) != self.L:
+                raise ValueError('expected %d pyramid levels' % self.L)
+            for src, (h, w), off in zip(activs, self.level_hw, self.level_off):
+                self.pyr[:, off:off + h * w, :].copy_(src.permute(0, 2, 3, 1).reshape(self.B, h * w, self.F))
+        cls_o = box_o = None
+        if want_cls:
+            self._run(self._cls_plan)
+            cls_o = self.head_views(self.cls_all, self.C)
+        if want_box:
+            self._run(self._box_plan)
+            box_o = self.head_views(self.box_all, 4)
+        return cls_o, box_o

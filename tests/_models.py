@@ -1,0 +1,23 @@
+"""Shared model builders for tests / smoke / bench: seeded weights for product model + oracle."""
+import torch
+
+from _seeded import seeded_tensor
+
+
+def seeded_model(name='tf_efficientdet_d0', image_size=256, num_classes=90, seed=3, cls_bias=None, soft_nms=False):
+    from ood_object_detection_amd.effdet.config import get_efficientdet_config, get_fpn_config
+    from ood_object_detection_amd.effdet.efficientdet import EfficientDet
+    cfg = get_efficientdet_config(name)
+    cfg.image_size = (image_size, image_size)
+    cfg.num_classes = num_classes
+    cfg.soft_nms = soft_nms
+    model = EfficientDet(cfg, pretrained_backbone=False).eval()
+    sd = model.state_dict()
+    new = {}
+    for k, v in sd.items():
+        new[k] = v if k.endswith('num_batches_tracked') else seeded_tensor(seed, k, v.shape)
+    if cls_bias is not None:
+        new['class_net.predict.conv_pw.bias'] = torch.full_like(new['class_net.predict.conv_pw.bias'], cls_bias)
+    model.load_state_dict(new, strict=True)
+    nodes = get_fpn_config(cfg.fpn_name, cfg.min_level, cfg.max_level).nodes
+    return model, cfg, nodes, {k: v.clone() for k, v in new.items()}

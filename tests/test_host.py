@@ -1,0 +1,137 @@
+"""Host-side logic (no GPU): config tables, anchors, state-dict layout, C ABI exports."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _norm(v):
+    if isinstance(v, (list, tuple)):
+        return [_norm(x) for x in v]
+    if isinstance(v, dict):
+        return {k: _norm(x) for k, x in v.items()}
+    return v
+
+
+@pytest.mark.parametrize('name', ['tf_efficientdet_d0', 'tf_efficientdet_d1', 'tf_efficientdet_d2', 'tf_efficientdet_d3',
+                                  'tf_efficientdet_d4', 'tf_efficientdet_d5'])
+def test_config_matches_reference(golden, name):
+    from ood_object_detection_amd.effdet.config import get_efficientdet_config
+    ref = json.loads(str(golden('config')[name]))
+    h = get_efficientdet_config(name)
+    assert sorted(h.keys()) == sorted(ref.keys())
+    for k in ref:
+        assert _norm(h[k]) == _norm(ref[k]), k
+
+
+def test_unknown_model_raises_keyerror():
+    from ood_object_detection_amd.effdet.config import get_efficientdet_config
+    with pytest.raises(KeyError):
+        get_efficientdet_config('nope')
+
+
+def test_bifpn_graph_matches_reference(golden):
+    from ood_object_detection_amd.effdet.config import get_fpn_config
+    g = golden('config')
+    for key, (name, lo, hi) in {'bifpn_fa_3_7': ('bifpn_fa', 3, 7), 'bifpn_sum_3_8': ('bifpn_sum', 3, 8)}.items():
+        ref = json.loads(str(g[key]))
+        got = [dict(n) for n in get_fpn_config(name, lo, hi).nodes]
+        assert _norm(got) == _norm(ref)
+
+
+@pytest.mark.parametrize('size', [128, 512, 640, 768, 1024])
+def test_product_anchors_bit_exact(golden, size):
+    import hashlib
+    from ood_object_detection_amd.effdet.anchors import Anchors
+    g = golden('anchors')
+    b = Anchors(3, 7, 3, [(1.0, 1.0), (1.4, 0.7), (0.7, 1.4)], 4.0, (size, size)).boxes
+    assert hashlib.sha256(b.numpy().tobytes()).digest() == g['sha256_%d' % size].tobytes()
+
+
+def test_product_anchors_odd(golden):
+    from ood_object_detection_amd.effdet.anchors import Anchors
+    b = Anchors(3, 6, 2, [1.0, 2.0, 0.5], [4.0, 3.0, 4.0, 5.0], (128, 256)).boxes
+    assert np.array_equal(b.numpy(), golden('anchors')['odd_full'])
+    with pytest.raises(AssertionError):
+        Anchors(3, 7, 3, [(1.0, 1.0)], 4.0, (100, 128))
+
+
+@pytest.mark.parametrize('tag,name', [('d0', 'tf_efficientdet_d0'), ('d1', 'tf_efficientdet_d1')])
+def test_state_dict_layout_matches_reference(golden, tag, name):
+    """fpn.* / class_net.* / box_net.* keys and shapes equal the reference module tree's."""
+    from ood_object_detection_amd.effdet.config import get_efficientdet_config
+    from ood_object_detection_amd.effdet.efficientdet import EfficientDet
+    g = golden('bifpn_head')
+    size, ncls, _ = [int(v) for v in g[tag + '_meta']]
+    cfg = get_efficientdet_config(name)
+    cfg.image_size = (size, size)
+    cfg.num_classes = ncls
+    sd = EfficientDet(cfg, pretrained_backbone=False).state_dict()
+    mine = {k: list(v.shape) for k, v in sd.items() if not k.endswith('num_batches_tracked')}
+    ref = {str(k): json.loads(str(s)) for k, s in zip(g[tag + '_keys'], g[tag + '_shapes'])}
+    assert mine == ref
+    assert list(mine.keys()) == list(ref.keys())       # same order too
+
+
+def test_reset_head_and_param_count():
+    from ood_object_detection_amd.effdet.factory import create_model
+    m = create_model('tf_efficientdet_d0', num_classes=90)
+    assert m.class_net.predict.conv_pw.weight.shape == (810, 64, 1, 1)
+    assert abs(float(m.class_net.predict.conv_pw.bias[0]) + np.log(99.0)) < 1e-6
+    n = sum(p.numel() for p in m.parameters())
+    assert 3.8e6 < n < 3.95e6                           # d0 ~ 3.9 M parameters
+
+
+def test_backbone_arch_tables():
+    from ood_object_detection_amd.backbone import efficientnet_arch
+    feats = {}
+    for name in ('tf_efficientnet_b0', 'tf_efficientnet_b2', 'tf_efficientnet_b4'):
+        stem, stages = efficientnet_arch(name)
+        feats[name] = [stages[i][-1]['cout'] for i in (2, 4, 6)]
+    # SURVEY §8 a3
+    assert feats == {'tf_efficientnet_b0': [40, 112, 320], 'tf_efficientnet_b2': [48, 120, 352],
+                     'tf_efficientnet_b4': [56, 160, 448]}
+
+
+def test_product_has_no_cpu_fallback():
+    """CPU tensors must fail loudly, never silently compute."""
+    from ood_object_detection_amd.effdet.factory import create_model
+    from ood_object_detection_amd.effdet.bench import _post_process
+    m = create_model('tf_efficientdet_d0', num_classes=3, image_size=(128, 128))
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 128, 128))
+    with pytest.raises(RuntimeError):
+        _post_process([torch.zeros(1, 27, 4, 4)], [torch.zeros(1, 36, 4, 4)], 1, 3, 10)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, 'ood_object_detection_amd')
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', src, re.M), f
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """libeffdet_hip.so loads on a GPU-less host and exports exactly what include/effdet_hip.h declares."""
+    from ood_object_detection_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    header = open(os.path.join(ROOT, 'include', 'effdet_hip.h')).read()
+    declared = set(re.findall(r'\b(effdet_[a-z0-9_]+)\s*\(', header))
+    assert declared == set(_lib.SIGNATURES.keys())
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.effdet_abi_version() == 1
+    # pure-host helpers are callable without a GPU
+    assert lib.effdet_dwconv_blocks_per_image(80, 80, 240) > 0
+    lib.effdet_topk_workspace_bytes.restype = ctypes.c_longlong
+    assert lib.effdet_topk_workspace_bytes(4) > 4 * 16384 * 8
