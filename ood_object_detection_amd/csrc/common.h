@@ -16,6 +16,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define DEV __device__ __forceinline__
 
+// Other HIP users of the process (e.g. the host framework probing a pointer) can leave a stale,
+// non-fatal error code behind; drop it on entry so effdet_check_launch() reports only our launch.
+#define EFFDET_ENTER() (void)hipGetLastError()
+
 static inline int effdet_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? EFFDET_OK : EFFDET_ELAUNCH;

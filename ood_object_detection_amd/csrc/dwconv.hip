@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(PoolArgs p) {
 extern "C" int effdet_stem_conv(void* stream, int in_dtype, int out_dtype,
                                 const void* X, const float* Wt, const float* scale, const float* shift,
                                 void* Y, int B, int H, int W, int Cout) {
+    EFFDET_ENTER();
     if (!X || !Wt || !scale || !shift || !Y || B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout % 8) return EFFDET_EINVAL;
     if ((in_dtype | out_dtype) & ~1) return EFFDET_EINVAL;
     StemArgs a{X, in_dtype, Wt, scale, shift, Y, B, H, W, Cout, same_out(H, 2), same_out(W, 2),
@@ -244,6 +245,7 @@ extern "C" int effdet_dwconv_bn_act(void* stream, int dtype, const void* X, void
                                     const float* scale, const float* shift, int act,
                                     float* pool_partial,
                                     int B, int H, int W, int C, int k, int stride) {
+    EFFDET_ENTER();
     if (!X || !Y || !Wt || !scale || !shift || B <= 0 || H <= 0 || W <= 0) return EFFDET_EINVAL;
     if (C <= 0 || C % 8 || C / 8 > 256 || (k != 3 && k != 5) || (stride != 1 && stride != 2)) return EFFDET_EINVAL;
     if ((dtype & ~1) || (act & ~1)) return EFFDET_EINVAL;
@@ -274,6 +276,7 @@ extern "C" int effdet_dwconv_bn_act(void* stream, int dtype, const void* X, void
 extern "C" int effdet_se_gate(void* stream, const float* partial, int nblk, int hw,
                               const float* W1, const float* b1, const float* W2, const float* b2,
                               float* gate, int B, int C, int R) {
+    EFFDET_ENTER();
     if (!partial || !W1 || !b1 || !W2 || !b2 || !gate || nblk <= 0 || hw <= 0 || B <= 0 || C <= 0 || R <= 0) return EFFDET_EINVAL;
     SeArgs a{partial, nblk, 1.0f / (float)hw, W1, b1, W2, b2, gate, C, R};
     const size_t sh = (size_t)(C + R) * sizeof(float);
@@ -284,6 +287,7 @@ extern "C" int effdet_se_gate(void* stream, const float* partial, int nblk, int 
 
 extern "C" int effdet_maxpool_same(void* stream, int dtype, const void* X, long long x_image_stride,
                                    void* Y, long long y_image_stride, int B, int H, int W, int C) {
+    EFFDET_ENTER();
     if (!X || !Y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || (dtype & ~1)) return EFFDET_EINVAL;
     PoolArgs a{X, Y, x_image_stride, y_image_stride, B, H, W, C, same_out(H, 2), same_out(W, 2),
                same_pad_before(H, 3, 2), same_pad_before(W, 3, 2)};

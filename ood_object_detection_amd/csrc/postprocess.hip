@@ -487,6 +487,7 @@ extern "C" int effdet_topk_select(void* stream, int dtype, const void* cls_all, 
                                   const void* box_all, int k,
                                   void* out_cls, void* out_box, long long* out_indices, long long* out_classes,
                                   void* workspace, long long workspace_bytes) {
+    EFFDET_ENTER();
     const long long L = n_anchors * (long long)C;
     if (!cls_all || !out_cls || !out_indices || !out_classes || !workspace || B <= 0 || C <= 0 || n_anchors <= 0) return EFFDET_EINVAL;
     if (k <= 0 || k > TOPK_CAP || k > L || L > 0x7fffffffLL || (dtype & ~1)) return EFFDET_EINVAL;
@@ -527,6 +528,7 @@ extern "C" int effdet_decode_threshold(void* stream, int dtype, const void* cls_
                                        const float* anchors, const long long* indices, const long long* classes,
                                        const float* img_scale, const float* img_size, int B, int k,
                                        float* boxes, float* scores, int* classes_out, int* src, int* count, float* maxcoord) {
+    EFFDET_ENTER();
     if (!cls_topk || !box_topk || !anchors || !indices || !classes || !boxes || !scores || !classes_out || !src || !count || !maxcoord) return EFFDET_EINVAL;
     if (B <= 0 || k <= 0 || (dtype & ~1)) return EFFDET_EINVAL;
     DecodeArgs a{cls_topk, box_topk, dtype, anchors, indices, classes, img_scale, img_size, k, boxes, scores, classes_out, src, count, maxcoord};
@@ -547,6 +549,7 @@ static int nms_common(NmsArgs& a, int B, bool soft, void* stream) {
 extern "C" int effdet_nms_hard(void* stream, const float* boxes, const float* scores, const int* classes, const int* src,
                                const int* count, const float* maxcoord, int B, int k, double iou_threshold, int max_det,
                                const float* img_scale, float* det, int* det_count, int* keep_src) {
+    EFFDET_ENTER();
     NmsArgs a{boxes, scores, classes, src, count, maxcoord, k, iou_threshold, max_det, img_scale, det, det_count, keep_src, 1, 0.5f, 0.3f, 0.001f};
     return nms_common(a, B, false, stream);
 }
@@ -555,6 +558,7 @@ extern "C" int effdet_nms_soft(void* stream, const float* boxes, const float* sc
                                const int* count, const float* maxcoord, int B, int k,
                                int method_gaussian, float sigma, float iou_threshold, float score_threshold, int max_det,
                                const float* img_scale, float* det, int* det_count, int* keep_src) {
+    EFFDET_ENTER();
     if (!(sigma > 0.f)) return EFFDET_EINVAL;
     NmsArgs a{boxes, scores, classes, src, count, maxcoord, k, (double)iou_threshold, max_det, img_scale, det, det_count, keep_src,
               method_gaussian ? 1 : 0, sigma, iou_threshold, score_threshold};
@@ -564,6 +568,7 @@ extern "C" int effdet_nms_soft(void* stream, const float* boxes, const float* sc
 extern "C" int effdet_gather_ood(void* stream, const int* keep_src, const long long* indices, const float* energy,
                                  const float* maxlogit, long long n_anchors, int B, int k, int max_det,
                                  float* out_energy, float* out_maxlogit) {
+    EFFDET_ENTER();
     if (!keep_src || !indices || !energy || !maxlogit || !out_energy || !out_maxlogit || B <= 0 || k <= 0 || max_det <= 0) return EFFDET_EINVAL;
     const int total = B * max_det;
     hipLaunchKernelGGL(gather_ood_kernel, dim3((total + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),

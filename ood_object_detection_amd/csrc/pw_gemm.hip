@@ -226,6 +226,7 @@ extern "C" int effdet_pw_gemm_bn_act(void* stream, int dtype,
                                      const void* residual,
                                      const float* gate, int rows_per_image,
                                      void* C, long long c_image_stride, long long ldc) {
+    EFFDET_ENTER();
     if (!A || !W || !C || !shift || M <= 0 || K <= 0 || N <= 0) return EFFDET_EINVAL;
     if (K % 8 != 0) return EFFDET_EINVAL;                 // 16-byte pieces along K
     if (act != 0 && act != 1) return EFFDET_EINVAL;

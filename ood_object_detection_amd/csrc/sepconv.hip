@@ -339,6 +339,7 @@ extern "C" int effdet_sepconv_fused(
     void* const* out_ptr, const long long* out_image_stride,   // [nlevels]
     int ood_classes, int num_anchors, float* ood_energy, float* ood_maxlogit,
     long long ood_image_stride, const long long* ood_level_off) {
+    EFFDET_ENTER();
     if (nlevels < 1 || nlevels > 5 || n_in < 1 || n_in > 3 || B <= 0) return EFFDET_EINVAL;
     if (!level_hw || !in_ptr || !in_image_stride || !in_hw || !in_mode || !dw_w || !pw_w || !shift || !affine_row ||
         !out_ptr || !out_image_stride) return EFFDET_EINVAL;

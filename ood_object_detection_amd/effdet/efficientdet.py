@@ -290,6 +290,12 @@ class EfficientDet(nn.Module):
         self._engine = None
         return super()._apply(fn, *a, **k)
 
+    def __getstate__(self):
+        # the engine holds device buffers and ctypes arrays: never copied / pickled, rebuilt on demand
+        d = self.__dict__.copy()
+        d['_engine'] = None
+        return d
+
     def prepare(self, batch_size, image_size=None):
         """Fold BN, repack weights to the kernel layouts and build the launch plan."""
         from ..engine import Engine

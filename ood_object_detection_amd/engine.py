@@ -48,6 +48,7 @@ class Engine(object):
         self.A = model.num_anchors
         self.L = cfg.num_levels
         self._keep = []          # tensors / ctypes arrays referenced by the launch lists
+        self.pyr_es = torch.empty(0, dtype=self.dtype).element_size()
         H, W = self.image_size
         if H % (2 ** cfg.max_level) or W % (2 ** cfg.max_level):
             raise ValueError('image size must be divisible by 2**max_level (reference: effdet/anchors.py:229-230)')
@@ -93,10 +94,32 @@ class Engine(object):
 
     def _run(self, plan):
         st = torch.cuda.current_stream(self.device).cuda_stream
-        for fn, args, what in plan:
+        for fn, args, what, _meta in plan:
             rc = fn(st, *args)
             if rc != 0:
                 raise RuntimeError('%s failed with code %d' % (what, rc))
+
+    def _gemm_meta(self, M, K, N, residual=False, gate=False):
+        es = self.pyr_es
+        b = (M * K + M * N + N * K) * es + (M * N * es if residual else 0) + (self.B * K * 4 if gate else 0)
+        return dict(kind='pw_gemm', bytes=b, flops=2 * M * K * N)
+
+    def profile(self, reps=5):
+        """Per-launch device time of every recorded launch (HIP events on the launch stream).
+        Returns [(what, kind, algorithmic_bytes, flops, ms)]; call after a forward so buffers are live."""
+        st = torch.cuda.current_stream(self.device)
+        out = []
+        for plan in (self._bb_plan, self._fpn_plan, self._cls_plan, self._box_plan):
+            for fn, args, what, meta in plan:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                fn(st.cuda_stream, *args)
+                e0.record(st)
+                for _ in range(reps):
+                    fn(st.cuda_stream, *args)
+                e1.record(st)
+                e1.synchronize()
+                out.append((what, meta['kind'], meta['bytes'], meta['flops'], e0.elapsed_time(e1) / reps))
+        return out
 
     # --------------------------------------------------------------------------------- backbone
     def _build_backbone(self, bb, H, W):
@@ -150,7 +173,8 @@ class Engine(object):
                     s1, t1 = self._f32(s1), self._f32(t1)
                     plan.append((lib.effdet_pw_gemm_bn_act,
                                  (dt, cur.data_ptr(), B * h * w, b['cin'], w1.data_ptr(), b['mid'], s1.data_ptr(),
-                                  t1.data_ptr(), 1, None, None, 0, ebuf.data_ptr(), 0, 0), what + '.conv_pw'))
+                                  t1.data_ptr(), 1, None, None, 0, ebuf.data_ptr(), 0, 0), what + '.conv_pw',
+                                 self._gemm_meta(B * h * w, b['cin'], b['mid'])))
                     dw_in, bn_dw, pw_out, bn_out = ebuf, m.bn2, m.conv_pwl, m.bn3
                 else:
                     dw_in, bn_dw, pw_out, bn_out = cur, m.bn1, m.conv_pw, m.bn2
@@ -160,21 +184,26 @@ class Engine(object):
                 nblk = lib.effdet_dwconv_blocks_per_image(ho, wo, b['mid'])
                 plan.append((lib.effdet_dwconv_bn_act,
                              (dt, dw_in.data_ptr(), dbuf.data_ptr(), taps.data_ptr(), s2.data_ptr(), t2.data_ptr(), 1,
-                              partial.data_ptr(), B, h, w, b['mid'], b['k'], b['s']), what + '.conv_dw'))
+                              partial.data_ptr(), B, h, w, b['mid'], b['k'], b['s']), what + '.conv_dw',
+                             dict(kind='dwconv', bytes=B * (h * w + ho * wo) * b['mid'] * self.pyr_es,
+                                  flops=2 * b['k'] * b['k'] * B * ho * wo * b['mid'])))
                 W1 = self._f32(m.se.conv_reduce.weight.reshape(b['se'], b['mid']))
                 b1 = self._f32(m.se.conv_reduce.bias)
                 W2 = self._f32(m.se.conv_expand.weight.reshape(b['mid'], b['se']))
                 b2 = self._f32(m.se.conv_expand.bias)
                 plan.append((lib.effdet_se_gate,
                              (partial.data_ptr(), nblk, ho * wo, W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(),
-                              gate.data_ptr(), B, b['mid'], b['se']), what + '.se'))
+                              gate.data_ptr(), B, b['mid'], b['se']), what + '.se',
+                             dict(kind='se_gate', bytes=B * (nblk + 1) * b['mid'] * 4 + 8 * b['mid'] * b['se'],
+                                  flops=4 * B * b['mid'] * b['se'])))
                 s3, t3 = self._fold(bn_out)
                 w3 = self._w(pw_out.weight.reshape(b['cout'], b['mid']))
                 s3, t3 = self._f32(s3), self._f32(t3)
                 plan.append((lib.effdet_pw_gemm_bn_act,
                              (dt, dbuf.data_ptr(), B * ho * wo, b['mid'], w3.data_ptr(), b['cout'], s3.data_ptr(),
                               t3.data_ptr(), 0, cur.data_ptr() if b['residual'] else None, gate.data_ptr(), ho * wo,
-                              out.data_ptr(), 0, 0), what + '.conv_pwl'))
+                              out.data_ptr(), 0, 0), what + '.conv_pwl',
+                             self._gemm_meta(B * ho * wo, b['mid'], b['cout'], residual=b['residual'], gate=True)))
                 cur, h, w = out, ho, wo
         self._bb_plan = plan
         self.feat_hw = [(f.shape[1], f.shape[2]) for f in self.feats]
@@ -236,11 +265,12 @@ class Engine(object):
                     sp = None
                 plan.append((lib.effdet_pw_gemm_bn_act,
                              (dt, prev.data_ptr(), B * ph * pw_, prev_c, wq.data_ptr(), F, sp, t.data_ptr(), 0, None, None, 0,
-                              tmp.data_ptr(), 0, 0), 'fpn.resample.%d.conv' % level))
+                              tmp.data_ptr(), 0, 0), 'fpn.resample.%d.conv' % level, self._gemm_meta(B * ph * pw_, prev_c, F)))
                 src = tmp
             out = dense(level)
             plan.append((lib.effdet_maxpool_same, (dt, src.data_ptr(), 0, out.data_ptr(), 0, B, ph, pw_, F),
-                         'fpn.resample.%d.downsample' % level))
+                         'fpn.resample.%d.downsample' % level,
+                         dict(kind='maxpool', bytes=B * (ph * pw_ + hw[level][0] * hw[level][1]) * F * self.pyr_es, flops=0)))
             level_src[level] = out
             prev, prev_c = out, F
 
@@ -285,7 +315,8 @@ class Engine(object):
                         plan.append((lib.effdet_pw_gemm_bn_act,
                                      (dt, src['t'].data_ptr(), B * sh * sw, src['chs'], wq.data_ptr(), F, sp, t.data_ptr(), 0,
                                       None, None, 0, lat.data_ptr(), 0, 0),
-                                     'fpn.cell.%d.fnode.%d.combine.resample.%d.conv' % (ci, ni, off)))
+                                     'fpn.cell.%d.fnode.%d.combine.resample.%d.conv' % (ci, ni, off),
+                                     self._gemm_meta(B * sh * sw, src['chs'], F)))
                         src = dict(raw=False, ptr=lat.data_ptr(), stride=sh * sw * F, level=src['level'])
                     d = src['level'] - lvl
                     mode = 0 if d == 0 else (1 if d == 1 else (2 if d == -1 else None))
@@ -343,7 +374,13 @@ class Engine(object):
         args = (self.dt, self.B, nl, c_hw, n_in, c_ptr, c_str, c_ihw, c_mode, fuse_mode, c_fw, ctypes.c_float(den), pre_act,
                 taps.data_ptr(), wq.data_ptr(), scale.data_ptr() if scale is not None else None, shift.data_ptr(),
                 c_aff, post_act, F, N, c_out, c_ostr) + ood_args
-        return (self.lib.effdet_sepconv_fused, args, what)
+        es = self.pyr_es
+        in_px = sum(i[2][0] * i[2][1] for lv in level_inputs for i in lv)
+        out_px = sum(h * w for h, w in level_hw)
+        meta = dict(kind='sepconv', bytes=self.B * (in_px * F + out_px * N) * es + N * F * es + 9 * F * 4 +
+                    (2 * self.B * out_px * self.A * 4 if ood is not None else 0),
+                    flops=2 * self.B * out_px * (9 * F + F * N))
+        return (self.lib.effdet_sepconv_fused, args, what, meta)
 
     def _load_feature_list(self, xs, dst_tensors):
         for src, dst in zip(xs, dst_tensors):

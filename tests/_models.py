@@ -16,8 +16,22 @@ def seeded_model(name='tf_efficientdet_d0', image_size=256, num_classes=90, seed
     new = {}
     for k, v in sd.items():
         new[k] = v if k.endswith('num_batches_tracked') else seeded_tensor(seed, k, v.shape)
+    # keep head outputs in a realistic range: class logits O(1), box regressions O(0.3)
+    new['class_net.predict.conv_pw.weight'] = new['class_net.predict.conv_pw.weight'] * 0.1
+    new['box_net.predict.conv_pw.weight'] = new['box_net.predict.conv_pw.weight'] * 0.01
     if cls_bias is not None:
         new['class_net.predict.conv_pw.bias'] = torch.full_like(new['class_net.predict.conv_pw.bias'], cls_bias)
+    # one oracle pass on seeded images sets every BN's running stats to what it actually sees
+    from oracle import model as om
+    from _seeded import seeded_array
+    nodes = get_fpn_config(cfg.fpn_name, cfg.min_level, cfg.max_level).nodes
+    xcal = torch.from_numpy(seeded_array(seed + 1000, 'calib', (2, 3, image_size, image_size)))
+    om.CALIBRATE = True
+    try:
+        with torch.no_grad():
+            om.efficientdet_forward(new, cfg, xcal, nodes)
+    finally:
+        om.CALIBRATE = False
     model.load_state_dict(new, strict=True)
     nodes = get_fpn_config(cfg.fpn_name, cfg.min_level, cfg.max_level).nodes
     return model, cfg, nodes, {k: v.clone() for k, v in new.items()}

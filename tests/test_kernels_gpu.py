@@ -223,10 +223,10 @@ def test_sepconv_head_levels_and_ood(dtype, C):
 
 
 # ------------------------------------------------------------------------------------ post-process
-def _pp_case(seed, B, C, sizes, A=9, cs=2.0, shift=0.0):
+def _pp_case(seed, B, C, sizes, A=9, cs=2.0, shift=0.0, bs=0.4):
     from _seeded import seeded_array
     cls = [torch.from_numpy(seeded_array(seed, 'cls%d' % i, (B, A * C, s, s), scale=cs)) - shift for i, s in enumerate(sizes)]
-    box = [torch.from_numpy(seeded_array(seed, 'box%d' % i, (B, A * 4, s, s), scale=0.4)) for i, s in enumerate(sizes)]
+    box = [torch.from_numpy(seeded_array(seed, 'box%d' % i, (B, A * 4, s, s), scale=bs)) for i, s in enumerate(sizes)]
     return cls, box
 
 
@@ -244,7 +244,7 @@ def test_topk_golden(golden):
     g = golden('post_process')
     B, C, A, k = [int(v) for v in g['meta'][:4]]
     sizes = [int(v) for v in g['meta'][4:]]
-    cls, box = _pp_case(1, B, C, sizes, A, 2.0)
+    cls, box = _pp_case(1, B, C, sizes, A, 2.0, bs=0.5)
     from ood_object_detection_amd.effdet.bench import _post_process
     gc, gb, gi, gcl = _post_process([c.to(DEV) for c in cls], [b.to(DEV) for b in box], 5, C, k)
     assert np.array_equal(gi.cpu().numpy(), g['indices']) and np.array_equal(gcl.cpu().numpy(), g['classes'])
