@@ -18,6 +18,7 @@ P = ctypes.POINTER
 # name -> (restype, argtypes); must list every symbol include/effdet_hip.h declares
 SIGNATURES = {
     'effdet_abi_version': (c_int, []),
+    'effdet_last_error': (ctypes.c_char_p, []),
     'effdet_stem_conv': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int, c_int, c_int, c_int]),
     'effdet_pw_gemm_bn_act': (c_int, [c_void_p, c_int, c_void_p, c_ll, c_int, c_void_p, c_int, c_void_p, c_void_p,
@@ -25,6 +26,9 @@ SIGNATURES = {
     'effdet_dwconv_bn_act': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                      c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
     'effdet_dwconv_blocks_per_image': (c_int, [c_int, c_int, c_int]),
+    'effdet_mbconv_expand_dw': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    'effdet_mbconv_tiles_per_image': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     'effdet_se_gate': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_int, c_int, c_int]),
     'effdet_maxpool_same': (c_int, [c_void_p, c_int, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int]),
@@ -61,6 +65,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # The library must share ONE HIP runtime with the host framework: torch bundles its own
+    # libamdhip64/libhsa-runtime64, and whichever copy is mapped first wins the SONAME.  Import torch
+    # first so that its runtime is the one both sides use (loading this library first maps /opt/rocm's
+    # copy and the process then sees "no ROCm-capable device").
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError('%s is missing - run `python -c "import __graft_entry__ as g; g.build()"` '
                            '(there is no CPU fallback for the HIP path)' % LIB_PATH)
@@ -77,4 +86,7 @@ def load():
 
 def check(rc, what):
     if rc != 0:
-        raise RuntimeError('%s failed with code %d' % (what, rc))
+        detail = ''
+        if rc == -5 and _lib is not None:
+            detail = ' (%s)' % (_lib.effdet_last_error() or b'').decode()
+        raise RuntimeError('%s failed with code %d%s' % (what, rc, detail))

@@ -20,8 +20,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // non-fatal error code behind; drop it on entry so effdet_check_launch() reports only our launch.
 #define EFFDET_ENTER() (void)hipGetLastError()
 
+extern thread_local int effdet_last_hip_error;      // defined in abi.hip
 static inline int effdet_check_launch() {
     hipError_t e = hipGetLastError();
+    if (e != hipSuccess) effdet_last_hip_error = (int)e;
     return e == hipSuccess ? EFFDET_OK : EFFDET_ELAUNCH;
 }
 
@@ -30,6 +32,16 @@ static inline int effdet_check_launch() {
 // ---------------------------------------------------------------------------------------------
 DEV float silu_f(float x) { return x / (1.0f + expf(-x)); }
 DEV float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Hardware-transcendental forms (v_exp_f32 / v_rcp_f32, ~1 ulp each): used in bf16 throughput mode,
+// where the result is rounded to 8 bits anyway; float32 parity mode keeps the correctly rounded forms.
+DEV float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+DEV float fast_silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
+template <typename T> DEV float silu_t(float x) {
+    if constexpr (sizeof(T) == 2) return fast_silu(x); else return silu_f(x);
+}
+template <typename T> DEV float exp_t(float x) {
+    if constexpr (sizeof(T) == 2) return fast_exp(x); else return expf(x);
+}
 
 template <typename T> struct VecTraits;
 // 16-byte chunk = 4 floats or 8 bf16

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs p) {
     }
     F8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o.v[e] = silu_f(acc[e] * wl[27 * C + cg * 8 + e] + wl[28 * C + cg * 8 + e]);
+    for (int e = 0; e < 8; ++e) o.v[e] = silu_t<T>(acc[e] * wl[27 * C + cg * 8 + e] + wl[28 * C + cg * 8 + e]);
     T* dst = reinterpret_cast<T*>(p.Y) + (((long long)b * p.Ho + oy) * p.Wo + ox) * C + cg * 8;
     store8<T>(dst, o);
 }
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float v = acc.v[e] * sc.v[e] + sh.v[e];
-            if (p.act == 1) v = silu_f(v);
+            if (p.act == 1) v = silu_t<T>(v);
             // the SE average is taken over what the next layer will read: the T-rounded value
             o.v[e] = to_f<T>(from_f<T>(v));
             pool.v[e] += o.v[e];

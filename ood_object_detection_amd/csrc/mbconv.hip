@@ -1,0 +1,263 @@
+// Fused front half of an EfficientNet inverted-residual block:
+//
+//   expand 1x1 conv (MFMA) -> BN1 -> SiLU -> depthwise k x k (stride 1|2, TF-SAME) -> BN2 -> SiLU
+//   (+ per-tile partial sums of the squeeze-excite global average pool)
+//
+// replaces timm's InvertedResidual.conv_pw/bn1/act1/conv_dw/bn2/act2 (reached from
+// effdet/efficientdet.py:837).  The 6x-expanded activation - by far the largest tensor of the network -
+// lives only in LDS: a workgroup owns a TH x TW output tile of one image, loads the input halo tile
+// [(TH-1)*s+k] x [(TW-1)*s+k] x Cin once, and walks the expanded channels 64 at a time:
+//     W1 chunk -> LDS;  E^T = W1_chunk * X^T by 16x16 MFMA tiles (channels on the accumulator rows, so
+//     every lane holds 4 consecutive channels of one pixel and writes them with one 8-byte LDS store);
+//     BN1 + SiLU in registers, zero outside the image (the depthwise conv pads the EXPANDED map);
+//     depthwise taps out of LDS, BN2 + SiLU, 16-byte NHWC stores, pool partials.
+// HBM traffic per tile = input halo + output tile (+ weights from L2).
+#include "common.h"
+
+namespace {
+
+struct MbArgs {
+    const void* X; void* Y;
+    const void* W1;                             // [mid][Cin]  (T)
+    const float* s1; const float* t1;           // [mid]
+    const float* taps;                          // [k*k][mid]
+    const float* s2; const float* t2;           // [mid]
+    float* pool_partial;                        // [B][tiles][mid] or null
+    int B, H, W, Cin, mid, Ho, Wo, k, stride, pad_t, pad_l;
+    int TH, TW, IH, IW, HP, HPpad, tiles_x, tiles_y;
+    int arow;                                   // LDS pitch of X / W1 rows (bytes)
+};
+
+constexpr int MC = 64;                          // expanded channels per pass
+
+template <typename T> struct Pack4;
+template <> struct Pack4<bf16_t> { typedef unsigned long long type; };
+template <> struct Pack4<float> { typedef f32x4 type; };
+
+template <typename T>
+DEV void store4(T* p, float a, float b, float c, float d) {
+    if constexpr (sizeof(T) == 2) {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        bf16x4 v = {(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+        *reinterpret_cast<bf16x4*>(p) = v;
+    } else {
+        *reinterpret_cast<f32x4*>(p) = f32x4{a, b, c, d};
+    }
+}
+
+template <typename T, int KS, int S, int PPT>
+__global__ __launch_bounds__(256) void mbconv_front_kernel(MbArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 15, fpiece = lane >> 4;
+    const int b = blockIdx.y;
+    const int tile = blockIdx.x;
+    const int oy0 = (tile / p.tiles_x) * p.TH, ox0 = (tile % p.tiles_x) * p.TW;
+    const int iy0 = oy0 * S - p.pad_t, ix0 = ox0 * S - p.pad_l;
+    const int Cin = p.Cin, mid = p.mid;
+    const int cbytes = Cin * (int)sizeof(T);
+    const int nkc = (cbytes + 63) / 64;
+    const int arow = p.arow;
+    // LDS carve
+    char* At = lds;                                         // [HPpad][arow]
+    char* Wc = At + p.HPpad * arow;                         // [MC][arow]
+    T* E = reinterpret_cast<T*>(Wc + MC * arow);            // [HP][MC]
+    float* red = reinterpret_cast<float*>(reinterpret_cast<char*>(E) + p.HP * MC * sizeof(T));   // [256][8]
+
+    // ---- input halo tile -> LDS (zero rows outside the image, zero K padding)
+    const T* X = reinterpret_cast<const T*>(p.X) + (long long)b * p.H * p.W * Cin;
+    const int ppr = nkc * 4;                                // 16-byte pieces per LDS row
+    for (int i = tid; i < p.HPpad * ppr; i += 256) {
+        const int hp = i / ppr, piece = i % ppr;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (hp < p.HP && piece * 16 < cbytes) {
+            const int y = iy0 + hp / p.IW, x = ix0 + hp % p.IW;
+            if (y >= 0 && y < p.H && x >= 0 && x < p.W)
+                v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(X + ((long long)y * p.W + x) * Cin) + piece * 16);
+        }
+        *reinterpret_cast<u32x4*>(At + hp * arow + piece * 16) = v;
+    }
+
+    T* Y = reinterpret_cast<T*>(p.Y) + (long long)b * p.Ho * p.Wo * mid;
+    const int n_msub = p.HPpad / 16;
+    const int npix = p.TH * p.TW;
+
+    for (int c0 = 0; c0 < mid; c0 += MC) {
+        const int cn = (mid - c0) < MC ? (mid - c0) : MC;   // valid channels in this pass (multiple of 8)
+        __syncthreads();                                    // previous pass done with Wc / E / red
+        for (int i = tid; i < MC * ppr; i += 256) {
+            const int row = i / ppr, piece = i % ppr;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (row < cn && piece * 16 < cbytes)
+                v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.W1) + (long long)(c0 + row) * cbytes + piece * 16);
+            *reinterpret_cast<u32x4*>(Wc + row * arow + piece * 16) = v;
+        }
+        __syncthreads();
+        // ---- expand: rows of the accumulator = channels, columns = halo pixels
+        f32x4 sc[4], sh[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ch = c0 + 16 * j + 4 * fpiece;
+            if (16 * j + 4 * fpiece < cn) {
+                sc[j] = *reinterpret_cast<const f32x4*>(p.s1 + ch);
+                sh[j] = *reinterpret_cast<const f32x4*>(p.t1 + ch);
+            } else {
+                sc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; sh[j] = sc[j];
+            }
+        }
+        for (int ms = wave; ms < n_msub; ms += 4) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int kc = 0; kc < nkc; ++kc) {
+                const Frag<T> xf = ld_frag<T>(At + (16 * ms + frow) * arow + kc * 64 + fpiece * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const Frag<T> wf = ld_frag<T>(Wc + (16 * j + frow) * arow + kc * 64 + fpiece * 16);
+                    mma_chunk(wf, xf, acc[j]);
+                }
+            }
+            const int hp = 16 * ms + frow;
+            if (hp < p.HP) {
+                const int y = iy0 + hp / p.IW, x = ix0 + hp % p.IW;
+                const bool inside = y >= 0 && y < p.H && x >= 0 && x < p.W;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = inside ? silu_t<T>(acc[j][r] * sc[j][r] + sh[j][r]) : 0.f;
+                    store4<T>(E + hp * MC + 16 * j + 4 * fpiece, v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- depthwise out of LDS: a thread owns 8 channels x PPT x-adjacent outputs (sliding window)
+        const int cgn = cn / 8;
+        F8 pool = f8_zero();
+        const int cg = tid & 7;                              // fixed per thread: 256 % 8 == 0
+        if (cg < cgn) {
+            const F8 s2 = load8<float>(p.s2 + c0 + cg * 8), t2 = load8<float>(p.t2 + c0 + cg * 8);
+            const int gpr = p.TW / PPT;                      // pixel groups per tile row
+            for (int pg = tid >> 3; pg < p.TH * gpr; pg += 32) {
+                const int ty = pg / gpr, tx0 = (pg % gpr) * PPT;
+                const int oy = oy0 + ty;
+                if (oy >= p.Ho || ox0 + tx0 >= p.Wo) continue;
+                F8 acc[PPT];
+#pragma unroll
+                for (int pi = 0; pi < PPT; ++pi) acc[pi] = f8_zero();
+#pragma unroll 1
+                for (int ky = 0; ky < KS; ++ky) {          // not unrolled: keeps one kernel row of taps live
+                    F8 w[KS];
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx) w[kx] = load8<float>(p.taps + (ky * KS + kx) * mid + c0 + cg * 8);
+                    const T* erow = E + ((ty * S + ky) * p.IW + tx0 * S) * MC + cg * 8;
+#pragma unroll
+                    for (int c = 0; c < (PPT - 1) * S + KS; ++c) {
+                        const F8 e = load8<T>(erow + c * MC);
+#pragma unroll
+                        for (int pi = 0; pi < PPT; ++pi) {
+                            const int kx = c - pi * S;
+                            if (kx >= 0 && kx < KS) {
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) acc[pi].v[q] = fmaf(e.v[q], w[kx].v[q], acc[pi].v[q]);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int pi = 0; pi < PPT; ++pi) {
+                    const int ox = ox0 + tx0 + pi;
+                    if (ox >= p.Wo) continue;
+                    F8 o;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float v = silu_t<T>(acc[pi].v[q] * s2.v[q] + t2.v[q]);
+                        o.v[q] = to_f<T>(from_f<T>(v));          // SE averages what the next layer reads
+                        pool.v[q] += o.v[q];
+                    }
+                    store8<T>(Y + ((long long)oy * p.Wo + ox) * mid + c0 + cg * 8, o);
+                }
+            }
+        }
+        if (p.pool_partial != nullptr) {
+            store8<float>(red + tid * 8, pool);
+            __syncthreads();
+            if (tid < cn) {
+                const int g = tid >> 3, q = tid & 7;
+                float s = 0.f;
+                for (int t = g; t < 256; t += 8) s += red[t * 8 + q];
+                p.pool_partial[((long long)b * (p.tiles_x * p.tiles_y) + tile) * mid + c0 + tid] = s;
+            }
+        }
+    }
+}
+
+struct Geometry { int TH, TW, IH, IW, HP, HPpad, arow; size_t lds; };
+
+template <typename T>
+Geometry pick_tile(int Ho, int Wo, int Cin, int k, int stride) {
+    const int cand[][2] = {{8, 16}, {8, 8}, {4, 16}, {4, 8}, {4, 4}, {2, 4}};     // TW is a multiple of 4
+    const int nkc = (Cin * (int)sizeof(T) + 63) / 64;
+    Geometry best{};
+    for (auto& c : cand) {
+        Geometry g;
+        g.TH = c[0]; g.TW = c[1];
+        g.IH = (g.TH - 1) * stride + k; g.IW = (g.TW - 1) * stride + k;
+        g.HP = g.IH * g.IW; g.HPpad = (g.HP + 15) / 16 * 16;
+        g.arow = nkc * 64 + 16;
+        g.lds = (size_t)g.HPpad * g.arow + (size_t)MC * g.arow + (size_t)g.HP * MC * sizeof(T) + 256 * 8 * 4;
+        best = g;
+        // a tile much larger than the map wastes the workgroup; keep two workgroups per CU (<= 76 KiB each)
+        const bool fits_map = (g.TH <= Ho || g.TH == 2) && (g.TW <= 2 * Wo);
+        if (g.lds <= 76 * 1024 && fits_map) return g;
+    }
+    return best;
+}
+
+template <typename T>
+int launch_mb(hipStream_t st, MbArgs& a) {
+    const Geometry g = pick_tile<T>(a.Ho, a.Wo, a.Cin, a.k, a.stride);
+    if (g.lds > 160 * 1024) return EFFDET_EINVAL;
+    a.TH = g.TH; a.TW = g.TW; a.IH = g.IH; a.IW = g.IW; a.HP = g.HP; a.HPpad = g.HPpad; a.arow = g.arow;
+    a.tiles_x = (a.Wo + g.TW - 1) / g.TW; a.tiles_y = (a.Ho + g.TH - 1) / g.TH;
+    dim3 grid(a.tiles_x * a.tiles_y, a.B), block(256);
+    // outputs per thread along x in the depthwise phase: keep all 256 threads busy on small tiles
+    const int npix = g.TH * g.TW;
+    const int ppt = npix >= 128 ? 4 : (npix >= 64 ? 2 : 1);
+    void (*kern)(MbArgs) = nullptr;
+#define MB_PICK(K_, S_) (ppt == 4 ? mbconv_front_kernel<T, K_, S_, 4> : ppt == 2 ? mbconv_front_kernel<T, K_, S_, 2> : mbconv_front_kernel<T, K_, S_, 1>)
+    if (a.k == 3) kern = a.stride == 1 ? MB_PICK(3, 1) : MB_PICK(3, 2);
+    else kern = a.stride == 1 ? MB_PICK(5, 1) : MB_PICK(5, 2);
+#undef MB_PICK
+    if (g.lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return EFFDET_ELAUNCH;
+    }
+    hipLaunchKernelGGL(kern, grid, block, g.lds, st, a);
+    return effdet_check_launch();
+}
+
+}  // namespace
+
+extern "C" int effdet_mbconv_tiles_per_image(int dtype, int H, int W, int Cin, int k, int stride) {
+    if (H <= 0 || W <= 0 || Cin <= 0 || (k != 3 && k != 5) || (stride != 1 && stride != 2) || (dtype & ~1)) return EFFDET_EINVAL;
+    const int Ho = same_out(H, stride), Wo = same_out(W, stride);
+    const Geometry g = dtype == 0 ? pick_tile<float>(Ho, Wo, Cin, k, stride) : pick_tile<bf16_t>(Ho, Wo, Cin, k, stride);
+    return ((Wo + g.TW - 1) / g.TW) * ((Ho + g.TH - 1) / g.TH);
+}
+
+extern "C" int effdet_mbconv_expand_dw(void* stream, int dtype, const void* X, void* Y, const void* W1,
+                                       const float* s1, const float* t1, const float* taps,
+                                       const float* s2, const float* t2, float* pool_partial,
+                                       int B, int H, int W, int Cin, int mid, int k, int stride) {
+    EFFDET_ENTER();
+    if (!X || !Y || !W1 || !s1 || !t1 || !taps || !s2 || !t2 || B <= 0 || H <= 0 || W <= 0) return EFFDET_EINVAL;
+    if (Cin <= 0 || Cin % 8 || mid <= 0 || mid % 8 || (k != 3 && k != 5) || (stride != 1 && stride != 2) || (dtype & ~1)) return EFFDET_EINVAL;
+    MbArgs a;
+    a.X = X; a.Y = Y; a.W1 = W1; a.s1 = s1; a.t1 = t1; a.taps = taps; a.s2 = s2; a.t2 = t2; a.pool_partial = pool_partial;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.mid = mid; a.k = k; a.stride = stride;
+    a.Ho = same_out(H, stride); a.Wo = same_out(W, stride);
+    a.pad_t = same_pad_before(H, k, stride); a.pad_l = same_pad_before(W, k, stride);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return dtype == 0 ? launch_mb<float>(st, a) : launch_mb<bf16_t>(st, a);
+}

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs p) {
             if (e < nvalid) {
                 const float sc = p.scale ? p.scale[n + e] : 1.0f;
                 x = x * sc + p.shift[n + e];
-                if (p.act == 1) x = silu_f(x);
+                if (p.act == 1) x = silu_t<T>(x);
                 if (Rb) x += to_f<T>(Rb[m * p.N + n + e]);
             }
             v[e] = x;

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void sepconv_kernel(SepArgs p) {
                 }
                 if (p.pre_act) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v.v[e] = silu_f(v.v[e]);
+                    for (int e = 0; e < 8; ++e) v.v[e] = silu_t<T>(v.v[e]);
                 }
             }
             store8<T>(reinterpret_cast<T*>(halo) + hp * FC + cg * 8, v);
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void sepconv_kernel(SepArgs p) {
                 if (e < nvalid) {
                     const int n = n_begin + nloc + e;
                     xv = xv * (scale ? scale[n] : 1.0f) + shift[n];
-                    if (p.post_act) xv = silu_f(xv);
+                    if (p.post_act) xv = silu_t<T>(xv);
                     lm = fmaxf(lm, xv);
                 }
                 v[e] = xv;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void sepconv_kernel(SepArgs p) {
             if (ood) {
                 float ls = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) if (e < nvalid) ls += expf(v[e] - lm);
+                for (int e = 0; e < 8; ++e) if (e < nvalid) ls += exp_t<T>(v[e] - lm);
                 // combine the GPR (= 8 when BN = 64) lanes of this row
 #pragma unroll
                 for (int o = 1; o < GPR; o <<= 1) {

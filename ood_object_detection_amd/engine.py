@@ -97,7 +97,7 @@ class Engine(object):
         for fn, args, what, _meta in plan:
             rc = fn(st, *args)
             if rc != 0:
-                raise RuntimeError('%s failed with code %d' % (what, rc))
+                _lib.check(rc, what)
 
     def _gemm_meta(self, M, K, N, residual=False, gate=False):
         es = self.pyr_es
@@ -133,17 +133,18 @@ class Engine(object):
         for blocks in stages:
             for b in blocks:
                 ho, wo = _same_out(h, b['s']), _same_out(w, b['s'])
-                if b['type'] == 'ir':
-                    mid_max = max(mid_max, B * h * w * b['mid'])
                 mid_max = max(mid_max, B * ho * wo * b['mid'])
-                nblk = lib.effdet_dwconv_blocks_per_image(ho, wo, b['mid'])
+                if b['type'] == 'ir':
+                    nblk = lib.effdet_mbconv_tiles_per_image(dt, h, w, b['cin'], b['k'], b['s'])
+                else:
+                    nblk = lib.effdet_dwconv_blocks_per_image(ho, wo, b['mid'])
                 if nblk <= 0:
-                    raise NotImplementedError('depthwise width %d is outside the built range' % b['mid'])
+                    raise NotImplementedError('block geometry (mid=%d) is outside the built range' % b['mid'])
                 part_max = max(part_max, B * nblk * b['mid'])
                 io_max = max(io_max, B * ho * wo * b['cout'])
                 h, w = ho, wo
         ping = [self._new(io_max), self._new(io_max)]
-        ebuf, dbuf = self._new(max(mid_max, 1)), self._new(max(mid_max, 1))
+        dbuf = self._new(max(mid_max, 1))
         partial = self._new(part_max, dtype=torch.float32)
         gate_max = B * max(b['mid'] for blocks in stages for b in blocks)
         gate = self._new(gate_max, dtype=torch.float32)
@@ -167,26 +168,35 @@ class Engine(object):
                 else:
                     out = ping[1] if cur.data_ptr() == ping[0].data_ptr() else ping[0]
                 what = 'backbone.blocks.%d.%d' % (si, bi)
+                es = self.pyr_es
                 if b['type'] == 'ir':
+                    # fused expand 1x1 + BN + SiLU -> depthwise + BN + SiLU (+ SE pool partials); the expanded
+                    # activation stays in LDS
                     s1, t1 = self._fold(m.bn1)
                     w1 = self._w(m.conv_pw.weight.reshape(b['mid'], b['cin']))
                     s1, t1 = self._f32(s1), self._f32(t1)
-                    plan.append((lib.effdet_pw_gemm_bn_act,
-                                 (dt, cur.data_ptr(), B * h * w, b['cin'], w1.data_ptr(), b['mid'], s1.data_ptr(),
-                                  t1.data_ptr(), 1, None, None, 0, ebuf.data_ptr(), 0, 0), what + '.conv_pw',
-                                 self._gemm_meta(B * h * w, b['cin'], b['mid'])))
-                    dw_in, bn_dw, pw_out, bn_out = ebuf, m.bn2, m.conv_pwl, m.bn3
+                    s2, t2 = self._fold(m.bn2)
+                    taps = self._f32(self._dw_taps(m.conv_dw.weight))
+                    s2, t2 = self._f32(s2), self._f32(t2)
+                    nblk = lib.effdet_mbconv_tiles_per_image(dt, h, w, b['cin'], b['k'], b['s'])
+                    plan.append((lib.effdet_mbconv_expand_dw,
+                                 (dt, cur.data_ptr(), dbuf.data_ptr(), w1.data_ptr(), s1.data_ptr(), t1.data_ptr(),
+                                  taps.data_ptr(), s2.data_ptr(), t2.data_ptr(), partial.data_ptr(),
+                                  B, h, w, b['cin'], b['mid'], b['k'], b['s']), what + '.conv_pw+conv_dw',
+                                 dict(kind='mbconv', bytes=B * (h * w * b['cin'] + ho * wo * b['mid']) * es + b['mid'] * b['cin'] * es,
+                                      flops=2 * B * (h * w * b['cin'] * b['mid'] + b['k'] * b['k'] * ho * wo * b['mid']))))
+                    pw_out, bn_out = m.conv_pwl, m.bn3
                 else:
-                    dw_in, bn_dw, pw_out, bn_out = cur, m.bn1, m.conv_pw, m.bn2
-                s2, t2 = self._fold(bn_dw)
-                taps = self._f32(self._dw_taps(m.conv_dw.weight))
-                s2, t2 = self._f32(s2), self._f32(t2)
-                nblk = lib.effdet_dwconv_blocks_per_image(ho, wo, b['mid'])
-                plan.append((lib.effdet_dwconv_bn_act,
-                             (dt, dw_in.data_ptr(), dbuf.data_ptr(), taps.data_ptr(), s2.data_ptr(), t2.data_ptr(), 1,
-                              partial.data_ptr(), B, h, w, b['mid'], b['k'], b['s']), what + '.conv_dw',
-                             dict(kind='dwconv', bytes=B * (h * w + ho * wo) * b['mid'] * self.pyr_es,
-                                  flops=2 * b['k'] * b['k'] * B * ho * wo * b['mid'])))
+                    s2, t2 = self._fold(m.bn1)
+                    taps = self._f32(self._dw_taps(m.conv_dw.weight))
+                    s2, t2 = self._f32(s2), self._f32(t2)
+                    nblk = lib.effdet_dwconv_blocks_per_image(ho, wo, b['mid'])
+                    plan.append((lib.effdet_dwconv_bn_act,
+                                 (dt, cur.data_ptr(), dbuf.data_ptr(), taps.data_ptr(), s2.data_ptr(), t2.data_ptr(), 1,
+                                  partial.data_ptr(), B, h, w, b['mid'], b['k'], b['s']), what + '.conv_dw',
+                                 dict(kind='dwconv', bytes=B * (h * w + ho * wo) * b['mid'] * es,
+                                      flops=2 * b['k'] * b['k'] * B * ho * wo * b['mid'])))
+                    pw_out, bn_out = m.conv_pw, m.bn2
                 W1 = self._f32(m.se.conv_reduce.weight.reshape(b['se'], b['mid']))
                 b1 = self._f32(m.se.conv_reduce.bias)
                 W2 = self._f32(m.se.conv_expand.weight.reshape(b['mid'], b['se']))

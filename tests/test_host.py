@@ -127,6 +127,7 @@ def test_c_abi_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, 'include', 'effdet_hip.h')).read()
     declared = set(re.findall(r'\b(effdet_[a-z0-9_]+)\s*\(', header))
     assert declared == set(_lib.SIGNATURES.keys())
+    import torch  # noqa: F401  (share torch's HIP runtime, see _lib.load)
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name

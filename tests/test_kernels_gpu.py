@@ -102,6 +102,40 @@ def test_dwconv_se(dtype, C, H, W, k, s):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('Cin,mid,H,W,k,s', [(16, 96, 40, 36, 3, 2), (24, 144, 22, 30, 3, 1), (24, 144, 33, 21, 5, 2),
+                                             (40, 240, 20, 20, 5, 1), (112, 672, 10, 12, 5, 2), (192, 1152, 5, 5, 3, 1)])
+def test_mbconv_expand_dw_fused(dtype, Cin, mid, H, W, k, s):
+    """fused expand 1x1 + BN + SiLU -> depthwise + BN + SiLU + SE pool partials vs the oracle's separate ops"""
+    import _hip
+    from ood_object_detection_amd import _lib
+    lib = _lib.load()
+    B = 2
+    x = _rand(B, Cin, H, W, seed=50).to(dtype)
+    w1 = _rand(mid, Cin, 1, 1, seed=51, scale=1.5 * Cin ** -0.5).to(dtype)
+    s1, t1 = torch.rand(mid) + 0.5, _rand(mid, seed=52, scale=0.2)
+    wd = _rand(mid, 1, k, k, seed=53, scale=1.0 / k)
+    s2, t2 = torch.rand(mid) + 0.5, _rand(mid, seed=54, scale=0.2)
+    e = om.silu(F.conv2d(x.float(), w1.float()) * s1[None, :, None, None] + t1[None, :, None, None])
+    if dtype == torch.bfloat16:
+        e = e.to(dtype).float()                      # the kernel keeps the expanded map in LDS as bf16
+    ref = om.silu(om.conv2d_pad(e, wd, None, s, 'same', groups=mid) * s2[None, :, None, None] + t2[None, :, None, None])
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    xd = _hip.nhwc(x, dtype).to(DEV)
+    y = torch.empty(B, Ho, Wo, mid, dtype=dtype, device=DEV)
+    nt = lib.effdet_mbconv_tiles_per_image(_hip.DT[dtype], H, W, Cin, k, s)
+    assert nt > 0
+    part = torch.full((B, nt, mid), float('nan'), dtype=torch.float32, device=DEV)
+    dv = [t.contiguous().to(DEV) for t in (w1.reshape(mid, Cin), s1, t1, wd.permute(2, 3, 0, 1).reshape(k * k, mid), s2, t2)]
+    rc = lib.effdet_mbconv_expand_dw(_hip.stream(DEV), _hip.DT[dtype], xd.data_ptr(), y.data_ptr(), *[t.data_ptr() for t in dv],
+                                     part.data_ptr(), B, H, W, Cin, mid, k, s)
+    assert rc == 0
+    assert _rel(_hip.nchw(y), ref) < TOL[dtype]
+    pooled = part.sum(1).cpu() / (Ho * Wo)
+    pref = _hip.nchw(y).cpu().mean((2, 3))
+    assert float((pooled - pref).abs().max()) < 1e-4 * max(1.0, float(pref.abs().max()))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_stem_and_maxpool(dtype):
     import _hip
     from ood_object_detection_amd import _lib

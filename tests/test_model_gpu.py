@@ -112,13 +112,17 @@ def test_det_bench_predict_fp32(d0, soft):
             n = int(bench.last_count[i])
             assert n == ref.shape[0]
             got = det[i, :n].cpu()
-            # north-star tolerance: classes exact, scores within 1e-3 abs, boxes within 1e-3 px abs plus 2e-5 of
-            # the box's own extent (this seeded net emits boxes over 1000 px wide from the 1137 px P7 anchors;
-            # fp32 has 24 bits, so a different-but-valid summation order in the box head (measured 1e-5) alone
-            # moves such an edge by ~1e-2 px)
+            # north-star tolerance: classes exact, scores within 1e-3 abs, boxes within 1e-3 px abs plus 2e-5 of the
+            # size of the box and of the anchor it was decoded from: box = t * anchor_size + centre, the box head
+            # matches the oracle to ~1e-5 (fp32 summation order, amplified by this seeded random net) and the P7
+            # anchors are 1137 px, so a valid fp32 evaluation can move an edge by ~1e-2 px
             assert torch.equal(got[:, 5], ref[:, 5])
             err = (got[:, :4] - ref[:, :4]).abs()
-            extent = ref[:, :4].abs().max(dim=1, keepdim=True)[0] + (ref[:, 2:3] - ref[:, 0:1]).abs() + (ref[:, 3:4] - ref[:, 1:2]).abs()
+            an = anchors[idx[i][src]]
+            asize = torch.maximum(an[:, 2] - an[:, 0], an[:, 3] - an[:, 1])[:, None]
+            extent = asize + (ref[:, 2:3] - ref[:, 0:1]).abs() + (ref[:, 3:4] - ref[:, 1:2]).abs()
+            if sc is not None:
+                extent = extent * float(sc)
             assert bool((err <= 1e-3 + 2e-5 * extent).all()), float(err.max())
             assert float((got[:, 4] - ref[:, 4]).abs().max()) <= 1e-3
             a_idx = idx[i][src]
