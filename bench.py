@@ -198,6 +198,34 @@ def main():
     with torch.no_grad():
         bench(x)
         prof = model._engine.profile(reps=5)
+    # the launches outside the engine plans: stem conv, top-k, decode + NMS + OOD gather
+    from ood_object_detection_amd.effdet.bench import _post_process
+    from ood_object_detection_amd.effdet.anchors import batched_detections
+    eng = model._engine
+    es = 2 if args.dtype == 'bf16' else 4
+
+    def timed(fn, reps=5):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            r = fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps, r
+    with torch.no_grad():
+        ms_bb, _ = timed(lambda: eng.run_backbone(x))
+        bb_plan_ms = sum(ms for what, kind, nb, fl, ms in prof if what.startswith('backbone.'))
+        stem_ms = max(ms_bb - bb_plan_ms, 0.0)
+        cls_o, box_o = eng.head_views(eng.cls_all, eng.C), eng.head_views(eng.box_all, 4)
+        ms_topk, pp = timed(lambda: _post_process(cls_o, box_o, cfg.num_levels, args.classes, cfg.max_detection_points))
+        ct, bt, idx, cl = pp
+        ms_det, _ = timed(lambda: batched_detections(ct.reshape(B, -1), bt, bench.anchors.boxes, idx, cl, None, None,
+                                                     cfg.max_det_per_image, bool(args.soft_nms)))
+    Hs = args.image // 2
+    prof.append(('backbone.conv_stem (by difference)', 'stem', B * (3 * args.image * args.image * es + Hs * Hs * 32 * es), 2 * 27 * 32 * B * Hs * Hs, stem_ms))
+    prof.append(('_post_process top-k', 'topk', 2 * B * eng.N * args.classes * es, 0, ms_topk))
+    prof.append(('decode + NMS', 'nms', B * cfg.max_detection_points * 40, 0, ms_det))
     fam = {}
     for what, kind, nbytes, flops, ms in prof:
         f = fam.setdefault(kind, dict(ms=0.0, bytes=0, flops=0, launches=0))

@@ -60,12 +60,13 @@ int effdet_dwconv_blocks_per_image(int Ho, int Wo, int C);
 /* Fused front half of an inverted-residual block: expand 1x1 (MFMA) + BN + SiLU -> depthwise k x k
  * (TF-SAME, stride 1|2) + BN + SiLU; the expanded activation never leaves LDS.  W1: [mid][Cin] (dtype),
  * taps: [k*k][mid] fp32.  pool_partial (optional): [B][effdet_mbconv_tiles_per_image(...)][mid] partial
- * sums for the SE average.  Replaces conv_pw/bn1/act1/conv_dw/bn2/act2 of timm's InvertedResidual. */
+ * sums for the SE average.  Early stages run as spatial tiles, late stages (wide inputs, small maps) as
+ * (row band x 64-channel slice) workgroups; the choice is internal.  Replaces conv_pw/bn1/act1/conv_dw/bn2/act2 of timm's InvertedResidual. */
 int effdet_mbconv_expand_dw(void* stream, int dtype, const void* X, void* Y, const void* W1,
                             const float* s1, const float* t1, const float* taps,
                             const float* s2, const float* t2, float* pool_partial,
                             int B, int H, int W, int Cin, int mid, int k, int stride);
-int effdet_mbconv_tiles_per_image(int dtype, int H, int W, int Cin, int k, int stride);
+int effdet_mbconv_tiles_per_image(int dtype, int H, int W, int Cin, int mid, int k, int stride);
 
 /* SqueezeExcite gate: mean -> fc(C->R)+SiLU -> fc(R->C) -> sigmoid.  W1: [R][C], W2: [C][R]. */
 int effdet_se_gate(void* stream, const float* partial, int nblk, int hw, const float* W1, const float* b1,

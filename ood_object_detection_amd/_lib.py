@@ -28,7 +28,7 @@ SIGNATURES = {
     'effdet_dwconv_blocks_per_image': (c_int, [c_int, c_int, c_int]),
     'effdet_mbconv_expand_dw': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
-    'effdet_mbconv_tiles_per_image': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    'effdet_mbconv_tiles_per_image': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'effdet_se_gate': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_int, c_int, c_int]),
     'effdet_maxpool_same': (c_int, [c_void_p, c_int, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int]),

@@ -192,6 +192,194 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(MbArgs p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// "Deep" decomposition for the late stages (small maps, many channels): a workgroup owns
+// (image, band of output rows, slice of 64 expanded channels).  The W1 slice is read once into LDS,
+// the input rows of the band are streamed from L2 straight into MFMA operand registers (they are
+// shared by all channel slices of the band), the expanded band [rows x W x 64] lives in LDS and the
+// depthwise conv walks it with explicit border checks (no x halo is stored).
+// ------------------------------------------------------------------------------------------------
+struct MbDeepArgs {
+    const void* X; void* Y; const void* W1;
+    const float* s1; const float* t1; const float* taps; const float* s2; const float* t2;
+    float* pool_partial;
+    int B, H, W, Cin, mid, Ho, Wo, pad_t, pad_l;
+    int band_rows, nbands, nchunks, arow, e_rows_max;
+};
+
+template <typename T, int KS, int S, int PPT>
+__global__ __launch_bounds__(256) void mbconv_deep_kernel(MbDeepArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 15, fpiece = lane >> 4;
+    const int b = blockIdx.y;
+    const int chunk = blockIdx.x % p.nchunks, band = blockIdx.x / p.nchunks;
+    const int Cin = p.Cin, mid = p.mid, W = p.W;
+    const int cbytes = Cin * (int)sizeof(T);
+    const int nkc = (cbytes + 63) / 64;
+    const int arow = p.arow;
+    const int c0 = chunk * MC;
+    const int cn = (mid - c0) < MC ? (mid - c0) : MC;
+    const int oy_b = band * p.band_rows;
+    const int oy_e = min(p.Ho, oy_b + p.band_rows);
+    const int iy_lo = max(0, oy_b * S - p.pad_t);
+    const int iy_hi = min(p.H, (oy_e - 1) * S - p.pad_t + KS);
+    const int npx = (iy_hi - iy_lo) * W;
+
+    char* Wc = lds;                                            // [MC][arow]; reused as pool scratch
+    float* red = reinterpret_cast<float*>(lds);
+    const int wc_bytes = (MC * arow > 256 * 8 * 4) ? MC * arow : 256 * 8 * 4;
+    T* E = reinterpret_cast<T*>(lds + wc_bytes);               // [npx][MC]
+
+    const int ppr = nkc * 4;
+    for (int i = tid; i < MC * ppr; i += 256) {
+        const int row = i / ppr, piece = i % ppr;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < cn && piece * 16 < cbytes)
+            v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.W1) + (long long)(c0 + row) * cbytes + piece * 16);
+        *reinterpret_cast<u32x4*>(Wc + row * arow + piece * 16) = v;
+    }
+    f32x4 sc[4], sh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (16 * j + 4 * fpiece < cn) {
+            sc[j] = *reinterpret_cast<const f32x4*>(p.s1 + c0 + 16 * j + 4 * fpiece);
+            sh[j] = *reinterpret_cast<const f32x4*>(p.t1 + c0 + 16 * j + 4 * fpiece);
+        } else {
+            sc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; sh[j] = sc[j];
+        }
+    }
+    __syncthreads();
+    // ---- expand the band: two 16-pixel sub-tiles per step share every W fragment read
+    const char* Xb = reinterpret_cast<const char*>(p.X) + ((long long)b * p.H * W + (long long)iy_lo * W) * cbytes;
+    const int n_pair = (npx + 31) / 32;
+    for (int mp = wave; mp < n_pair; mp += 4) {
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int hp0 = 32 * mp + frow, hp1 = hp0 + 16;
+        const char* x0 = Xb + (long long)(hp0 < npx ? hp0 : 0) * cbytes;
+        const char* x1 = Xb + (long long)(hp1 < npx ? hp1 : 0) * cbytes;
+        for (int kc = 0; kc < nkc; ++kc) {
+            const int off = kc * 64 + fpiece * 16;
+            Frag<T> xf0, xf1;
+            if (off < cbytes) { xf0 = ld_frag<T>(x0 + off); xf1 = ld_frag<T>(x1 + off); }
+            else { xf0.v = decltype(xf0.v){}; xf1.v = decltype(xf1.v){}; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const Frag<T> wf = ld_frag<T>(Wc + (16 * j + frow) * arow + off);
+                mma_chunk(wf, xf0, acc[0][j]);
+                mma_chunk(wf, xf1, acc[1][j]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int hp = u == 0 ? hp0 : hp1;
+            if (hp < npx) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    store4<T>(E + hp * MC + 16 * j + 4 * fpiece,
+                              silu_t<T>(acc[u][j][0] * sc[j][0] + sh[j][0]), silu_t<T>(acc[u][j][1] * sc[j][1] + sh[j][1]),
+                              silu_t<T>(acc[u][j][2] * sc[j][2] + sh[j][2]), silu_t<T>(acc[u][j][3] * sc[j][3] + sh[j][3]));
+            }
+        }
+    }
+    __syncthreads();
+    // ---- depthwise over the band, borders by index checks
+    T* Y = reinterpret_cast<T*>(p.Y) + (long long)b * p.Ho * p.Wo * mid;
+    const int cgn = cn / 8;
+    F8 pool = f8_zero();
+    const int cg = tid & 7;
+    if (cg < cgn) {
+        const F8 s2 = load8<float>(p.s2 + c0 + cg * 8), t2 = load8<float>(p.t2 + c0 + cg * 8);
+        const int gpr = (p.Wo + PPT - 1) / PPT;
+        for (int pg = tid >> 3; pg < (oy_e - oy_b) * gpr; pg += 32) {
+            const int oy = oy_b + pg / gpr, ox0 = (pg % gpr) * PPT;
+            F8 acc[PPT];
+#pragma unroll
+            for (int pi = 0; pi < PPT; ++pi) acc[pi] = f8_zero();
+#pragma unroll 1
+            for (int ky = 0; ky < KS; ++ky) {
+                const int iy = oy * S - p.pad_t + ky;
+                if (iy < 0 || iy >= p.H) continue;
+                F8 w[KS];
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) w[kx] = load8<float>(p.taps + (ky * KS + kx) * mid + c0 + cg * 8);
+                const T* erow = E + (long long)(iy - iy_lo) * W * MC + cg * 8;
+                const int ix0 = ox0 * S - p.pad_l;
+#pragma unroll
+                for (int c = 0; c < (PPT - 1) * S + KS; ++c) {
+                    const int ix = ix0 + c;
+                    if (ix < 0 || ix >= W) continue;
+                    const F8 e = load8<T>(erow + ix * MC);
+#pragma unroll
+                    for (int pi = 0; pi < PPT; ++pi) {
+                        const int kx = c - pi * S;
+                        if (kx >= 0 && kx < KS) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) acc[pi].v[q] = fmaf(e.v[q], w[kx].v[q], acc[pi].v[q]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int pi = 0; pi < PPT; ++pi) {
+                const int ox = ox0 + pi;
+                if (ox >= p.Wo) continue;
+                F8 o;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float v = silu_t<T>(acc[pi].v[q] * s2.v[q] + t2.v[q]);
+                    o.v[q] = to_f<T>(from_f<T>(v));
+                    pool.v[q] += o.v[q];
+                }
+                store8<T>(Y + ((long long)oy * p.Wo + ox) * mid + c0 + cg * 8, o);
+            }
+        }
+    }
+    if (p.pool_partial != nullptr) {
+        __syncthreads();                                       // every wave is done reading Wc
+        store8<float>(red + tid * 8, pool);
+        __syncthreads();
+        if (tid < cn) {
+            const int g = tid >> 3, q = tid & 7;
+            float s = 0.f;
+            for (int t = g; t < 256; t += 8) s += red[t * 8 + q];
+            p.pool_partial[((long long)b * p.nbands + band) * mid + c0 + tid] = s;
+        }
+    }
+}
+
+struct DeepGeometry { bool use; int band_rows, nbands, nchunks, arow, e_rows_max; size_t lds; };
+
+template <typename T>
+DeepGeometry pick_deep(int H, int W, int Cin, int mid, int k, int stride) {
+    DeepGeometry g{};
+    const int Ho = same_out(H, stride);
+    const int nkc = (Cin * (int)sizeof(T) + 63) / 64;
+    g.arow = nkc * 64 + 16;
+    g.nchunks = (mid + MC - 1) / MC;
+    const size_t wc = (size_t)MC * g.arow > 8192 ? (size_t)MC * g.arow : 8192;
+    const size_t budget = 78 * 1024;      // two workgroups per CU (160 KiB LDS)
+    g.use = false;
+    if (Cin * (int)sizeof(T) < 128 || wc + (size_t)k * W * MC * sizeof(T) > budget) return g;   // wide inputs, narrow maps only
+    int rows = Ho;
+    for (;;) {
+        const int in_rows = (rows - 1) * stride + k < H ? (rows - 1) * stride + k : H;
+        const size_t lds = wc + (size_t)in_rows * W * MC * sizeof(T);
+        if (lds <= budget) { g.band_rows = rows; g.e_rows_max = in_rows; g.lds = lds; break; }
+        if (rows == 1) return g;
+        rows = (rows + 1) / 2;
+    }
+    if (g.band_rows < 3 && g.band_rows < Ho) return g;          // too much halo recompute: use spatial tiles
+    g.nbands = (Ho + g.band_rows - 1) / g.band_rows;
+    g.use = true;
+    return g;
+}
+
 struct Geometry { int TH, TW, IH, IW, HP, HPpad, arow; size_t lds; };
 
 template <typename T>
@@ -215,7 +403,24 @@ Geometry pick_tile(int Ho, int Wo, int Cin, int k, int stride) {
 }
 
 template <typename T>
+int launch_deep(hipStream_t st, const MbArgs& a, const DeepGeometry& g) {
+    MbDeepArgs d{a.X, a.Y, a.W1, a.s1, a.t1, a.taps, a.s2, a.t2, a.pool_partial, a.B, a.H, a.W, a.Cin, a.mid, a.Ho, a.Wo,
+                 a.pad_t, a.pad_l, g.band_rows, g.nbands, g.nchunks, g.arow, g.e_rows_max};
+    void (*kern)(MbDeepArgs) = nullptr;
+    if (a.k == 3) kern = a.stride == 1 ? mbconv_deep_kernel<T, 3, 1, 4> : mbconv_deep_kernel<T, 3, 2, 4>;
+    else kern = a.stride == 1 ? mbconv_deep_kernel<T, 5, 1, 4> : mbconv_deep_kernel<T, 5, 2, 4>;
+    if (g.lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return EFFDET_ELAUNCH;
+    }
+    hipLaunchKernelGGL(kern, dim3(g.nchunks * g.nbands, a.B), dim3(256), g.lds, st, d);
+    return effdet_check_launch();
+}
+
+template <typename T>
 int launch_mb(hipStream_t st, MbArgs& a) {
+    const DeepGeometry dg = pick_deep<T>(a.H, a.W, a.Cin, a.mid, a.k, a.stride);
+    if (dg.use) return launch_deep<T>(st, a, dg);
     const Geometry g = pick_tile<T>(a.Ho, a.Wo, a.Cin, a.k, a.stride);
     if (g.lds > 160 * 1024) return EFFDET_EINVAL;
     a.TH = g.TH; a.TW = g.TW; a.IH = g.IH; a.IW = g.IW; a.HP = g.HP; a.HPpad = g.HPpad; a.arow = g.arow;
@@ -239,9 +444,11 @@ int launch_mb(hipStream_t st, MbArgs& a) {
 
 }  // namespace
 
-extern "C" int effdet_mbconv_tiles_per_image(int dtype, int H, int W, int Cin, int k, int stride) {
-    if (H <= 0 || W <= 0 || Cin <= 0 || (k != 3 && k != 5) || (stride != 1 && stride != 2) || (dtype & ~1)) return EFFDET_EINVAL;
+extern "C" int effdet_mbconv_tiles_per_image(int dtype, int H, int W, int Cin, int mid, int k, int stride) {
+    if (H <= 0 || W <= 0 || Cin <= 0 || mid <= 0 || (k != 3 && k != 5) || (stride != 1 && stride != 2) || (dtype & ~1)) return EFFDET_EINVAL;
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
+    const DeepGeometry dg = dtype == 0 ? pick_deep<float>(H, W, Cin, mid, k, stride) : pick_deep<bf16_t>(H, W, Cin, mid, k, stride);
+    if (dg.use) return dg.nbands;
     const Geometry g = dtype == 0 ? pick_tile<float>(Ho, Wo, Cin, k, stride) : pick_tile<bf16_t>(Ho, Wo, Cin, k, stride);
     return ((Wo + g.TW - 1) / g.TW) * ((Ho + g.TH - 1) / g.TH);
 }

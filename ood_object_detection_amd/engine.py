@@ -135,7 +135,7 @@ class Engine(object):
                 ho, wo = _same_out(h, b['s']), _same_out(w, b['s'])
                 mid_max = max(mid_max, B * ho * wo * b['mid'])
                 if b['type'] == 'ir':
-                    nblk = lib.effdet_mbconv_tiles_per_image(dt, h, w, b['cin'], b['k'], b['s'])
+                    nblk = lib.effdet_mbconv_tiles_per_image(dt, h, w, b['cin'], b['mid'], b['k'], b['s'])
                 else:
                     nblk = lib.effdet_dwconv_blocks_per_image(ho, wo, b['mid'])
                 if nblk <= 0:
@@ -178,7 +178,7 @@ class Engine(object):
                     s2, t2 = self._fold(m.bn2)
                     taps = self._f32(self._dw_taps(m.conv_dw.weight))
                     s2, t2 = self._f32(s2), self._f32(t2)
-                    nblk = lib.effdet_mbconv_tiles_per_image(dt, h, w, b['cin'], b['k'], b['s'])
+                    nblk = lib.effdet_mbconv_tiles_per_image(dt, h, w, b['cin'], b['mid'], b['k'], b['s'])
                     plan.append((lib.effdet_mbconv_expand_dw,
                                  (dt, cur.data_ptr(), dbuf.data_ptr(), w1.data_ptr(), s1.data_ptr(), t1.data_ptr(),
                                   taps.data_ptr(), s2.data_ptr(), t2.data_ptr(), partial.data_ptr(),

@@ -103,7 +103,8 @@ def test_dwconv_se(dtype, C, H, W, k, s):
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('Cin,mid,H,W,k,s', [(16, 96, 40, 36, 3, 2), (24, 144, 22, 30, 3, 1), (24, 144, 33, 21, 5, 2),
-                                             (40, 240, 20, 20, 5, 1), (112, 672, 10, 12, 5, 2), (192, 1152, 5, 5, 3, 1)])
+                                             (40, 240, 20, 20, 5, 1), (112, 672, 10, 12, 5, 2), (192, 1152, 5, 5, 3, 1),
+                                             (80, 480, 40, 40, 3, 1), (112, 672, 40, 40, 5, 2), (192, 1152, 20, 20, 5, 1), (112, 680, 23, 17, 5, 1)])
 def test_mbconv_expand_dw_fused(dtype, Cin, mid, H, W, k, s):
     """fused expand 1x1 + BN + SiLU -> depthwise + BN + SiLU + SE pool partials vs the oracle's separate ops"""
     import _hip
@@ -122,7 +123,7 @@ def test_mbconv_expand_dw_fused(dtype, Cin, mid, H, W, k, s):
     Ho, Wo = ref.shape[2], ref.shape[3]
     xd = _hip.nhwc(x, dtype).to(DEV)
     y = torch.empty(B, Ho, Wo, mid, dtype=dtype, device=DEV)
-    nt = lib.effdet_mbconv_tiles_per_image(_hip.DT[dtype], H, W, Cin, k, s)
+    nt = lib.effdet_mbconv_tiles_per_image(_hip.DT[dtype], H, W, Cin, mid, k, s)
     assert nt > 0
     part = torch.full((B, nt, mid), float('nan'), dtype=torch.float32, device=DEV)
     dv = [t.contiguous().to(DEV) for t in (w1.reshape(mid, Cin), s1, t1, wd.permute(2, 3, 0, 1).reshape(k * k, mid), s2, t2)]
