@@ -178,9 +178,11 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs p) {
         T* dst = Cb + b * p.c_image_stride + pix * p.ldc + n;
         const int nvalid = (p.N - n) < 8 ? (p.N - n) : 8;
         float v[8];
+        const f32x4 va = *reinterpret_cast<const f32x4*>(S + row * SROW + cg * 8);        // aligned: SROW % 4 == 0
+        const f32x4 vb = *reinterpret_cast<const f32x4*>(S + row * SROW + cg * 8 + 4);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float x = S[row * SROW + cg * 8 + e];
+            float x = e < 4 ? va[e] : vb[e - 4];
             if (e < nvalid) {
                 const float sc = p.scale ? p.scale[n + e] : 1.0f;
                 x = x * sc + p.shift[n + e];

@@ -46,6 +46,14 @@ struct SepArgs {
 
 constexpr int FC = 64;    // channels per halo pass
 
+// (m, s) <- log-sum-exp merge with (om, os); a -inf maximum carries a zero sum
+DEV void merge_lse(float& m, float& s, float om, float os) {
+    const float nm = fmaxf(m, om);
+    const float s1 = (m == -INFINITY) ? 0.f : s * expf(m - nm);
+    const float s2 = (om == -INFINITY) ? 0.f : os * expf(om - nm);
+    m = nm; s = s1 + s2;
+}
+
 template <typename T>
 DEV F8 fetch_input(const SepInput& in, int b, int y, int x, int F, int c) {
     const T* base = reinterpret_cast<const T*>(in.ptr) + (long long)b * in.image_stride;
@@ -74,7 +82,7 @@ __global__ __launch_bounds__(256) void sepconv_kernel(SepArgs p) {
     constexpr int HW_ = (TH + 2) * (TW + 2);
     constexpr int WPT = BM / 64;                 // 16-row MFMA tiles per wave (BM/4 rows per wave)
     constexpr int NT = BN / 16;
-    constexpr int SROW = BN + 4;
+    constexpr int SROW = BN + 12;                // + 8 columns the alignment shift can spill into, + 4 bank spread
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int F = p.F, N = p.N;
@@ -173,9 +181,12 @@ __global__ __launch_bounds__(256) void sepconv_kernel(SepArgs p) {
     const float* scale = p.scale ? p.scale + (long long)L.affine_row * N : nullptr;
     const float* shift = p.shift + (long long)L.affine_row * N;
     T* out = reinterpret_cast<T*>(L.out) + (long long)b * L.out_image_stride;
+    float* cs = dww + 9 * F;                           // per-chunk scale[BN], shift[BN]
+    const int ppr = nkc * 4;                           // 16-byte pieces per W row
+    constexpr int WPC = 4;                             // W pieces a thread may prefetch (BN * ppr <= 1024)
+    u32x4 wpre[WPC];
 
-    for (int ch = 0; ch < nchunks; ++ch) {
-        int n_begin, n_count;
+    auto chunk_range = [&](int ch, int& n_begin, int& n_count) {
         if (ood) {
             const int a = ch / subs, sc = ch % subs;
             n_begin = a * C + sc * BN;
@@ -184,20 +195,57 @@ __global__ __launch_bounds__(256) void sepconv_kernel(SepArgs p) {
             n_begin = ch * BN;
             n_count = N - n_begin; if (n_count > BN) n_count = BN;
         }
-        // W chunk -> LDS (rows beyond n_count and the K padding are zero)
-        const int ppr = nkc * 4;                       // 16-byte pieces per row
-        for (int i = tid; i < BN * ppr; i += 256) {
-            const int row = i / ppr, piece = i % ppr;
+    };
+    const bool prefetch = BN * ppr <= 256 * WPC;
+    auto w_fetch = [&](int ch) {                        // global -> registers (in flight across the epilogue)
+        int n_begin, n_count;
+        chunk_range(ch, n_begin, n_count);
+#pragma unroll
+        for (int q = 0; q < WPC; ++q) {
+            const int i = tid + 256 * q;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (row < n_count && piece * 16 < fbytes)
-                v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.pw_w) +
-                                                    (long long)(n_begin + row) * fbytes + piece * 16);
-            *reinterpret_cast<u32x4*>(Wt + row * arow + piece * 16) = v;
+            if (i < BN * ppr) {
+                const int row = i / ppr, piece = i % ppr;
+                if (row < n_count && piece * 16 < fbytes)
+                    v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.pw_w) +
+                                                        (long long)(n_begin + row) * fbytes + piece * 16);
+            }
+            wpre[q] = v;
+        }
+    };
+    auto w_commit = [&]() {
+#pragma unroll
+        for (int q = 0; q < WPC; ++q) {
+            const int i = tid + 256 * q;
+            if (i < BN * ppr) *reinterpret_cast<u32x4*>(Wt + (i / ppr) * arow + (i % ppr) * 16) = wpre[q];
+        }
+    };
+    if (prefetch) w_fetch(0);
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        int n_begin, n_count;
+        chunk_range(ch, n_begin, n_count);
+        if (prefetch) {
+            w_commit();
+        } else {
+            for (int i = tid; i < BN * ppr; i += 256) {
+                const int row = i / ppr, piece = i % ppr;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (row < n_count && piece * 16 < fbytes)
+                    v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.pw_w) +
+                                                        (long long)(n_begin + row) * fbytes + piece * 16);
+                *reinterpret_cast<u32x4*>(Wt + row * arow + piece * 16) = v;
+            }
+        }
+        if (tid < BN) {
+            cs[tid] = (scale && tid < n_count) ? scale[n_begin + tid] : 1.0f;
+            cs[BN + tid] = tid < n_count ? shift[n_begin + tid] : 0.0f;
         }
         if (ood && (ch % subs) == 0) {
             for (int i = tid; i < BM; i += 256) { run_m[i] = -INFINITY; run_s[i] = 0.f; }
         }
         __syncthreads();
+        if (prefetch && ch + 1 < nchunks) w_fetch(ch + 1);
 
         f32x4 acc[WPT][NT];
 #pragma unroll
@@ -216,71 +264,97 @@ __global__ __launch_bounds__(256) void sepconv_kernel(SepArgs p) {
                 for (int i = 0; i < WPT; ++i) mma_chunk(a[i], bf, acc[i][j]);
             }
         }
+        // Stage the finished values (affine + activation applied here, in MFMA layout) into LDS.  Row `row` is
+        // stored shifted right by delta(row) columns, chosen so that staging column 8k of the row is the element
+        // that sits on a 16-byte boundary IN MEMORY (a row may start at any element offset, e.g. the 1620-byte
+        // class rows): the store pass then reads two aligned float4 per thread and writes whole 16-byte pieces.
+        constexpr int ALIGN_E = 16 / (int)sizeof(T);       // elements per 16 bytes
+        {
+            int delta[WPT][4];
 #pragma unroll
-        for (int i = 0; i < WPT; ++i)
+            for (int i = 0; i < WPT; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * WPT * wave + 16 * i + 4 * fpiece + r;
+                    const T* drow = out + ((long long)(y0 + row / TW) * W + (x0 + row % TW)) * N + n_begin;
+                    const int e0 = (int)((reinterpret_cast<uintptr_t>(drow) / sizeof(T)) % ALIGN_E);
+                    delta[i][r] = (8 - (ALIGN_E - e0) % ALIGN_E) % 8;
+                }
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    S[(16 * WPT * wave + 16 * i + 4 * fpiece + r) * SROW + 16 * j + frow] = acc[i][j][r];
+            for (int j = 0; j < NT; ++j) {
+                const float csc = cs[16 * j + frow], csh = cs[BN + 16 * j + frow];
+#pragma unroll
+                for (int i = 0; i < WPT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[i][j][r] * csc + csh;
+                        if (p.post_act) v = silu_t<T>(v);
+                        S[(16 * WPT * wave + 16 * i + 4 * fpiece + r) * SROW + 16 * j + frow + delta[i][r]] = v;
+                    }
+            }
+        }
         __syncthreads();
 
+        // Store pass: GPR threads per row, thread cg owns staging columns [8cg, 8cg+8) (+ the last thread of the
+        // row the 9th window that the shift can spill into).
         constexpr int GPR = BN / 8;
-        for (int g = tid; g < BM * GPR; g += 256) {     // BM*GPR is a multiple of 256: no divergence
+        for (int g = tid; g < BM * GPR; g += 256) {        // BM*GPR is a multiple of 256: no divergence
             const int row = g / GPR, cg = g % GPR;
             const int y = y0 + row / TW, x = x0 + row % TW;
             const bool inside = (y < H) && (x < W);
-            const int nloc = cg * 8;
-            int nvalid = n_count - nloc; nvalid = nvalid < 0 ? 0 : (nvalid > 8 ? 8 : nvalid);
-            float v[8];
-            float lm = -INFINITY;
+            T* drow = out + ((long long)y * W + x) * N + n_begin;
+            const int e0 = (int)((reinterpret_cast<uintptr_t>(drow) / sizeof(T)) % ALIGN_E);
+            const int dl = (8 - (ALIGN_E - e0) % ALIGN_E) % 8;
+            float tm = -INFINITY, ts = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float xv = S[row * SROW + nloc + e];
-                if (e < nvalid) {
-                    const int n = n_begin + nloc + e;
-                    xv = xv * (scale ? scale[n] : 1.0f) + shift[n];
-                    if (p.post_act) xv = silu_t<T>(xv);
-                    lm = fmaxf(lm, xv);
+            for (int pass = 0; pass < 2; ++pass) {
+                const int s0 = pass == 0 ? cg * 8 : BN;        // staging column of this window
+                if (pass == 1 && (cg != GPR - 1 || dl == 0)) continue;
+                const f32x4 va = *reinterpret_cast<const f32x4*>(S + row * SROW + s0);
+                const f32x4 vb = *reinterpret_cast<const f32x4*>(S + row * SROW + s0 + 4);
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = va[e]; v[4 + e] = vb[e]; }
+                const int c_lo = s0 - dl;                      // chunk column of v[0]
+                int lo = c_lo < 0 ? -c_lo : 0;                 // valid element range [lo, hi) inside the window
+                int hi = n_count - c_lo; hi = hi > 8 ? 8 : hi;
+                if (lo >= hi) continue;
+                if (inside) {
+                    T* dst = drow + c_lo;
+                    if (lo == 0 && hi == 8) {
+                        F8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o.v[e] = v[e];
+                        store8<T>(dst, o);
+                    } else {
+                        for (int e = lo; e < hi; ++e) dst[e] = from_f<T>(v[e]);
+                    }
                 }
-                v[e] = xv;
-            }
-            if (inside && nvalid > 0) {
-                T* dst = out + ((long long)y * W + x) * N + n_begin + nloc;
-                if (nvalid == 8 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
-                    F8 o;
+                if (ood) {
+                    float wm = -INFINITY, wsum = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o.v[e] = v[e];
-                    store8<T>(dst, o);
-                } else {
-                    for (int e = 0; e < nvalid; ++e) dst[e] = from_f<T>(v[e]);
+                    for (int e = 0; e < 8; ++e) if (e >= lo && e < hi) wm = fmaxf(wm, v[e]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (e >= lo && e < hi) wsum += exp_t<T>(v[e] - wm);
+                    merge_lse(tm, ts, wm, wsum);
                 }
             }
             if (ood) {
-                float ls = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) if (e < nvalid) ls += exp_t<T>(v[e] - lm);
-                // combine the GPR (= 8 when BN = 64) lanes of this row
 #pragma unroll
                 for (int o = 1; o < GPR; o <<= 1) {
-                    const float om = __shfl_xor(lm, o, 64), os = __shfl_xor(ls, o, 64);
-                    const float nm = fmaxf(lm, om);
-                    const float s1 = (lm == -INFINITY) ? 0.f : ls * expf(lm - nm);
-                    const float s2 = (om == -INFINITY) ? 0.f : os * expf(om - nm);
-                    lm = nm; ls = s1 + s2;
+                    const float om = __shfl_xor(tm, o, 64), os = __shfl_xor(ts, o, 64);
+                    merge_lse(tm, ts, om, os);
                 }
                 if (cg == 0) {
-                    const float pm = run_m[row], ps = run_s[row];
-                    const float nm = fmaxf(pm, lm);
-                    const float s1 = (pm == -INFINITY) ? 0.f : ps * expf(pm - nm);
-                    const float s2 = (lm == -INFINITY) ? 0.f : ls * expf(lm - nm);
-                    run_m[row] = nm; run_s[row] = s1 + s2;
+                    float pm = run_m[row], ps = run_s[row];
+                    merge_lse(pm, ps, tm, ts);
+                    run_m[row] = pm; run_s[row] = ps;
                     if ((ch % subs) == subs - 1 && inside) {
                         const int a = ch / subs;
                         const long long idx = (long long)b * p.ood_image_stride + L.ood_off +
                                               ((long long)y * W + x) * p.num_anchors + a;
-                        p.ood_energy[idx] = -(nm + logf(s1 + s2));
-                        p.ood_maxlogit[idx] = nm;
+                        p.ood_energy[idx] = -(pm + logf(ps));
+                        p.ood_maxlogit[idx] = pm;
                     }
                 }
             }
@@ -293,12 +367,12 @@ template <typename T, int TH, int TW, int BN>
 size_t sep_lds_bytes(int F) {
     constexpr int BM = TH * TW;
     constexpr int HW_ = (TH + 2) * (TW + 2);
-    constexpr int SROW = BN + 4;
+    constexpr int SROW = BN + 12;
     const int nkc = (F * (int)sizeof(T) + 63) / 64;
     const int arow = nkc * 64 + 16;
     const size_t halo = (size_t)HW_ * FC * sizeof(T);
     const size_t stage = (size_t)BM * SROW * 4 + BM * 8;
-    return (halo > stage ? halo : stage) + (size_t)BM * arow + (size_t)BN * arow + (size_t)9 * F * 4;
+    return (halo > stage ? halo : stage) + (size_t)BM * arow + (size_t)BN * arow + (size_t)9 * F * 4 + (size_t)2 * BN * 4;
 }
 
 template <typename T, int TH, int TW, int BN>

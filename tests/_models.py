@@ -32,6 +32,10 @@ def seeded_model(name='tf_efficientdet_d0', image_size=256, num_classes=90, seed
             om.efficientdet_forward(new, cfg, xcal, nodes)
     finally:
         om.CALIBRATE = False
+    # tiny maps (P6/P7 of a small image) give 2-8 samples per channel: keep their variances sane
+    for k in list(new.keys()):
+        if k.endswith('running_var'):
+            new[k] = new[k].clamp(min=0.25)
     model.load_state_dict(new, strict=True)
     nodes = get_fpn_config(cfg.fpn_name, cfg.min_level, cfg.max_level).nodes
     return model, cfg, nodes, {k: v.clone() for k, v in new.items()}
