@@ -1,0 +1,17 @@
+#!/bin/bash
+# Runs on the GPU box: rocprofv3 kernel trace + stats, then FETCH_SIZE and WRITE_SIZE PMC passes (separate runs).
+set -o pipefail
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out
+export TMPDIR=/tmp
+cd /tmp
+ARGS="$REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rp_kt -- python3 $ARGS > $OUT/rp_kt.log 2>&1 || echo "kt failed" >> $OUT/rp_kt.log
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/rp_fetch -- python3 $ARGS > $OUT/rp_fetch.log 2>&1 || echo "fetch failed" >> $OUT/rp_fetch.log
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/rp_write -- python3 $ARGS > $OUT/rp_write.log 2>&1 || echo "write failed" >> $OUT/rp_write.log
+python3 $REPO/tools/summarize_rocprof.py $OUT/rp_kt $OUT/rocprof_kernel_trace_summary.txt
+python3 $REPO/tools/summarize_rocprof.py $OUT/rp_fetch $OUT/rocprof_pmc_fetch_summary.txt
+python3 $REPO/tools/summarize_rocprof.py $OUT/rp_write $OUT/rocprof_pmc_write_summary.txt
+# keep the merged-back payload small
+find $OUT/rp_kt $OUT/rp_fetch $OUT/rp_write -name '*.csv' -size +2M -delete 2>/dev/null
+true

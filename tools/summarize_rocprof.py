@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Condense rocprofv3 CSV output (kernel trace / stats / PMC) into a small text summary for profiles/."""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r'\(anonymous namespace\)::', '', name)
+    name = re.sub(r'void ', '', name)
+    return name[:110]
+
+
+def main(root, out):
+    lines = []
+    traces = glob.glob(os.path.join(root, '**', '*kernel_trace.csv'), recursive=True)
+    agg = defaultdict(lambda: [0, 0])
+    for f in traces:
+        for r in csv.DictReader(open(f)):
+            k = short(r.get('Kernel_Name', '?'))
+            dur = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+            agg[k][0] += 1
+            agg[k][1] += dur
+    if agg:
+        tot = sum(v[1] for v in agg.values())
+        lines.append('# rocprofv3 --kernel-trace: per kernel (all dispatches of the run)')
+        lines.append('%-112s %8s %12s %10s %6s' % ('kernel', 'calls', 'total_us', 'avg_us', '%'))
+        for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            lines.append('%-112s %8d %12.1f %10.2f %6.2f' % (k, n, t / 1e3, t / 1e3 / n, 100.0 * t / tot))
+    stats = glob.glob(os.path.join(root, '**', '*kernel_stats.csv'), recursive=True)
+    for f in stats:
+        lines.append('')
+        lines.append('# rocprofv3 --stats (%s)' % os.path.basename(f))
+        rows = list(csv.reader(open(f)))
+        for r in rows[:40]:
+            lines.append(' | '.join(c[:100] for c in r))
+    pmc = glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True)
+    cagg = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+    for f in pmc:
+        for r in csv.DictReader(open(f)):
+            k = short(r.get('Kernel_Name', '?'))
+            c = r.get('Counter_Name', '?')
+            cagg[c][k][0] += 1
+            cagg[c][k][1] += float(r.get('Counter_Value', 0))
+    for c, per in cagg.items():
+        lines.append('')
+        lines.append('# PMC %s: per kernel sum over dispatches (raw counter units; FETCH_SIZE/WRITE_SIZE are KiB;'
+                     ' gfx950: double FETCH_SIZE for wide coalesced reads - MI355X_MICROARCH.md)' % c)
+        lines.append('%-112s %8s %16s %16s' % ('kernel', 'calls', 'sum', 'per_call'))
+        for k, (n, v) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+            lines.append('%-112s %8d %16.1f %16.1f' % (k, n, v, v / n))
+    open(out, 'w').write('\n'.join(lines) + '\n')
+    print('wrote', out, len(lines), 'lines')
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2])
