@@ -1,0 +1,37 @@
+"""Image sharding across the GPUs of one node (one process per GPU, no collective on the data path).
+
+Inference over a batch is embarrassingly parallel (BN runs on running statistics), so rank r simply
+takes the contiguous slice `shard_range(n, r, world)` of the images.  The only exchanges are optional:
+`max_over_ranks` (benchmark timing) and `gather_detections`, which mirrors what the reference's evaluator
+does with `all_gather_container` (effdet/distributed.py:255-278, effdet/evaluator.py:38-39) on the
+fixed-shape `[B/G, max_det, 6]` + counts tensors (RCCL on GPUs, gloo on CPU).
+"""
+import torch
+
+
+def shard_range(n, rank, world):
+    """Contiguous, balanced slice [lo, hi) of n items for `rank` of `world`."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def max_over_ranks(value, device='cpu'):
+    import torch.distributed as dist
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_detections(det, count):
+    """All-gather per-rank detections [b_r, max_det, 6] / counts [b_r] (equal b_r on every rank)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return det, count
+    world = dist.get_world_size()
+    dets = [torch.empty_like(det) for _ in range(world)]
+    counts = [torch.empty_like(count) for _ in range(world)]
+    dist.all_gather(dets, det.contiguous())
+    dist.all_gather(counts, count.contiguous())
+    return torch.cat(dets, 0), torch.cat(counts, 0)

@@ -1,0 +1,58 @@
+"""N > 1 path on CPU: two gloo ranks shard a batch, gather fixed-shape detections, reduce the bench timing."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ood_object_detection_amd.sharding import gather_detections, max_over_ranks, shard_range
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    n = 8
+    lo, hi = shard_range(n, rank, world)
+    full = torch.arange(n * 100 * 6, dtype=torch.float32).reshape(n, 100, 6)
+    counts = torch.arange(n, dtype=torch.int32)
+    det, cnt = gather_detections(full[lo:hi], counts[lo:hi])
+    t = max_over_ranks(1.0 + rank)
+    q.put((rank, lo, hi, bool(torch.equal(det, full)), bool(torch.equal(cnt, counts)), t))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_covers_everything():
+    for n in (1, 7, 64, 65):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_ranks_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [(o[1], o[2]) for o in out] == [(0, 4), (4, 8)]
+    assert all(o[3] and o[4] for o in out)
+    assert all(o[5] == 2.0 for o in out)           # max over ranks of (1.0, 2.0)
