@@ -144,29 +144,39 @@ struct SeArgs {
     const float* W1; const float* b1;       // [R][C], [R]
     const float* W2; const float* b2;       // [C][R], [C]
     float* gate;                            // [B, C]
-    int C, R;
+    int C, R, nw;                           // nw: waves that split the partial-sum rows
 };
 
-__global__ __launch_bounds__(256) void se_gate_kernel(SeArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];    // pooled[C] + r[R]
+__global__ __launch_bounds__(1024) void se_gate_kernel(SeArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];    // pooled[C] + r[R] + wave partials [16][C]
     float* pooled = sm;
     float* red = sm + p.C;
+    float* wsum = red + p.R;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int c = tid; c < p.C; c += 256) {
+    // partial sums: wave w (< nw) takes blocks w, w+nw, ... (fixed order -> bitwise reproducible)
+    for (int c = lane; c < p.C; c += 64) {
         float s = 0.f;
         const float* src = p.partial + (long long)b * p.nblk * p.C + c;
-        for (int q = 0; q < p.nblk; ++q) s += src[(long long)q * p.C];
+        if (wave < p.nw) {
+            for (int q = wave; q < p.nblk; q += p.nw) s += src[(long long)q * p.C];
+            wsum[wave * p.C + c] = s;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < p.C; c += 1024) {
+        float s = 0.f;
+        for (int w = 0; w < p.nw; ++w) s += wsum[w * p.C + c];
         pooled[c] = s * p.inv_hw;
     }
     __syncthreads();
-    for (int j = wave; j < p.R; j += 4) {
+    for (int j = wave; j < p.R; j += 16) {
         float s = 0.f;
         for (int c = lane; c < p.C; c += 64) s = fmaf(p.W1[(long long)j * p.C + c], pooled[c], s);
         s = wave_reduce_sum(s);
         if (lane == 0) red[j] = silu_f(s + p.b1[j]);
     }
     __syncthreads();
-    for (int c = tid; c < p.C; c += 256) {
+    for (int c = tid; c < p.C; c += 1024) {
         float s = p.b2[c];
         for (int j = 0; j < p.R; ++j) s = fmaf(p.W2[(long long)c * p.R + j], red[j], s);
         p.gate[(long long)b * p.C + c] = sigmoid_f(s);
@@ -278,10 +288,11 @@ extern "C" int effdet_se_gate(void* stream, const float* partial, int nblk, int 
                               float* gate, int B, int C, int R) {
     EFFDET_ENTER();
     if (!partial || !W1 || !b1 || !W2 || !b2 || !gate || nblk <= 0 || hw <= 0 || B <= 0 || C <= 0 || R <= 0) return EFFDET_EINVAL;
-    SeArgs a{partial, nblk, 1.0f / (float)hw, W1, b1, W2, b2, gate, C, R};
-    const size_t sh = (size_t)(C + R) * sizeof(float);
+    const int nw = C <= 768 ? 16 : 4;
+    SeArgs a{partial, nblk, 1.0f / (float)hw, W1, b1, W2, b2, gate, C, R, nw};
+    const size_t sh = (size_t)((nw + 1) * C + R) * sizeof(float);
     if (sh > 64 * 1024) return EFFDET_EINVAL;
-    hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), sh, reinterpret_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(1024), sh, reinterpret_cast<hipStream_t>(stream), a);
     return effdet_check_launch();
 }
 

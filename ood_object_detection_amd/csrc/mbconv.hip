@@ -29,6 +29,9 @@ struct MbArgs {
 };
 
 constexpr int MC = 64;                          // expanded channels per pass
+// Row pitch of the expanded tile in LDS: +16 bytes so that the 16 lanes which write one 4-channel column
+// of 16 different pixels spread over the banks (a 128-byte pitch puts all of them on one bank: 16-way conflict)
+template <typename T> struct ERow { static constexpr int value = MC + 16 / (int)sizeof(T); };
 
 template <typename T> struct Pack4;
 template <> struct Pack4<bf16_t> { typedef unsigned long long type; };
@@ -61,8 +64,9 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(MbArgs p) {
     // LDS carve
     char* At = lds;                                         // [HPpad][arow]
     char* Wc = At + p.HPpad * arow;                         // [MC][arow]
-    T* E = reinterpret_cast<T*>(Wc + MC * arow);            // [HP][MC]
-    float* red = reinterpret_cast<float*>(reinterpret_cast<char*>(E) + p.HP * MC * sizeof(T));   // [256][8]
+    constexpr int EROW = ERow<T>::value;
+    T* E = reinterpret_cast<T*>(Wc + MC * arow);            // [HP][EROW]
+    float* red = reinterpret_cast<float*>(reinterpret_cast<char*>(E) + p.HP * EROW * sizeof(T));   // [256][8]
 
     // ---- input halo tile -> LDS (zero rows outside the image, zero K padding)
     const T* X = reinterpret_cast<const T*>(p.X) + (long long)b * p.H * p.W * Cin;
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(MbArgs p) {
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = inside ? silu_t<T>(acc[j][r] * sc[j][r] + sh[j][r]) : 0.f;
-                    store4<T>(E + hp * MC + 16 * j + 4 * fpiece, v[0], v[1], v[2], v[3]);
+                    store4<T>(E + hp * EROW + 16 * j + 4 * fpiece, v[0], v[1], v[2], v[3]);
                 }
             }
         }
@@ -150,10 +154,10 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(MbArgs p) {
                     F8 w[KS];
 #pragma unroll
                     for (int kx = 0; kx < KS; ++kx) w[kx] = load8<float>(p.taps + (ky * KS + kx) * mid + c0 + cg * 8);
-                    const T* erow = E + ((ty * S + ky) * p.IW + tx0 * S) * MC + cg * 8;
+                    const T* erow = E + ((ty * S + ky) * p.IW + tx0 * S) * EROW + cg * 8;
 #pragma unroll
                     for (int c = 0; c < (PPT - 1) * S + KS; ++c) {
-                        const F8 e = load8<T>(erow + c * MC);
+                        const F8 e = load8<T>(erow + c * EROW);
 #pragma unroll
                         for (int pi = 0; pi < PPT; ++pi) {
                             const int kx = c - pi * S;
@@ -230,7 +234,8 @@ __global__ __launch_bounds__(256) void mbconv_deep_kernel(MbDeepArgs p) {
     char* Wc = lds;                                            // [MC][arow]; reused as pool scratch
     float* red = reinterpret_cast<float*>(lds);
     const int wc_bytes = (MC * arow > 256 * 8 * 4) ? MC * arow : 256 * 8 * 4;
-    T* E = reinterpret_cast<T*>(lds + wc_bytes);               // [npx][MC]
+    constexpr int EROW = ERow<T>::value;
+    T* E = reinterpret_cast<T*>(lds + wc_bytes);               // [npx][EROW]
 
     const int ppr = nkc * 4;
     for (int i = tid; i < MC * ppr; i += 256) {
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(256) void mbconv_deep_kernel(MbDeepArgs p) {
             if (hp < npx) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    store4<T>(E + hp * MC + 16 * j + 4 * fpiece,
+                    store4<T>(E + hp * EROW + 16 * j + 4 * fpiece,
                               silu_t<T>(acc[u][j][0] * sc[j][0] + sh[j][0]), silu_t<T>(acc[u][j][1] * sc[j][1] + sh[j][1]),
                               silu_t<T>(acc[u][j][2] * sc[j][2] + sh[j][2]), silu_t<T>(acc[u][j][3] * sc[j][3] + sh[j][3]));
             }
@@ -308,13 +313,13 @@ __global__ __launch_bounds__(256) void mbconv_deep_kernel(MbDeepArgs p) {
                 F8 w[KS];
 #pragma unroll
                 for (int kx = 0; kx < KS; ++kx) w[kx] = load8<float>(p.taps + (ky * KS + kx) * mid + c0 + cg * 8);
-                const T* erow = E + (long long)(iy - iy_lo) * W * MC + cg * 8;
+                const T* erow = E + (long long)(iy - iy_lo) * W * EROW + cg * 8;
                 const int ix0 = ox0 * S - p.pad_l;
 #pragma unroll
                 for (int c = 0; c < (PPT - 1) * S + KS; ++c) {
                     const int ix = ix0 + c;
                     if (ix < 0 || ix >= W) continue;
-                    const F8 e = load8<T>(erow + ix * MC);
+                    const F8 e = load8<T>(erow + ix * EROW);
 #pragma unroll
                     for (int pi = 0; pi < PPT; ++pi) {
                         const int kx = c - pi * S;
@@ -365,11 +370,11 @@ DeepGeometry pick_deep(int H, int W, int Cin, int mid, int k, int stride) {
     const size_t wc = (size_t)MC * g.arow > 8192 ? (size_t)MC * g.arow : 8192;
     const size_t budget = 78 * 1024;      // two workgroups per CU (160 KiB LDS)
     g.use = false;
-    if (Cin * (int)sizeof(T) < 128 || wc + (size_t)k * W * MC * sizeof(T) > budget) return g;   // wide inputs, narrow maps only
+    if (Cin * (int)sizeof(T) < 128 || wc + (size_t)k * W * ERow<T>::value * sizeof(T) > budget) return g;   // wide inputs, narrow maps only
     int rows = Ho;
     for (;;) {
         const int in_rows = (rows - 1) * stride + k < H ? (rows - 1) * stride + k : H;
-        const size_t lds = wc + (size_t)in_rows * W * MC * sizeof(T);
+        const size_t lds = wc + (size_t)in_rows * W * ERow<T>::value * sizeof(T);
         if (lds <= budget) { g.band_rows = rows; g.e_rows_max = in_rows; g.lds = lds; break; }
         if (rows == 1) return g;
         rows = (rows + 1) / 2;
@@ -393,7 +398,7 @@ Geometry pick_tile(int Ho, int Wo, int Cin, int k, int stride) {
         g.IH = (g.TH - 1) * stride + k; g.IW = (g.TW - 1) * stride + k;
         g.HP = g.IH * g.IW; g.HPpad = (g.HP + 15) / 16 * 16;
         g.arow = nkc * 64 + 16;
-        g.lds = (size_t)g.HPpad * g.arow + (size_t)MC * g.arow + (size_t)g.HP * MC * sizeof(T) + 256 * 8 * 4;
+        g.lds = (size_t)g.HPpad * g.arow + (size_t)MC * g.arow + (size_t)g.HP * ERow<T>::value * sizeof(T) + 256 * 8 * 4;
         best = g;
         // a tile much larger than the map wastes the workgroup; keep two workgroups per CU (<= 76 KiB each)
         const bool fits_map = (g.TH <= Ho || g.TH == 2) && (g.TW <= 2 * Wo);

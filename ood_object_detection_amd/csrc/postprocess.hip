@@ -94,11 +94,18 @@ __global__ __launch_bounds__(256) void topk_hist_kernel(const T* X, long long L,
     const int pshift = 64 - st.bits_done;
     const unsigned long long prefix = st.prefix;
     if (seg0 < seg1) {
+        // logits cluster in a handful of bins: run-length aggregate per thread so that identical consecutive
+        // bins cost one LDS atomic instead of one per element (same-address LDS atomics serialise)
+        unsigned int last_bin = 0xFFFFFFFFu, run = 0;
         for_each_element<T>(X + (long long)b * L, seg0, seg1, threadIdx.x, 256, [&](float f, unsigned int idx) {
             const unsigned long long key = comp_key(f, idx);
-            if (pass == 0 || (key >> pshift) == prefix)
-                atomicAdd(&h[(unsigned int)(key >> shift) & mask], 1u);
+            if (pass == 0 || (key >> pshift) == prefix) {
+                const unsigned int bin = (unsigned int)(key >> shift) & mask;
+                if (bin == last_bin) { ++run; }
+                else { if (run) atomicAdd(&h[last_bin], run); last_bin = bin; run = 1; }
+            }
         });
+        if (run) atomicAdd(&h[last_bin], run);
     }
     __syncthreads();
     unsigned int* gh = hist + (long long)b * HIST_BINS;

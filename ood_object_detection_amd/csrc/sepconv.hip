@@ -17,6 +17,7 @@
 //            LDS, affine/activation applied, whole 16-byte row pieces stored to HBM
 // so every feature map is read once and written once per node/layer.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -46,13 +47,6 @@ struct SepArgs {
 
 constexpr int FC = 64;    // channels per halo pass
 
-// (m, s) <- log-sum-exp merge with (om, os); a -inf maximum carries a zero sum
-DEV void merge_lse(float& m, float& s, float om, float os) {
-    const float nm = fmaxf(m, om);
-    const float s1 = (m == -INFINITY) ? 0.f : s * expf(m - nm);
-    const float s2 = (om == -INFINITY) ? 0.f : os * expf(om - nm);
-    m = nm; s = s1 + s2;
-}
 
 template <typename T>
 DEV F8 fetch_input(const SepInput& in, int b, int y, int x, int F, int c) {
@@ -76,13 +70,15 @@ DEV F8 fetch_input(const SepInput& in, int b, int y, int x, int F, int c) {
     return m;
 }
 
-template <typename T, int TH, int TW, int BN>
-__global__ __launch_bounds__(256) void sepconv_kernel(SepArgs p) {
+template <typename T, int TH, int TW, int BN, bool OOD>
+__global__ __launch_bounds__(256, (OOD || sizeof(T) == 4) ? 2 : 3) void sepconv_kernel(SepArgs p) {
+    // staging element: fp32 when the OOD reduction reads it back, else the output dtype (half the LDS)
+    typedef typename std::conditional<OOD, float, T>::type ST;
     constexpr int BM = TH * TW;
     constexpr int HW_ = (TH + 2) * (TW + 2);
     constexpr int WPT = BM / 64;                 // 16-row MFMA tiles per wave (BM/4 rows per wave)
     constexpr int NT = BN / 16;
-    constexpr int SROW = BN + 12;                // + 8 columns the alignment shift can spill into, + 4 bank spread
+    constexpr int SROW = BN + 24;                // + 8 columns the alignment shift can spill into, + bank spread
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int F = p.F, N = p.N;
@@ -91,11 +87,11 @@ __global__ __launch_bounds__(256) void sepconv_kernel(SepArgs p) {
     const int arow = nkc * 64 + 16;              // A / W row pitch in bytes
     // LDS carve (all multiples of 16)
     constexpr int HALO_BYTES = HW_ * FC * (int)sizeof(T);
-    constexpr int STAGE_BYTES = BM * SROW * 4 + BM * 8;
+    constexpr int STAGE_BYTES = BM * SROW * (int)sizeof(ST) + (OOD ? BM * 8 : 0);
     constexpr int R0 = HALO_BYTES > STAGE_BYTES ? HALO_BYTES : STAGE_BYTES;
     char* halo = lds;                            // phase 1/2
-    float* S = reinterpret_cast<float*>(lds);    // phase 3 staging (aliases halo)
-    float* run_m = S + BM * SROW;                // running max / sum-exp per row (OOD)
+    ST* S = reinterpret_cast<ST*>(lds);          // phase 3 staging (aliases halo)
+    float* run_m = reinterpret_cast<float*>(lds + BM * SROW * sizeof(ST));   // running max / sum-exp per row (OOD)
     float* run_s = run_m + BM;
     char* At = lds + R0;
     char* Wt = At + BM * arow;
@@ -174,8 +170,8 @@ __global__ __launch_bounds__(256) void sepconv_kernel(SepArgs p) {
 
     // ------------------------------------------------------------------ phase 3: column chunks
     const int frow = lane & 15, fpiece = lane >> 4;
-    const int C = p.ood_classes;
-    const bool ood = C > 0;
+    const int C = OOD ? p.ood_classes : 0;
+    constexpr bool ood = OOD;
     const int subs = ood ? (C + BN - 1) / BN : 1;
     const int nchunks = ood ? p.num_anchors * subs : (N + BN - 1) / BN;
     const float* scale = p.scale ? p.scale + (long long)L.affine_row * N : nullptr;
@@ -222,6 +218,34 @@ __global__ __launch_bounds__(256) void sepconv_kernel(SepArgs p) {
     };
     if (prefetch) w_fetch(0);
 
+    // Per-row constants of this tile, computed once: element offset of the row inside the image's output
+    // (pixel * N) and its position on the 16-byte grid.  `rowmod + n_begin` (mod ALIGN_E) is the shift that
+    // puts staging column 8k on a 16-byte boundary in memory.
+    constexpr int ALIGN_E = 16 / (int)sizeof(T);       // elements per 16 bytes
+    constexpr int GPR = BN / 8;
+    constexpr int RPT = BM * GPR / 256;                // rows per thread in the store pass
+    const int base_mod = (int)((reinterpret_cast<uintptr_t>(out) / sizeof(T)) % ALIGN_E);
+    int st_mod[WPT][4];                                // staging rows of this lane (MFMA layout)
+#pragma unroll
+    for (int i = 0; i < WPT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * WPT * wave + 16 * i + 4 * fpiece + r;
+            const int pix = (y0 + row / TW) * W + (x0 + row % TW);
+            st_mod[i][r] = (base_mod + (int)(((long long)pix * N) % ALIGN_E)) % ALIGN_E;
+        }
+    int sp_off[RPT], sp_mod[RPT];                      // store-pass rows of this thread
+    bool sp_in[RPT];
+    const int cg = tid % GPR;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int row = (tid + 256 * k) / GPR;
+        const int y = y0 + row / TW, x = x0 + row % TW;
+        sp_in[k] = (y < H) && (x < W);
+        sp_off[k] = (y * W + x) * N;
+        sp_mod[k] = (base_mod + (int)(((long long)(y * W + x) * N) % ALIGN_E)) % ALIGN_E;
+    }
+
     for (int ch = 0; ch < nchunks; ++ch) {
         int n_begin, n_count;
         chunk_range(ch, n_begin, n_count);
@@ -247,6 +271,7 @@ __global__ __launch_bounds__(256) void sepconv_kernel(SepArgs p) {
         __syncthreads();
         if (prefetch && ch + 1 < nchunks) w_fetch(ch + 1);
 
+        const int njt = (n_count + 15) / 16;               // 16-column tiles that hold real columns
         f32x4 acc[WPT][NT];
 #pragma unroll
         for (int i = 0; i < WPT; ++i)
@@ -259,29 +284,21 @@ __global__ __launch_bounds__(256) void sepconv_kernel(SepArgs p) {
                 a[i] = ld_frag<T>(At + (16 * WPT * wave + 16 * i + frow) * arow + kc * 64 + fpiece * 16);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                Frag<T> bf = ld_frag<T>(Wt + (16 * j + frow) * arow + kc * 64 + fpiece * 16);
+                if (j < njt) {
+                    Frag<T> bf = ld_frag<T>(Wt + (16 * j + frow) * arow + kc * 64 + fpiece * 16);
 #pragma unroll
-                for (int i = 0; i < WPT; ++i) mma_chunk(a[i], bf, acc[i][j]);
+                    for (int i = 0; i < WPT; ++i) mma_chunk(a[i], bf, acc[i][j]);
+                }
             }
         }
-        // Stage the finished values (affine + activation applied here, in MFMA layout) into LDS.  Row `row` is
-        // stored shifted right by delta(row) columns, chosen so that staging column 8k of the row is the element
-        // that sits on a 16-byte boundary IN MEMORY (a row may start at any element offset, e.g. the 1620-byte
-        // class rows): the store pass then reads two aligned float4 per thread and writes whole 16-byte pieces.
-        constexpr int ALIGN_E = 16 / (int)sizeof(T);       // elements per 16 bytes
-        {
-            int delta[WPT][4];
+        // Stage the finished values (affine + activation applied here, in MFMA layout).  Row `row` is stored
+        // shifted right by delta(row) columns so that staging column 8k is the element on a 16-byte boundary
+        // IN MEMORY (rows may start anywhere, e.g. the 1620-byte class rows): the store pass then reads aligned
+        // 8-element windows and writes whole 16-byte pieces.
+        const int nb_mod = n_begin % ALIGN_E;
 #pragma unroll
-            for (int i = 0; i < WPT; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * WPT * wave + 16 * i + 4 * fpiece + r;
-                    const T* drow = out + ((long long)(y0 + row / TW) * W + (x0 + row % TW)) * N + n_begin;
-                    const int e0 = (int)((reinterpret_cast<uintptr_t>(drow) / sizeof(T)) % ALIGN_E);
-                    delta[i][r] = (8 - (ALIGN_E - e0) % ALIGN_E) % 8;
-                }
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
+        for (int j = 0; j < NT; ++j) {
+            if (j < njt) {
                 const float csc = cs[16 * j + frow], csh = cs[BN + 16 * j + frow];
 #pragma unroll
                 for (int i = 0; i < WPT; ++i)
@@ -289,70 +306,103 @@ __global__ __launch_bounds__(256) void sepconv_kernel(SepArgs p) {
                     for (int r = 0; r < 4; ++r) {
                         float v = acc[i][j][r] * csc + csh;
                         if (p.post_act) v = silu_t<T>(v);
-                        S[(16 * WPT * wave + 16 * i + 4 * fpiece + r) * SROW + 16 * j + frow + delta[i][r]] = v;
+                        const int delta = (st_mod[i][r] + nb_mod) % ALIGN_E;
+                        S[(16 * WPT * wave + 16 * i + 4 * fpiece + r) * SROW + 16 * j + frow + delta] = (ST)v;
                     }
             }
         }
         __syncthreads();
 
-        // Store pass: GPR threads per row, thread cg owns staging columns [8cg, 8cg+8) (+ the last thread of the
-        // row the 9th window that the shift can spill into).
-        constexpr int GPR = BN / 8;
-        for (int g = tid; g < BM * GPR; g += 256) {        // BM*GPR is a multiple of 256: no divergence
-            const int row = g / GPR, cg = g % GPR;
-            const int y = y0 + row / TW, x = x0 + row % TW;
-            const bool inside = (y < H) && (x < W);
-            T* drow = out + ((long long)y * W + x) * N + n_begin;
-            const int e0 = (int)((reinterpret_cast<uintptr_t>(drow) / sizeof(T)) % ALIGN_E);
-            const int dl = (8 - (ALIGN_E - e0) % ALIGN_E) % 8;
-            float tm = -INFINITY, ts = 0.f;
+        // Store pass: GPR threads per row; thread cg owns staging columns [8cg, 8cg+8); the last thread of the
+        // row also owns the window the shift spills into.
+        constexpr float LOG2E = 1.4426950408889634f;
 #pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-                const int s0 = pass == 0 ? cg * 8 : BN;        // staging column of this window
-                if (pass == 1 && (cg != GPR - 1 || dl == 0)) continue;
-                const f32x4 va = *reinterpret_cast<const f32x4*>(S + row * SROW + s0);
-                const f32x4 vb = *reinterpret_cast<const f32x4*>(S + row * SROW + s0 + 4);
-                float v[8];
+        for (int k = 0; k < RPT; ++k) {
+            const int row = (tid + 256 * k) / GPR;
+            const int dl = (sp_mod[k] + nb_mod) % ALIGN_E;
+            T* drow = out + sp_off[k] + n_begin;
+            const int c_lo = cg * 8 - dl;
+            float v[8];
+            if constexpr (sizeof(ST) == 4) {
+                const f32x4 va = *reinterpret_cast<const f32x4*>(S + row * SROW + cg * 8);
+                const f32x4 vb = *reinterpret_cast<const f32x4*>(S + row * SROW + cg * 8 + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] = va[e]; v[4 + e] = vb[e]; }
-                const int c_lo = s0 - dl;                      // chunk column of v[0]
-                int lo = c_lo < 0 ? -c_lo : 0;                 // valid element range [lo, hi) inside the window
-                int hi = n_count - c_lo; hi = hi > 8 ? 8 : hi;
-                if (lo >= hi) continue;
-                if (inside) {
-                    T* dst = drow + c_lo;
-                    if (lo == 0 && hi == 8) {
-                        F8 o;
+            } else {
+                const bf16x8 va = *reinterpret_cast<const bf16x8*>(S + row * SROW + cg * 8);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) o.v[e] = v[e];
-                        store8<T>(dst, o);
-                    } else {
-                        for (int e = lo; e < hi; ++e) dst[e] = from_f<T>(v[e]);
-                    }
+                for (int e = 0; e < 8; ++e) v[e] = (float)va[e];
+            }
+            const bool full = (c_lo >= 0) && (c_lo + 8 <= n_count);
+            float rm = -INFINITY, rs = 0.f;
+            if (full) {                                        // the common case: no masks
+                if (sp_in[k]) {
+                    F8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o.v[e] = v[e];
+                    store8<T>(drow + c_lo, o);
                 }
-                if (ood) {
-                    float wm = -INFINITY, wsum = 0.f;
+                if constexpr (OOD) {
+                    rm = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
+                }
+            } else {
+                const int lo = c_lo < 0 ? -c_lo : 0;
+                int hi = n_count - c_lo; hi = hi > 8 ? 8 : hi;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) if (e >= lo && e < hi) wm = fmaxf(wm, v[e]);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) if (e >= lo && e < hi) wsum += exp_t<T>(v[e] - wm);
-                    merge_lse(tm, ts, wm, wsum);
+                for (int e = 0; e < 8; ++e) {
+                    const bool ok = e >= lo && e < hi;
+                    if (ok && sp_in[k]) drow[c_lo + e] = from_f<T>(v[e]);
+                    if (!ok) v[e] = -INFINITY;
+                    if constexpr (OOD) rm = fmaxf(rm, v[e]);
                 }
             }
-            if (ood) {
+            float v2[8];
+            bool spill = false;
+            if (cg == GPR - 1 && dl > 0) {                     // the spill window [BN, BN + dl)
+                spill = true;
+                const int c2 = BN - dl;
 #pragma unroll
-                for (int o = 1; o < GPR; o <<= 1) {
-                    const float om = __shfl_xor(tm, o, 64), os = __shfl_xor(ts, o, 64);
-                    merge_lse(tm, ts, om, os);
+                for (int e = 0; e < 8; ++e) {
+                    const bool ok = e < dl && c2 + e < n_count;
+                    v2[e] = ok ? (float)S[row * SROW + BN + e] : -INFINITY;
+                    if (ok && sp_in[k]) drow[c2 + e] = from_f<T>(v2[e]);
+                    if constexpr (OOD) rm = fmaxf(rm, v2[e]);
                 }
+            }
+            if constexpr (OOD) {
+#pragma unroll
+                for (int o = 1; o < GPR; o <<= 1) rm = fmaxf(rm, __shfl_xor(rm, o, 64));
+                const float t = (rm == -INFINITY) ? 0.f : rm;
+                if constexpr (sizeof(T) == 2) {
+                    const float tl = t * LOG2E;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rs += __builtin_amdgcn_exp2f(fmaf(v[e], LOG2E, -tl));   // exp2(-inf) = 0
+                    if (spill) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) rs += __builtin_amdgcn_exp2f(fmaf(v2[e], LOG2E, -tl));
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rs += (v[e] == -INFINITY) ? 0.f : expf(v[e] - t);
+                    if (spill) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) rs += (v2[e] == -INFINITY) ? 0.f : expf(v2[e] - t);
+                    }
+                }
+#pragma unroll
+                for (int o = 1; o < GPR; o <<= 1) rs += __shfl_xor(rs, o, 64);
                 if (cg == 0) {
                     float pm = run_m[row], ps = run_s[row];
-                    merge_lse(pm, ps, tm, ts);
+                    if (rm != -INFINITY) {
+                        const float nm = fmaxf(pm, rm);
+                        ps = (pm == -INFINITY ? 0.f : ps * exp_t<T>(pm - nm)) + rs * exp_t<T>(rm - nm);
+                        pm = nm;
+                    }
                     run_m[row] = pm; run_s[row] = ps;
-                    if ((ch % subs) == subs - 1 && inside) {
+                    if ((ch % subs) == subs - 1 && sp_in[k]) {
                         const int a = ch / subs;
                         const long long idx = (long long)b * p.ood_image_stride + L.ood_off +
-                                              ((long long)y * W + x) * p.num_anchors + a;
+                                              (long long)(sp_off[k] / N) * p.num_anchors + a;
                         p.ood_energy[idx] = -(pm + logf(ps));
                         p.ood_maxlogit[idx] = pm;
                     }
@@ -363,19 +413,19 @@ __global__ __launch_bounds__(256) void sepconv_kernel(SepArgs p) {
     }
 }
 
-template <typename T, int TH, int TW, int BN>
+template <typename T, int TH, int TW, int BN, bool OOD>
 size_t sep_lds_bytes(int F) {
     constexpr int BM = TH * TW;
     constexpr int HW_ = (TH + 2) * (TW + 2);
-    constexpr int SROW = BN + 12;
+    constexpr int SROW = BN + 24;
     const int nkc = (F * (int)sizeof(T) + 63) / 64;
     const int arow = nkc * 64 + 16;
     const size_t halo = (size_t)HW_ * FC * sizeof(T);
-    const size_t stage = (size_t)BM * SROW * 4 + BM * 8;
+    const size_t stage = (size_t)BM * SROW * (OOD ? 4 : sizeof(T)) + (OOD ? BM * 8 : 0);
     return (halo > stage ? halo : stage) + (size_t)BM * arow + (size_t)BN * arow + (size_t)9 * F * 4 + (size_t)2 * BN * 4;
 }
 
-template <typename T, int TH, int TW, int BN>
+template <typename T, int TH, int TW, int BN, bool OOD>
 int launch_sep(hipStream_t st, SepArgs& a, int B) {
     int tiles = 0;
     for (int i = 0; i < a.nlevels; ++i) {
@@ -384,12 +434,16 @@ int launch_sep(hipStream_t st, SepArgs& a, int B) {
         a.lv[i].tile_begin = tiles;
         tiles += a.lv[i].tiles_x * a.lv[i].tiles_y;
     }
-    const size_t lds = sep_lds_bytes<T, TH, TW, BN>(a.F);
+    const size_t lds = sep_lds_bytes<T, TH, TW, BN, OOD>(a.F);
     if (lds > 160 * 1024) return EFFDET_EINVAL;
-    auto kern = sepconv_kernel<T, TH, TW, BN>;
+    auto kern = sepconv_kernel<T, TH, TW, BN, OOD>;
     if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return EFFDET_ELAUNCH;
+        static bool attr_done = false;           // one per template instantiation
+        if (!attr_done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return EFFDET_ELAUNCH;
+            attr_done = true;
+        }
     }
     hipLaunchKernelGGL(kern, dim3(tiles, B), dim3(256), lds, st, a);
     return effdet_check_launch();
@@ -453,6 +507,7 @@ extern "C" int effdet_sepconv_fused(
         }
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == 0) return launch_sep<float, 8, 8, 64>(st, a, B);
-    return launch_sep<bf16_t, 8, 16, 64>(st, a, B);
+    const bool ood = a.ood_classes > 0;
+    if (dtype == 0) return ood ? launch_sep<float, 8, 8, 64, true>(st, a, B) : launch_sep<float, 8, 8, 64, false>(st, a, B);
+    return ood ? launch_sep<bf16_t, 8, 16, 64, true>(st, a, B) : launch_sep<bf16_t, 8, 16, 64, false>(st, a, B);
 }
