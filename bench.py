@@ -223,7 +223,8 @@ def main():
         ms_det, _ = timed(lambda: batched_detections(ct.reshape(B, -1), bt, bench.anchors.boxes, idx, cl, None, None,
                                                      cfg.max_det_per_image, bool(args.soft_nms)))
     Hs = args.image // 2
-    prof.append(('backbone.conv_stem (by difference)', 'stem', B * (3 * args.image * args.image * es + Hs * Hs * 32 * es), 2 * 27 * 32 * B * Hs * Hs, stem_ms))
+    prof.append(('backbone.conv_stem%s (by difference)' % ('+blocks.0.0.conv_dw' if eng._fuse_stem else ''), eng._stem_meta['kind'],
+                 eng._stem_meta['bytes'], eng._stem_meta['flops'], stem_ms))
     prof.append(('_post_process top-k', 'topk', 2 * B * eng.N * args.classes * es, 0, ms_topk))
     prof.append(('decode + NMS', 'nms', B * cfg.max_detection_points * 40, 0, ms_det))
     fam = {}

@@ -38,6 +38,15 @@ const char* effdet_last_error(void);
 int effdet_stem_conv(void* stream, int in_dtype, int out_dtype, const void* X, const float* Wt,
                      const float* scale, const float* shift, void* Y, int B, int H, int W, int Cout);
 
+/* Fused conv_stem + bn1 + SiLU -> blocks.0.0 depthwise 3x3/s1 + BN + SiLU (+ SE pool partials); the stem
+ * output stays in LDS.  Wk: [C][32] im2col weights (dtype), k = (ky*3+kx)*3+ci zero-padded from 27 to 32;
+ * taps [9][C] fp32; Y NHWC [B,ceil(H/2),ceil(W/2),C]; pool_partial [B][effdet_stem_dw_tiles_per_image][C]
+ * or NULL.  C <= 64. */
+int effdet_stem_dw_fused(void* stream, int in_dtype, int dtype, const void* X, const void* Wk,
+                         const float* s1, const float* t1, const float* taps, const float* s2, const float* t2,
+                         void* Y, float* pool_partial, int B, int H, int W, int C);
+int effdet_stem_dw_tiles_per_image(int H, int W);
+
 /* 1x1 conv as GEMM with folded BN / bias, optional SiLU (act=1), optional SE gate on A
  * (gate [B,K] fp32, rows_per_image = H*W), optional residual [M,N].  A: [M,K], W: [N,K].
  * Output row m goes to C + (m / rows_per_image) * c_image_stride + (m % rows_per_image) * ldc

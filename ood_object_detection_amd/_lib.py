@@ -21,6 +21,9 @@ SIGNATURES = {
     'effdet_last_error': (ctypes.c_char_p, []),
     'effdet_stem_conv': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int, c_int, c_int, c_int]),
+    'effdet_stem_dw_fused': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
+    'effdet_stem_dw_tiles_per_image': (c_int, [c_int, c_int]),
     'effdet_pw_gemm_bn_act': (c_int, [c_void_p, c_int, c_void_p, c_ll, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                       c_int, c_void_p, c_void_p, c_int, c_void_p, c_ll, c_ll]),
     'effdet_dwconv_bn_act': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

@@ -137,7 +137,7 @@ class Engine(object):
                 if b['type'] == 'ir':
                     nblk = lib.effdet_mbconv_tiles_per_image(dt, h, w, b['cin'], b['mid'], b['k'], b['s'])
                 else:
-                    nblk = lib.effdet_dwconv_blocks_per_image(ho, wo, b['mid'])
+                    nblk = max(lib.effdet_dwconv_blocks_per_image(ho, wo, b['mid']), lib.effdet_stem_dw_tiles_per_image(H, W))
                 if nblk <= 0:
                     raise NotImplementedError('block geometry (mid=%d) is outside the built range' % b['mid'])
                 part_max = max(part_max, B * nblk * b['mid'])
@@ -151,9 +151,26 @@ class Engine(object):
 
         self.x_shape = (B, 3, H, W)
         s, t = self._fold(bb.bn1)
-        wt = self._f32(bb.conv_stem.weight.detach().float().permute(2, 3, 1, 0).reshape(27, stem_c))
         s, t = self._f32(s), self._f32(t)
-        self._stem = (wt, s, t, ping[0], H, W, stem_c)
+        b00 = stages[0][0]
+        self._fuse_stem = (b00['type'] == 'ds' and b00['k'] == 3 and b00['s'] == 1 and stem_c <= 64)
+        if self._fuse_stem:
+            # conv_stem + bn1 + SiLU + blocks.0.0.conv_dw + bn1 + SiLU in one launch (stem map stays in LDS)
+            wk = torch.zeros(stem_c, 32, dtype=torch.float32, device=self.device)
+            wk[:, :27] = bb.conv_stem.weight.detach().float().permute(0, 2, 3, 1).reshape(stem_c, 27).to(self.device)
+            wk = self._w(wk)
+            m0 = bb.blocks[0][0]
+            s2, t2 = self._fold(m0.bn1)
+            taps0 = self._f32(self._dw_taps(m0.conv_dw.weight))
+            s2, t2 = self._f32(s2), self._f32(t2)
+            self._stem = (wk, s, t, taps0, s2, t2, dbuf, partial, H, W, stem_c)
+            self._stem_meta = dict(kind='stem_dw', flops=2 * B * Hs * Ws * stem_c * (27 + 9),
+                                   bytes=B * (3 * H * W + Hs * Ws * stem_c) * self.pyr_es)
+        else:
+            wt = self._f32(bb.conv_stem.weight.detach().float().permute(2, 3, 1, 0).reshape(27, stem_c))
+            self._stem = (wt, s, t, ping[0], H, W, stem_c)
+            self._stem_meta = dict(kind='stem', flops=2 * 27 * B * Hs * Ws * stem_c,
+                                   bytes=B * (3 * H * W + Hs * Ws * stem_c) * self.pyr_es)
         cur = ping[0]
         h, w = Hs, Ws
         self.feats = []
@@ -186,6 +203,9 @@ class Engine(object):
                                  dict(kind='mbconv', bytes=B * (h * w * b['cin'] + ho * wo * b['mid']) * es + b['mid'] * b['cin'] * es,
                                       flops=2 * B * (h * w * b['cin'] * b['mid'] + b['k'] * b['k'] * ho * wo * b['mid']))))
                     pw_out, bn_out = m.conv_pwl, m.bn3
+                elif si == 0 and bi == 0 and self._fuse_stem:
+                    nblk = lib.effdet_stem_dw_tiles_per_image(H, W)       # launched by run_backbone (takes x)
+                    pw_out, bn_out = m.conv_pw, m.bn2
                 else:
                     s2, t2 = self._fold(m.bn1)
                     taps = self._f32(self._dw_taps(m.conv_dw.weight))
@@ -224,12 +244,22 @@ class Engine(object):
         if x.device != self.device or x.dtype not in _DT:
             raise RuntimeError('input must be a float32/bfloat16 tensor on %s' % (self.device,))
         x = x.contiguous()
-        wt, s, t, out, H, W, c = self._stem
-        st = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(self.lib.effdet_stem_conv(st, _DT[x.dtype], self.dt, x.data_ptr(), wt.data_ptr(), s.data_ptr(),
-                                             t.data_ptr(), out.data_ptr(), self.B, H, W, c), 'backbone.conv_stem')
+        self._stem_call(x)
         self._run(self._bb_plan)
         return [f.permute(0, 3, 1, 2) for f in self.feats]
+
+    def _stem_call(self, x):
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        if self._fuse_stem:
+            wk, s, t, taps0, s2, t2, dbuf, partial, H, W, c = self._stem
+            _lib.check(self.lib.effdet_stem_dw_fused(st, _DT[x.dtype], self.dt, x.data_ptr(), wk.data_ptr(), s.data_ptr(),
+                                                     t.data_ptr(), taps0.data_ptr(), s2.data_ptr(), t2.data_ptr(),
+                                                     dbuf.data_ptr(), partial.data_ptr(), self.B, H, W, c),
+                       'backbone.conv_stem+blocks.0.0.conv_dw')
+        else:
+            wt, s, t, out, H, W, c = self._stem
+            _lib.check(self.lib.effdet_stem_conv(st, _DT[x.dtype], self.dt, x.data_ptr(), wt.data_ptr(), s.data_ptr(),
+                                                 t.data_ptr(), out.data_ptr(), self.B, H, W, c), 'backbone.conv_stem')
 
     # ------------------------------------------------------------------------------------- BiFPN
     def _build_fpn(self, fpn):

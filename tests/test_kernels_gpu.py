@@ -137,6 +137,40 @@ def test_mbconv_expand_dw_fused(dtype, Cin, mid, H, W, k, s):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('C,H,W', [(32, 64, 96), (48, 70, 38), (40, 34, 34)])
+def test_stem_dw_fused(dtype, C, H, W):
+    """conv_stem + BN + SiLU -> depthwise 3x3 + BN + SiLU (+ pool partials) in one launch vs the oracle ops"""
+    import _hip
+    from ood_object_detection_amd import _lib
+    lib = _lib.load()
+    B = 2
+    x = _rand(B, 3, H, W, seed=60).to(dtype)
+    w = _rand(C, 3, 3, 3, seed=61, scale=0.25).to(dtype)
+    s1, t1 = torch.rand(C) + 0.5, _rand(C, seed=62, scale=0.2)
+    wd = _rand(C, 1, 3, 3, seed=63, scale=0.35)
+    s2, t2 = torch.rand(C) + 0.5, _rand(C, seed=64, scale=0.2)
+    e = om.silu(om.conv2d_pad(x.float(), w.float(), None, 2, 'same') * s1[None, :, None, None] + t1[None, :, None, None])
+    if dtype == torch.bfloat16:
+        e = e.to(dtype).float()
+    ref = om.silu(om.conv2d_pad(e, wd, None, 1, 'same', groups=C) * s2[None, :, None, None] + t2[None, :, None, None])
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    wk = torch.zeros(C, 32)
+    wk[:, :27] = w.float().permute(0, 2, 3, 1).reshape(C, 27)
+    nt = lib.effdet_stem_dw_tiles_per_image(H, W)
+    y = torch.empty(B, Ho, Wo, C, dtype=dtype, device=DEV)
+    part = torch.full((B, nt, C), float('nan'), dtype=torch.float32, device=DEV)
+    dv = [t.contiguous().to(DEV) for t in (wk.to(dtype), s1, t1, wd.permute(2, 3, 0, 1).reshape(9, C), s2, t2)]
+    xd = x.to(DEV)
+    rc = lib.effdet_stem_dw_fused(_hip.stream(DEV), _hip.DT[dtype], _hip.DT[dtype], xd.data_ptr(), *[t.data_ptr() for t in dv],
+                                  y.data_ptr(), part.data_ptr(), B, H, W, C)
+    assert rc == 0
+    assert _rel(_hip.nchw(y), ref) < TOL[dtype]
+    pooled = part.sum(1).cpu() / (Ho * Wo)
+    pref = _hip.nchw(y).cpu().mean((2, 3))
+    assert float((pooled - pref).abs().max()) < 1e-4 * max(1.0, float(pref.abs().max()))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_stem_and_maxpool(dtype):
     import _hip
     from ood_object_detection_amd import _lib

@@ -103,8 +103,14 @@ def test_det_bench_predict_fp32(d0, soft):
         det = bench(x, info)
         assert det.shape == (2, 100, 6)
         anchors = op.anchor_boxes(3, 7, 3, m.config.aspect_ratios, 4.0, (256, 256))
-        c, b, idx, cl = op.post_process(d0['cls'], d0['box'], 5, 90, 5000)
-        e_ref, m_ref = om.ood_scores(d0['cls'], 90)
+        # Discrete decisions (top-k membership, the 0.01 threshold, NMS) flip on 1-ulp logit changes, so the
+        # post-processing chain is checked against the oracle fed the SAME head outputs (the head outputs
+        # themselves are checked against the oracle in test_fp32_all_stages).
+        eng = m._engine
+        cls_g = [t.float().cpu() for t in eng.head_views(eng.cls_all, 90)]
+        box_g = [t.float().cpu() for t in eng.head_views(eng.box_all, 4)]
+        c, b, idx, cl = op.post_process(cls_g, box_g, 5, 90, 5000)
+        e_ref, m_ref = om.ood_scores(cls_g, 90)
         for i in range(2):
             sc = None if info is None else info['img_scale'][i].cpu()
             sz = torch.tensor(256) if info is None else info['img_size'][i].cpu()
@@ -112,22 +118,25 @@ def test_det_bench_predict_fp32(d0, soft):
             n = int(bench.last_count[i])
             assert n == ref.shape[0]
             got = det[i, :n].cpu()
-            # north-star tolerance: classes exact, scores within 1e-3 abs, boxes within 1e-3 px abs plus 2e-5 of the
-            # size of the box and of the anchor it was decoded from: box = t * anchor_size + centre, the box head
-            # matches the oracle to ~1e-5 (fp32 summation order, amplified by this seeded random net) and the P7
-            # anchors are 1137 px, so a valid fp32 evaluation can move an edge by ~1e-2 px
-            assert torch.equal(got[:, 5], ref[:, 5])
-            err = (got[:, :4] - ref[:, :4]).abs()
-            an = anchors[idx[i][src]]
-            asize = torch.maximum(an[:, 2] - an[:, 0], an[:, 3] - an[:, 1])[:, None]
-            extent = asize + (ref[:, 2:3] - ref[:, 0:1]).abs() + (ref[:, 3:4] - ref[:, 1:2]).abs()
-            if sc is not None:
-                extent = extent * float(sc)
-            assert bool((err <= 1e-3 + 2e-5 * extent).all()), float(err.max())
-            assert float((got[:, 4] - ref[:, 4]).abs().max()) <= 1e-3
+            assert torch.equal(got[:, 5], ref[:, 5])                                   # classes exact
+            assert float((got[:, 4] - ref[:, 4]).abs().max()) <= 1e-5                  # scores (sigmoid / exp ulps)
+            assert float((got[:, :4] - ref[:, :4]).abs().max()) <= 1e-3               # boxes: north-star 1e-3 px
             a_idx = idx[i][src]
-            assert float((bench.last_ood['energy'][i, :n].cpu() - e_ref[i][a_idx]).abs().max()) <= 1e-3
-            assert float((bench.last_ood['max_logit'][i, :n].cpu() - m_ref[i][a_idx]).abs().max()) <= 1e-3
+            assert float((bench.last_ood['energy'][i, :n].cpu() - e_ref[i][a_idx]).abs().max()) <= 1e-4
+            assert float((bench.last_ood['max_logit'][i, :n].cpu() - m_ref[i][a_idx]).abs().max()) <= 1e-5
+        # end-to-end vs the all-CPU oracle: same detections up to the rare discrete flip
+        c0, b0, idx0, cl0 = op.post_process(d0['cls'], d0['box'], 5, 90, 5000)
+        for i in range(2):
+            sc = None if info is None else info['img_scale'][i].cpu()
+            sz = torch.tensor(256) if info is None else info['img_size'][i].cpu()
+            ref = op.generate_detections(c0[i], b0[i], anchors, idx0[i], cl0[i], sc, sz, 100, soft)
+            got = det[i, :int(bench.last_count[i])].cpu()
+            matched = 0
+            for r in ref:
+                same = got[got[:, 5] == r[5]]
+                if same.numel() and float((same[:, :4] - r[:4]).abs().max(dim=1)[0].min()) <= 0.05 + 1e-4 * float(r[:4].abs().max()):
+                    matched += 1
+            assert matched >= 0.9 * ref.shape[0], (matched, ref.shape[0])
     m.config.soft_nms = False
 
 
