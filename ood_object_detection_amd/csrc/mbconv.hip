@@ -26,6 +26,7 @@ struct MbArgs {
     int B, H, W, Cin, mid, Ho, Wo, k, stride, pad_t, pad_l;
     int TH, TW, IH, IW, HP, HPpad, tiles_x, tiles_y;
     int arow;                                   // LDS pitch of X / W1 rows (bytes)
+    int e_bytes;                                // size of the expanded tile (also hosts the pool scratch)
 };
 
 constexpr int MC = 64;                          // expanded channels per pass
@@ -66,58 +67,126 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(MbArgs p) {
     char* Wc = At + p.HPpad * arow;                         // [MC][arow]
     constexpr int EROW = ERow<T>::value;
     T* E = reinterpret_cast<T*>(Wc + MC * arow);            // [HP][EROW]
-    float* red = reinterpret_cast<float*>(reinterpret_cast<char*>(E) + p.HP * EROW * sizeof(T));   // [256][8]
+    float* red = reinterpret_cast<float*>(E);               // [256][8] pool scratch: reuses E after the depthwise pass
 
     // ---- input halo tile -> LDS (zero rows outside the image, zero K padding)
     const T* X = reinterpret_cast<const T*>(p.X) + (long long)b * p.H * p.W * Cin;
-    const int ppr = nkc * 4;                                // 16-byte pieces per LDS row
-    for (int i = tid; i < p.HPpad * ppr; i += 256) {
-        const int hp = i / ppr, piece = i % ppr;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (hp < p.HP && piece * 16 < cbytes) {
-            const int y = iy0 + hp / p.IW, x = ix0 + hp % p.IW;
-            if (y >= 0 && y < p.H && x >= 0 && x < p.W)
-                v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(X + ((long long)y * p.W + x) * Cin) + piece * 16);
+    const int ppr = cbytes / 16;                            // 16-byte pieces per LDS row
+    // (loads are issued four at a time before their LDS stores: a load -> store loop with a runtime trip
+    //  count is not pipelined by the compiler and would expose one memory round trip per iteration)
+    for (int i0 = tid; i0 < p.HPpad * ppr; i0 += 1024) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 256 * u;
+            v[u] = u32x4{0u, 0u, 0u, 0u};
+            if (i < p.HPpad * ppr) {
+                const int hp = i / ppr, piece = i % ppr;
+                if (hp < p.HP && piece * 16 < cbytes) {
+                    const int y = iy0 + hp / p.IW, x = ix0 + hp % p.IW;
+                    if (y >= 0 && y < p.H && x >= 0 && x < p.W)
+                        v[u] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(X + ((long long)y * p.W + x) * Cin) + piece * 16);
+                }
+            }
         }
-        *reinterpret_cast<u32x4*>(At + hp * arow + piece * 16) = v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 256 * u;
+            if (i < p.HPpad * ppr) *reinterpret_cast<u32x4*>(At + (i / ppr) * arow + (i % ppr) * 16) = v[u];
+        }
     }
 
     T* Y = reinterpret_cast<T*>(p.Y) + (long long)b * p.Ho * p.Wo * mid;
     const int n_msub = p.HPpad / 16;
     const int npix = p.TH * p.TW;
 
+    // Per-pass constants live in LDS: cpar = [s1 | t1 | s2 | t2 | taps k*k][MC].  W1 and the constants of pass
+    // c+1 are fetched into registers at the start of pass c and committed at the start of pass c+1, so their
+    // latency hides behind the expand + depthwise work.
+    constexpr int NPAR = 4 + KS * KS;
+    float* cpar = reinterpret_cast<float*>(reinterpret_cast<char*>(E) + p.e_bytes);
+    constexpr int WPC = 4, PPC = (NPAR * MC + 255) / 256;    // prefetch registers per thread
+    const bool w_pref = MC * ppr <= 256 * WPC;
+    u32x4 wpre[WPC];
+    float ppre[PPC];
+    auto fetch = [&](int c0n) {
+        const int cnn = (mid - c0n) < MC ? (mid - c0n) : MC;
+        if (w_pref) {
+#pragma unroll
+            for (int q = 0; q < WPC; ++q) {
+                const int i = tid + 256 * q;
+                wpre[q] = u32x4{0u, 0u, 0u, 0u};
+                if (i < MC * ppr) {
+                    const int row = i / ppr, piece = i % ppr;
+                    if (row < cnn && piece * 16 < cbytes)
+                        wpre[q] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.W1) + (long long)(c0n + row) * cbytes + piece * 16);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PPC; ++q) {
+            const int i = tid + 256 * q;
+            float v = 0.f;
+            if (i < NPAR * MC) {
+                const int r = i / MC, c = i % MC;
+                if (c < cnn) {
+                    const float* src = r == 0 ? p.s1 : r == 1 ? p.t1 : r == 2 ? p.s2 : r == 3 ? p.t2 : p.taps + (long long)(r - 4) * mid;
+                    v = src[c0n + c];
+                }
+            }
+            ppre[q] = v;
+        }
+    };
+    auto commit = [&](int c0n) {
+        const int cnn = (mid - c0n) < MC ? (mid - c0n) : MC;
+        if (w_pref) {
+#pragma unroll
+            for (int q = 0; q < WPC; ++q) {
+                const int i = tid + 256 * q;
+                if (i < MC * ppr) *reinterpret_cast<u32x4*>(Wc + (i / ppr) * arow + (i % ppr) * 16) = wpre[q];
+            }
+        } else {
+            for (int i = tid; i < MC * ppr; i += 256) {
+                const int row = i / ppr, piece = i % ppr;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (row < cnn && piece * 16 < cbytes)
+                    v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.W1) + (long long)(c0n + row) * cbytes + piece * 16);
+                *reinterpret_cast<u32x4*>(Wc + row * arow + piece * 16) = v;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PPC; ++q) {
+            const int i = tid + 256 * q;
+            if (i < NPAR * MC) cpar[i] = ppre[q];
+        }
+    };
+    fetch(0);
+
     for (int c0 = 0; c0 < mid; c0 += MC) {
         const int cn = (mid - c0) < MC ? (mid - c0) : MC;   // valid channels in this pass (multiple of 8)
-        __syncthreads();                                    // previous pass done with Wc / E / red
-        for (int i = tid; i < MC * ppr; i += 256) {
-            const int row = i / ppr, piece = i % ppr;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (row < cn && piece * 16 < cbytes)
-                v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.W1) + (long long)(c0 + row) * cbytes + piece * 16);
-            *reinterpret_cast<u32x4*>(Wc + row * arow + piece * 16) = v;
-        }
+        __syncthreads();                                    // previous pass done with Wc / E / red / cpar
+        commit(c0);
         __syncthreads();
+        if (c0 + MC < mid) fetch(c0 + MC);
         // ---- expand: rows of the accumulator = channels, columns = halo pixels
         f32x4 sc[4], sh[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int ch = c0 + 16 * j + 4 * fpiece;
-            if (16 * j + 4 * fpiece < cn) {
-                sc[j] = *reinterpret_cast<const f32x4*>(p.s1 + ch);
-                sh[j] = *reinterpret_cast<const f32x4*>(p.t1 + ch);
-            } else {
-                sc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; sh[j] = sc[j];
-            }
+            sc[j] = *reinterpret_cast<const f32x4*>(cpar + 16 * j + 4 * fpiece);          // zero past cn
+            sh[j] = *reinterpret_cast<const f32x4*>(cpar + MC + 16 * j + 4 * fpiece);
         }
         for (int ms = wave; ms < n_msub; ms += 4) {
             f32x4 acc[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int kc = 0; kc < nkc; ++kc) {
-                const Frag<T> xf = ld_frag<T>(At + (16 * ms + frow) * arow + kc * 64 + fpiece * 16);
+                const int off = kc * 64 + fpiece * 16;        // rows hold exactly cbytes (+16 pad): guard the tail
+                Frag<T> xf;
+                if (off < cbytes) xf = ld_frag<T>(At + (16 * ms + frow) * arow + off); else xf.v = decltype(xf.v){};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const Frag<T> wf = ld_frag<T>(Wc + (16 * j + frow) * arow + kc * 64 + fpiece * 16);
+                    Frag<T> wf;
+                    if (off < cbytes) wf = ld_frag<T>(Wc + (16 * j + frow) * arow + off); else wf.v = decltype(wf.v){};
                     mma_chunk(wf, xf, acc[j]);
                 }
             }
@@ -140,7 +209,7 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(MbArgs p) {
         F8 pool = f8_zero();
         const int cg = tid & 7;                              // fixed per thread: 256 % 8 == 0
         if (cg < cgn) {
-            const F8 s2 = load8<float>(p.s2 + c0 + cg * 8), t2 = load8<float>(p.t2 + c0 + cg * 8);
+            const F8 s2 = load8<float>(cpar + 2 * MC + cg * 8), t2 = load8<float>(cpar + 3 * MC + cg * 8);
             const int gpr = p.TW / PPT;                      // pixel groups per tile row
             for (int pg = tid >> 3; pg < p.TH * gpr; pg += 32) {
                 const int ty = pg / gpr, tx0 = (pg % gpr) * PPT;
@@ -153,7 +222,7 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(MbArgs p) {
                 for (int ky = 0; ky < KS; ++ky) {          // not unrolled: keeps one kernel row of taps live
                     F8 w[KS];
 #pragma unroll
-                    for (int kx = 0; kx < KS; ++kx) w[kx] = load8<float>(p.taps + (ky * KS + kx) * mid + c0 + cg * 8);
+                    for (int kx = 0; kx < KS; ++kx) w[kx] = load8<float>(cpar + (4 + ky * KS + kx) * MC + cg * 8);
                     const T* erow = E + ((ty * S + ky) * p.IW + tx0 * S) * EROW + cg * 8;
 #pragma unroll
                     for (int c = 0; c < (PPT - 1) * S + KS; ++c) {
@@ -184,6 +253,7 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(MbArgs p) {
             }
         }
         if (p.pool_partial != nullptr) {
+            __syncthreads();                                // every thread is done reading E
             store8<float>(red + tid * 8, pool);
             __syncthreads();
             if (tid < cn) {
@@ -255,6 +325,20 @@ __global__ __launch_bounds__(256) void mbconv_deep_kernel(MbDeepArgs p) {
             sc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; sh[j] = sc[j];
         }
     }
+    // depthwise constants of this channel slice: fetched now, parked in the W slot once the expand is done
+    constexpr int NPAR = 2 + KS * KS;                         // s2 | t2 | taps
+    constexpr int PPC = (NPAR * MC + 255) / 256;
+    float ppre[PPC];
+#pragma unroll
+    for (int q = 0; q < PPC; ++q) {
+        const int i = tid + 256 * q;
+        float v = 0.f;
+        if (i < NPAR * MC) {
+            const int r = i / MC, c = i % MC;
+            if (c < cn) v = (r == 0 ? p.s2 : r == 1 ? p.t2 : p.taps + (long long)(r - 2) * mid)[c0 + c];
+        }
+        ppre[q] = v;
+    }
     __syncthreads();
     // ---- expand the band: two 16-pixel sub-tiles per step share every W fragment read
     const char* Xb = reinterpret_cast<const char*>(p.X) + ((long long)b * p.H * W + (long long)iy_lo * W) * cbytes;
@@ -268,16 +352,27 @@ __global__ __launch_bounds__(256) void mbconv_deep_kernel(MbDeepArgs p) {
         const int hp0 = 32 * mp + frow, hp1 = hp0 + 16;
         const char* x0 = Xb + (long long)(hp0 < npx ? hp0 : 0) * cbytes;
         const char* x1 = Xb + (long long)(hp1 < npx ? hp1 : 0) * cbytes;
-        for (int kc = 0; kc < nkc; ++kc) {
-            const int off = kc * 64 + fpiece * 16;
-            Frag<T> xf0, xf1;
-            if (off < cbytes) { xf0 = ld_frag<T>(x0 + off); xf1 = ld_frag<T>(x1 + off); }
-            else { xf0.v = decltype(xf0.v){}; xf1.v = decltype(xf1.v){}; }
+        // X fragments of four K-chunks are fetched together (one exposed L2 round trip per four chunks
+        // instead of one per chunk), then consumed by the MFMAs
+        for (int kc0 = 0; kc0 < nkc; kc0 += 4) {
+            Frag<T> xa[4], xb[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const Frag<T> wf = ld_frag<T>(Wc + (16 * j + frow) * arow + off);
-                mma_chunk(wf, xf0, acc[0][j]);
-                mma_chunk(wf, xf1, acc[1][j]);
+            for (int u = 0; u < 4; ++u) {
+                const int off = (kc0 + u) * 64 + fpiece * 16;
+                if (kc0 + u < nkc && off < cbytes) { xa[u] = ld_frag<T>(x0 + off); xb[u] = ld_frag<T>(x1 + off); }
+                else { xa[u].v = decltype(xa[u].v){}; xb[u].v = decltype(xb[u].v){}; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (kc0 + u < nkc) {
+                    const int off = (kc0 + u) * 64 + fpiece * 16;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const Frag<T> wf = ld_frag<T>(Wc + (16 * j + frow) * arow + off);
+                        mma_chunk(wf, xa[u], acc[0][j]);
+                        mma_chunk(wf, xb[u], acc[1][j]);
+                    }
+                }
             }
         }
 #pragma unroll
@@ -293,13 +388,20 @@ __global__ __launch_bounds__(256) void mbconv_deep_kernel(MbDeepArgs p) {
         }
     }
     __syncthreads();
+    float* cpar = reinterpret_cast<float*>(lds);               // reuses the W slot: [s2 | t2 | taps][MC]
+#pragma unroll
+    for (int q = 0; q < PPC; ++q) {
+        const int i = tid + 256 * q;
+        if (i < NPAR * MC) cpar[i] = ppre[q];
+    }
+    __syncthreads();
     // ---- depthwise over the band, borders by index checks
     T* Y = reinterpret_cast<T*>(p.Y) + (long long)b * p.Ho * p.Wo * mid;
     const int cgn = cn / 8;
     F8 pool = f8_zero();
     const int cg = tid & 7;
     if (cg < cgn) {
-        const F8 s2 = load8<float>(p.s2 + c0 + cg * 8), t2 = load8<float>(p.t2 + c0 + cg * 8);
+        const F8 s2 = load8<float>(cpar + cg * 8), t2 = load8<float>(cpar + MC + cg * 8);
         const int gpr = (p.Wo + PPT - 1) / PPT;
         for (int pg = tid >> 3; pg < (oy_e - oy_b) * gpr; pg += 32) {
             const int oy = oy_b + pg / gpr, ox0 = (pg % gpr) * PPT;
@@ -312,7 +414,7 @@ __global__ __launch_bounds__(256) void mbconv_deep_kernel(MbDeepArgs p) {
                 if (iy < 0 || iy >= p.H) continue;
                 F8 w[KS];
 #pragma unroll
-                for (int kx = 0; kx < KS; ++kx) w[kx] = load8<float>(p.taps + (ky * KS + kx) * mid + c0 + cg * 8);
+                for (int kx = 0; kx < KS; ++kx) w[kx] = load8<float>(cpar + (2 + ky * KS + kx) * MC + cg * 8);
                 const T* erow = E + (long long)(iy - iy_lo) * W * EROW + cg * 8;
                 const int ix0 = ox0 * S - p.pad_l;
 #pragma unroll
@@ -385,24 +487,26 @@ DeepGeometry pick_deep(int H, int W, int Cin, int mid, int k, int stride) {
     return g;
 }
 
-struct Geometry { int TH, TW, IH, IW, HP, HPpad, arow; size_t lds; };
+struct Geometry { int TH, TW, IH, IW, HP, HPpad, arow, e_bytes; size_t lds; };
 
 template <typename T>
 Geometry pick_tile(int Ho, int Wo, int Cin, int k, int stride) {
     const int cand[][2] = {{8, 16}, {8, 8}, {4, 16}, {4, 8}, {4, 4}, {2, 4}};     // TW is a multiple of 4
-    const int nkc = (Cin * (int)sizeof(T) + 63) / 64;
     Geometry best{};
     for (auto& c : cand) {
         Geometry g;
         g.TH = c[0]; g.TW = c[1];
         g.IH = (g.TH - 1) * stride + k; g.IW = (g.TW - 1) * stride + k;
         g.HP = g.IH * g.IW; g.HPpad = (g.HP + 15) / 16 * 16;
-        g.arow = nkc * 64 + 16;
-        g.lds = (size_t)g.HPpad * g.arow + (size_t)MC * g.arow + (size_t)g.HP * ERow<T>::value * sizeof(T) + 256 * 8 * 4;
+        g.arow = Cin * (int)sizeof(T) + 16;
+        g.e_bytes = g.HP * ERow<T>::value * (int)sizeof(T);
+        if (g.e_bytes < 256 * 8 * 4) g.e_bytes = 256 * 8 * 4;
+        g.e_bytes = (g.e_bytes + 15) / 16 * 16;
+        g.lds = (size_t)g.HPpad * g.arow + (size_t)MC * g.arow + (size_t)g.e_bytes + (size_t)(4 + k * k) * MC * 4;
         best = g;
         // a tile much larger than the map wastes the workgroup; keep two workgroups per CU (<= 76 KiB each)
         const bool fits_map = (g.TH <= Ho || g.TH == 2) && (g.TW <= 2 * Wo);
-        if (g.lds <= 76 * 1024 && fits_map) return g;
+        if (g.lds <= 78 * 1024 && fits_map) return g;
     }
     return best;
 }
@@ -428,7 +532,7 @@ int launch_mb(hipStream_t st, MbArgs& a) {
     if (dg.use) return launch_deep<T>(st, a, dg);
     const Geometry g = pick_tile<T>(a.Ho, a.Wo, a.Cin, a.k, a.stride);
     if (g.lds > 160 * 1024) return EFFDET_EINVAL;
-    a.TH = g.TH; a.TW = g.TW; a.IH = g.IH; a.IW = g.IW; a.HP = g.HP; a.HPpad = g.HPpad; a.arow = g.arow;
+    a.TH = g.TH; a.TW = g.TW; a.IH = g.IH; a.IW = g.IW; a.HP = g.HP; a.HPpad = g.HPpad; a.arow = g.arow; a.e_bytes = g.e_bytes;
     a.tiles_x = (a.Wo + g.TW - 1) / g.TW; a.tiles_y = (a.Ho + g.TH - 1) / g.TH;
     dim3 grid(a.tiles_x * a.tiles_y, a.B), block(256);
     // outputs per thread along x in the depthwise phase: keep all 256 threads busy on small tiles

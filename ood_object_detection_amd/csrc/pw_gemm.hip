@@ -26,7 +26,6 @@ struct PwArgs {
 };
 
 constexpr int BM = 128;
-constexpr int ROWB = 80;   // bytes per LDS row: 64-byte K-chunk + 16 pad
 
 template <typename T> struct Chunk { u32x4 raw; };
 
@@ -50,6 +49,10 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs p) {
     constexpr int EPC = VecTraits<T>::EPC;          // elements per 16-byte piece
     constexpr int KPC = 64 / (int)sizeof(T);        // elements per 64-byte K-chunk
     constexpr int NT = BN / 16;                     // 16-wide column tiles per wave
+    // 64-byte K-chunks per pipeline stage: two for the wide tile (more bytes in flight at 2 workgroups/CU),
+    // one for the narrow tiles, whose small LDS footprint already gives 4-6 workgroups per CU
+    constexpr int KCH = BN >= 128 ? 2 : 1;
+    constexpr int ROWB = KCH * 64 + 16;             // bytes per LDS row: stage of K + 16 pad
     constexpr int A_BYTES = BM * ROWB;
     constexpr int W_BYTES = BN * ROWB;
     constexpr int TILE_BYTES = 2 * (A_BYTES + W_BYTES);
@@ -69,61 +72,65 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs p) {
     const int n0 = nt * BN;
     const int K = p.K;
     const long long pitch = (long long)K * (long long)sizeof(T);
-    const int nkc = (K + KPC - 1) / KPC;
+    const int nkc = (K + KPC - 1) / KPC;            // 64-byte chunks
+    const int nst = (nkc + KCH - 1) / KCH;          // pipeline stages
 
     const char* Ab = reinterpret_cast<const char*>(p.A);
     const char* Wb = reinterpret_cast<const char*>(p.W);
 
-    // staging assignment: A has 512 pieces (128 rows x 4), W has BN*4 pieces
-    const int a_piece = tid & 3;
-    const int a_row0 = tid >> 2;                    // rows a_row0 and a_row0 + 64
-    constexpr int W_PIECES = BN * 4;
+    // staging assignment: per stage A has 128 rows x PPR pieces, W has BN x PPR pieces (16 bytes each)
+    constexpr int PPR = KCH * 4;
+    constexpr int A_PER_THREAD = BM * PPR / 256;
+    constexpr int W_PIECES = BN * PPR;
     constexpr int W_PER_THREAD = (W_PIECES + 255) / 256;
 
-    u32x4 a_reg[2];
+    u32x4 a_reg[A_PER_THREAD];
     u32x4 w_reg[W_PER_THREAD];
 
-    auto load_chunk = [&](int kc) {
-        const int kb = kc * 64 + a_piece * 16;       // byte offset inside the row
-        const int ke = kc * KPC + a_piece * EPC;     // element offset
+    auto load_stage = [&](int stg) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const long long m = m0 + a_row0 + 64 * h;
+        for (int q = 0; q < A_PER_THREAD; ++q) {
+            const int idx = tid + 256 * q;
+            const int piece = idx % PPR, row = idx / PPR;
+            const long long m = m0 + row;
+            const int ke = stg * KCH * KPC + piece * EPC;    // element offset along K
             u32x4 v = {0u, 0u, 0u, 0u};
             if (m < p.M && ke < K) {
-                v = *reinterpret_cast<const u32x4*>(Ab + m * pitch + kb);
+                v = *reinterpret_cast<const u32x4*>(Ab + m * pitch + (long long)ke * sizeof(T));
                 if (p.gate != nullptr) {
                     const long long b = m / p.rows_per_image;
                     v = apply_gate<T>(v, p.gate + b * K + ke);
                 }
             }
-            a_reg[h] = v;
+            a_reg[q] = v;
         }
 #pragma unroll
         for (int q = 0; q < W_PER_THREAD; ++q) {
             const int idx = tid + 256 * q;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (idx < W_PIECES) {
-                const int piece = idx & 3, row = idx >> 2;
+                const int piece = idx % PPR, row = idx / PPR;
                 const int n = n0 + row;
-                const int kew = kc * KPC + piece * EPC;
-                if (n < p.N && kew < K)
-                    v = *reinterpret_cast<const u32x4*>(Wb + (long long)n * pitch + kc * 64 + piece * 16);
+                const int ke = stg * KCH * KPC + piece * EPC;
+                if (n < p.N && ke < K)
+                    v = *reinterpret_cast<const u32x4*>(Wb + (long long)n * pitch + (long long)ke * sizeof(T));
             }
             w_reg[q] = v;
         }
     };
-    auto store_chunk = [&](int buf) {
+    auto store_stage = [&](int buf) {
         char* Ad = lds + buf * (A_BYTES + W_BYTES);
         char* Wd = Ad + A_BYTES;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-            *reinterpret_cast<u32x4*>(Ad + (a_row0 + 64 * h) * ROWB + a_piece * 16) = a_reg[h];
+        for (int q = 0; q < A_PER_THREAD; ++q) {
+            const int idx = tid + 256 * q;
+            *reinterpret_cast<u32x4*>(Ad + (idx / PPR) * ROWB + (idx % PPR) * 16) = a_reg[q];
+        }
 #pragma unroll
         for (int q = 0; q < W_PER_THREAD; ++q) {
             const int idx = tid + 256 * q;
             if (idx < W_PIECES)
-                *reinterpret_cast<u32x4*>(Wd + (idx >> 2) * ROWB + (idx & 3) * 16) = w_reg[q];
+                *reinterpret_cast<u32x4*>(Wd + (idx / PPR) * ROWB + (idx % PPR) * 16) = w_reg[q];
         }
     };
 
@@ -133,25 +140,30 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    load_chunk(0);
-    store_chunk(0);
+    load_stage(0);
+    store_stage(0);
     __syncthreads();
 
     const int frow = lane & 15, fpiece = lane >> 4;
-    for (int kc = 0; kc < nkc; ++kc) {
-        const int buf = kc & 1;
-        if (kc + 1 < nkc) load_chunk(kc + 1);
+    for (int stg = 0; stg < nst; ++stg) {
+        const int buf = stg & 1;
+        if (stg + 1 < nst) load_stage(stg + 1);
         const char* As = lds + buf * (A_BYTES + W_BYTES);
         const char* Ws = As + A_BYTES;
-        Frag<T> a0 = ld_frag<T>(As + (32 * wave + frow) * ROWB + fpiece * 16);
-        Frag<T> a1 = ld_frag<T>(As + (32 * wave + 16 + frow) * ROWB + fpiece * 16);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            Frag<T> b = ld_frag<T>(Ws + (16 * j + frow) * ROWB + fpiece * 16);
-            mma_chunk(a0, b, acc[0][j]);
-            mma_chunk(a1, b, acc[1][j]);
+        for (int sub = 0; sub < KCH; ++sub) {
+            if (stg * KCH + sub < nkc) {
+                Frag<T> a0 = ld_frag<T>(As + (32 * wave + frow) * ROWB + sub * 64 + fpiece * 16);
+                Frag<T> a1 = ld_frag<T>(As + (32 * wave + 16 + frow) * ROWB + sub * 64 + fpiece * 16);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    Frag<T> b = ld_frag<T>(Ws + (16 * j + frow) * ROWB + sub * 64 + fpiece * 16);
+                    mma_chunk(a0, b, acc[0][j]);
+                    mma_chunk(a1, b, acc[1][j]);
+                }
+            }
         }
-        if (kc + 1 < nkc) store_chunk(buf ^ 1);
+        if (stg + 1 < nst) store_stage(buf ^ 1);
         __syncthreads();
     }
 

@@ -122,32 +122,54 @@ __global__ __launch_bounds__(256, (OOD || sizeof(T) == 4) ? 2 : 3) void sepconv_
         const int fcn = (F - fc0) < FC ? (F - fc0) : FC;
         const int fcg = fcn / 8;
         __syncthreads();
-        for (int it = tid; it < HW_ * fcg; it += 256) {
-            const int cg = it % fcg, hp = it / fcg;
-            const int y = y0 + hp / (TW + 2) - 1, x = x0 + hp % (TW + 2) - 1;
-            F8 v = f8_zero();
-            if (y >= 0 && y < H && x >= 0 && x < W) {
-                const int c = fc0 + cg * 8;
-                if (p.fuse_mode == 0) {
-                    v = fetch_input<T>(L.in[0], b, y, x, F, c);
-                } else {
-                    for (int i = 0; i < p.n_in; ++i) {
-                        const F8 xi = fetch_input<T>(L.in[i], b, y, x, F, c);
-                        if (p.fuse_mode == 1) {
+        // two halo items per step: their input loads are all issued before the first use (the loop has a runtime
+        // trip count, so the compiler would otherwise expose one memory round trip per item)
+        for (int it0 = tid; it0 < HW_ * fcg; it0 += 512) {
+            F8 xin[2][3];
+            bool ok[2];
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v.v[e] += (xi.v[e] * p.fw[i]) / p.fden;
-                        } else {
+            for (int u = 0; u < 2; ++u) {
+                const int it = it0 + 256 * u;
+                const int cgh = it % fcg, hp = it / fcg;
+                const int y = y0 + hp / (TW + 2) - 1, x = x0 + hp % (TW + 2) - 1;
+                ok[u] = it < HW_ * fcg && y >= 0 && y < H && x >= 0 && x < W;
+                if (ok[u]) {
+                    const int c = fc0 + cgh * 8;
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v.v[e] += xi.v[e] * p.fw[i];
-                        }
-                    }
-                }
-                if (p.pre_act) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v.v[e] = silu_t<T>(v.v[e]);
+                    for (int i = 0; i < 3; ++i)
+                        if (i < p.n_in) xin[u][i] = fetch_input<T>(L.in[i], b, y, x, F, c);
                 }
             }
-            store8<T>(reinterpret_cast<T*>(halo) + hp * FC + cg * 8, v);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int it = it0 + 256 * u;
+                if (it >= HW_ * fcg) continue;
+                const int cgh = it % fcg, hp = it / fcg;
+                F8 v = f8_zero();
+                if (ok[u]) {
+                    if (p.fuse_mode == 0) {
+                        v = xin[u][0];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            if (i < p.n_in) {
+                                if (p.fuse_mode == 1) {
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) v.v[e] += (xin[u][i].v[e] * p.fw[i]) / p.fden;
+                                } else {
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) v.v[e] += xin[u][i].v[e] * p.fw[i];
+                                }
+                            }
+                        }
+                    }
+                    if (p.pre_act) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v.v[e] = silu_t<T>(v.v[e]);
+                    }
+                }
+                store8<T>(reinterpret_cast<T*>(halo) + hp * FC + cgh * 8, v);
+            }
         }
         __syncthreads();
         for (int it = tid; it < BM * fcg; it += 256) {
@@ -181,6 +203,7 @@ __global__ __launch_bounds__(256, (OOD || sizeof(T) == 4) ? 2 : 3) void sepconv_
     const int ppr = nkc * 4;                           // 16-byte pieces per W row
     constexpr int WPC = 4;                             // W pieces a thread may prefetch (BN * ppr <= 1024)
     u32x4 wpre[WPC];
+    float cpre_s = 1.0f, cpre_t = 0.0f;                 // next chunk's scale / shift for column `tid`
 
     auto chunk_range = [&](int ch, int& n_begin, int& n_count) {
         if (ood) {
@@ -207,6 +230,10 @@ __global__ __launch_bounds__(256, (OOD || sizeof(T) == 4) ? 2 : 3) void sepconv_
                                                         (long long)(n_begin + row) * fbytes + piece * 16);
             }
             wpre[q] = v;
+        }
+        if (tid < BN) {
+            cpre_s = (scale && tid < n_count) ? scale[n_begin + tid] : 1.0f;
+            cpre_t = tid < n_count ? shift[n_begin + tid] : 0.0f;
         }
     };
     auto w_commit = [&]() {
@@ -262,8 +289,11 @@ __global__ __launch_bounds__(256, (OOD || sizeof(T) == 4) ? 2 : 3) void sepconv_
             }
         }
         if (tid < BN) {
-            cs[tid] = (scale && tid < n_count) ? scale[n_begin + tid] : 1.0f;
-            cs[BN + tid] = tid < n_count ? shift[n_begin + tid] : 0.0f;
+            if (prefetch) { cs[tid] = cpre_s; cs[BN + tid] = cpre_t; }
+            else {
+                cs[tid] = (scale && tid < n_count) ? scale[n_begin + tid] : 1.0f;
+                cs[BN + tid] = tid < n_count ? shift[n_begin + tid] : 0.0f;
+            }
         }
         if (ood && (ch % subs) == 0) {
             for (int i = tid; i < BM; i += 256) { run_m[i] = -INFINITY; run_s[i] = 0.f; }

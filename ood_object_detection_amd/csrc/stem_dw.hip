@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(SdArgs p) {
     char* Wl = lds + ((IN_ELEMS * (int)sizeof(T) + 15) / 16) * 16;           // [cpad][WROW]
     T* E = reinterpret_cast<T*>(Wl + cpad * WROW);                           // [HP][erow]
     float* red = reinterpret_cast<float*>(reinterpret_cast<char*>(E) + ((SD_HP * erow * (int)sizeof(T) + 15) / 16) * 16);
+    float* par = red + 256 * 8;                                              // [13][C] per-channel constants
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fpiece = lane >> 4;
@@ -58,19 +59,33 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(SdArgs p) {
     const int sy0 = oy0 - 1, sx0 = ox0 - 1;
     const int iy0 = 2 * sy0 - p.pad_t, ix0 = 2 * sx0 - p.pad_l;
 
-    // ---- phase 0: input patch
+    // ---- phase 0: input patch.  All loads of a thread are issued before the first LDS store (a load -> store
+    // loop with a runtime trip count is not pipelined by the compiler: every iteration would expose a full
+    // memory round trip).
     const long long plane = (long long)p.H * p.W;
-    for (int i = tid; i < IN_ELEMS; i += 256) {
-        float v = 0.f;
-        if (i < 3 * SD_IH * SD_IW) {
-            const int ci = i / (SD_IH * SD_IW), rem = i % (SD_IH * SD_IW);
-            const int y = iy0 + rem / SD_IW, x = ix0 + rem % SD_IW;
-            if (y >= 0 && y < p.H && x >= 0 && x < p.W) {
-                const long long off = ((long long)b * 3 + ci) * plane + (long long)y * p.W + x;
-                v = p.in_dtype == 0 ? reinterpret_cast<const float*>(p.X)[off] : (float)reinterpret_cast<const bf16_t*>(p.X)[off];
+    constexpr int IN_REAL = 3 * SD_IH * SD_IW;
+    constexpr int IN_PER_THREAD = (IN_ELEMS + 255) / 256;
+    {
+        float vin[IN_PER_THREAD];
+#pragma unroll
+        for (int q = 0; q < IN_PER_THREAD; ++q) {
+            const int i = tid + 256 * q;
+            float v = 0.f;
+            if (i < IN_REAL) {
+                const int ci = i / (SD_IH * SD_IW), rem = i % (SD_IH * SD_IW);
+                const int y = iy0 + rem / SD_IW, x = ix0 + rem % SD_IW;
+                if (y >= 0 && y < p.H && x >= 0 && x < p.W) {
+                    const long long off = ((long long)b * 3 + ci) * plane + (long long)y * p.W + x;
+                    v = p.in_dtype == 0 ? reinterpret_cast<const float*>(p.X)[off] : (float)reinterpret_cast<const bf16_t*>(p.X)[off];
+                }
             }
+            vin[q] = v;
         }
-        In[i] = from_f<T>(v);
+#pragma unroll
+        for (int q = 0; q < IN_PER_THREAD; ++q) {
+            const int i = tid + 256 * q;
+            if (i < IN_ELEMS) In[i] = from_f<T>(vin[q]);
+        }
     }
     for (int i = tid; i < cpad * (WROW / 16); i += 256) {
         const int row = i / (WROW / 16), piece = i % (WROW / 16);
@@ -78,6 +93,16 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(SdArgs p) {
         if (row < C && piece * 16 < 32 * (int)sizeof(T))
             v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.Wk) + row * 32 * sizeof(T) + piece * 16);
         *reinterpret_cast<u32x4*>(Wl + row * WROW + piece * 16) = v;
+    }
+    // per-channel constants of both convs -> LDS once: taps [9][C], s1, t1, s2, t2
+    for (int i = tid; i < 13 * C; i += 256) {
+        float v;
+        if (i < 9 * C) v = p.taps[i];
+        else if (i < 10 * C) v = p.s1[i - 9 * C];
+        else if (i < 11 * C) v = p.t1[i - 10 * C];
+        else if (i < 12 * C) v = p.s2[i - 11 * C];
+        else v = p.t2[i - 12 * C];
+        par[i] = v;
     }
     // per-lane im2col offsets (relative to the pixel's top-left input element); k >= 27 -> the zero slot
     int koff[NKC][EPC];
@@ -114,8 +139,8 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(SdArgs p) {
             }
             const int ch = 16 * j + 4 * fpiece;
             if (hp < SD_HP && ch < C) {
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(p.s1 + ch);
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(p.t1 + ch);
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(par + 9 * C + ch);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(par + 10 * C + ch);
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = inside ? silu_t<T>(acc[r] * sc[r] + sh[r]) : 0.f;
@@ -137,7 +162,7 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(SdArgs p) {
     F8 pool = f8_zero();
     const int cg = tid % cgn, pg0 = tid / cgn;
     if (pg0 < PG) {
-        const F8 s2 = load8<float>(p.s2 + cg * 8), t2 = load8<float>(p.t2 + cg * 8);
+        const F8 s2 = load8<float>(par + 11 * C + cg * 8), t2 = load8<float>(par + 12 * C + cg * 8);
         constexpr int GPRW = SD_TW / 4;
         for (int pg = pg0; pg < SD_TH * GPRW; pg += PG) {
             const int ty = pg / GPRW, tx0 = (pg % GPRW) * 4;
@@ -150,7 +175,7 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(SdArgs p) {
             for (int ky = 0; ky < 3; ++ky) {
                 F8 w[3];
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) w[kx] = load8<float>(p.taps + (ky * 3 + kx) * C + cg * 8);
+                for (int kx = 0; kx < 3; ++kx) w[kx] = load8<float>(par + (ky * 3 + kx) * C + cg * 8);
                 const T* er = E + ((ty + ky) * SD_HW + tx0) * erow + cg * 8;
 #pragma unroll
                 for (int c = 0; c < 6; ++c) {
@@ -201,6 +226,7 @@ size_t sd_lds_bytes(int C) {
     n += (size_t)cpad * WROW;
     n += ((size_t)SD_HP * erow * sizeof(T) + 15) / 16 * 16;
     n += 256 * 8 * 4;
+    n += (size_t)13 * C * 4;
     return n;
 }
 
