@@ -79,7 +79,7 @@ struct DwArgs {
     const float* scale; const float* shift;
     float* pool_partial;                    // [B, blocks_per_image, C] or null
     int B, H, W, C, Ho, Wo, k, stride, pad_t, pad_l, act;
-    int CG, PT, pix_per_block, blocks_per_image;
+    int CG, PT, pix_per_block, blocks_per_image;   // CG: channel groups handled by one workgroup (grid.z slices)
 };
 
 template <typename T, int KS>
@@ -89,10 +89,11 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs p) {
     const int cg = tid % p.CG;
     const int pt = tid / p.CG;
     const int b = blockIdx.y;
+    const int cbase = blockIdx.z * p.CG * 8;             // first channel of this slice
     const int npix = p.Ho * p.Wo;
     const int pix0 = blockIdx.x * p.pix_per_block;
     const int pix1 = min(pix0 + p.pix_per_block, npix);
-    const int c0 = cg * 8;
+    const int c0 = cbase + cg * 8;
     const T* X = reinterpret_cast<const T*>(p.X) + (long long)b * p.H * p.W * p.C;
     T* Y = reinterpret_cast<T*>(p.Y) + (long long)b * npix * p.C;
 
@@ -128,12 +129,13 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs p) {
         store8<T>(Y + (long long)pix * p.C + c0, o);
     }
     if (p.pool_partial != nullptr) {
-        store8<float>(red + pt * p.C + c0, pool);
+        const int CS = p.CG * 8;                          // channels of this slice
+        store8<float>(red + pt * CS + cg * 8, pool);
         __syncthreads();
-        for (int c = tid; c < p.C; c += blockDim.x) {
+        for (int c = tid; c < CS; c += blockDim.x) {
             float s = 0.f;
-            for (int q = 0; q < p.PT; ++q) s += red[q * p.C + c];
-            p.pool_partial[((long long)b * p.blocks_per_image + blockIdx.x) * p.C + c] = s;
+            for (int q = 0; q < p.PT; ++q) s += red[q * CS + c];
+            p.pool_partial[((long long)b * p.blocks_per_image + blockIdx.x) * p.C + cbase + c] = s;
         }
     }
 }
@@ -242,9 +244,16 @@ extern "C" int effdet_stem_conv(void* stream, int in_dtype, int out_dtype,
 
 // Geometry helper shared with the host: how many partial-sum blocks per image the depthwise kernel
 // uses for an output of Ho x Wo pixels and C channels.
+// channel slices (grid.z) so that one workgroup handles at most 256 groups of 8 channels
+static inline int dw_slices(int C) {
+    const int cg = C / 8;
+    for (int nz = 1; nz <= cg; ++nz) if (cg % nz == 0 && cg / nz <= 256) return nz;
+    return 1;
+}
+
 extern "C" int effdet_dwconv_blocks_per_image(int Ho, int Wo, int C) {
-    if (Ho <= 0 || Wo <= 0 || C <= 0 || C % 8 || C / 8 > 256) return EFFDET_EINVAL;
-    const int CG = C / 8, PT = 256 / CG;
+    if (Ho <= 0 || Wo <= 0 || C <= 0 || C % 8) return EFFDET_EINVAL;
+    const int CG = C / 8 / dw_slices(C), PT = 256 / CG;
     const int npix = Ho * Wo;
     int ppb = PT * 8;                                     // 8 pixels per thread
     if (ppb > npix) ppb = ((npix + PT - 1) / PT) * PT;
@@ -257,21 +266,22 @@ extern "C" int effdet_dwconv_bn_act(void* stream, int dtype, const void* X, void
                                     int B, int H, int W, int C, int k, int stride) {
     EFFDET_ENTER();
     if (!X || !Y || !Wt || !scale || !shift || B <= 0 || H <= 0 || W <= 0) return EFFDET_EINVAL;
-    if (C <= 0 || C % 8 || C / 8 > 256 || (k != 3 && k != 5) || (stride != 1 && stride != 2)) return EFFDET_EINVAL;
+    if (C <= 0 || C % 8 || (k != 3 && k != 5) || (stride != 1 && stride != 2)) return EFFDET_EINVAL;
     if ((dtype & ~1) || (act & ~1)) return EFFDET_EINVAL;
     DwArgs a;
     a.X = X; a.Y = Y; a.Wt = Wt; a.scale = scale; a.shift = shift; a.pool_partial = pool_partial;
     a.B = B; a.H = H; a.W = W; a.C = C; a.k = k; a.stride = stride; a.act = act;
     a.Ho = same_out(H, stride); a.Wo = same_out(W, stride);
     a.pad_t = same_pad_before(H, k, stride); a.pad_l = same_pad_before(W, k, stride);
-    a.CG = C / 8; a.PT = 256 / a.CG;
+    const int nz = dw_slices(C);
+    a.CG = C / 8 / nz; a.PT = 256 / a.CG;
     const int npix = a.Ho * a.Wo;
     int ppb = a.PT * 8;
     if (ppb > npix) ppb = ((npix + a.PT - 1) / a.PT) * a.PT;
     a.pix_per_block = ppb;
     a.blocks_per_image = (npix + ppb - 1) / ppb;
-    dim3 grid(a.blocks_per_image, B), block(a.CG * a.PT);
-    const size_t sh = pool_partial ? (size_t)a.PT * C * sizeof(float) : 0;
+    dim3 grid(a.blocks_per_image, B, nz), block(a.CG * a.PT);
+    const size_t sh = pool_partial ? (size_t)a.PT * a.CG * 8 * sizeof(float) : 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == 0) {
         if (k == 3) hipLaunchKernelGGL((dwconv_kernel<float, 3>), grid, block, sh, st, a);

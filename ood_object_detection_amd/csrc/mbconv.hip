@@ -559,6 +559,7 @@ extern "C" int effdet_mbconv_tiles_per_image(int dtype, int H, int W, int Cin, i
     const DeepGeometry dg = dtype == 0 ? pick_deep<float>(H, W, Cin, mid, k, stride) : pick_deep<bf16_t>(H, W, Cin, mid, k, stride);
     if (dg.use) return dg.nbands;
     const Geometry g = dtype == 0 ? pick_tile<float>(Ho, Wo, Cin, k, stride) : pick_tile<bf16_t>(Ho, Wo, Cin, k, stride);
+    if (g.lds > 160 * 1024) return EFFDET_EINVAL;      // no fused geometry fits: the caller runs expand GEMM + depthwise
     return ((Wo + g.TW - 1) / g.TW) * ((Ho + g.TH - 1) / g.TH);
 }
 

@@ -128,7 +128,7 @@ class Engine(object):
         plan = []
         Hs, Ws = _same_out(H, 2), _same_out(W, 2)
         # geometry pass: buffer sizes
-        io_max, mid_max, part_max = B * Hs * Ws * stem_c, 0, 0
+        io_max, mid_max, part_max, exp_max = B * Hs * Ws * stem_c, 0, 0, 0
         h, w = Hs, Ws
         for blocks in stages:
             for b in blocks:
@@ -136,6 +136,9 @@ class Engine(object):
                 mid_max = max(mid_max, B * ho * wo * b['mid'])
                 if b['type'] == 'ir':
                     nblk = lib.effdet_mbconv_tiles_per_image(dt, h, w, b['cin'], b['mid'], b['k'], b['s'])
+                    if nblk <= 0:        # no fused geometry (very wide fp32 inputs): expand GEMM + depthwise kernels
+                        nblk = lib.effdet_dwconv_blocks_per_image(ho, wo, b['mid'])
+                        exp_max = max(exp_max, B * h * w * b['mid'])
                 else:
                     nblk = max(lib.effdet_dwconv_blocks_per_image(ho, wo, b['mid']), lib.effdet_stem_dw_tiles_per_image(H, W))
                 if nblk <= 0:
@@ -145,6 +148,7 @@ class Engine(object):
                 h, w = ho, wo
         ping = [self._new(io_max), self._new(io_max)]
         dbuf = self._new(max(mid_max, 1))
+        ebuf = self._new(exp_max) if exp_max else None
         partial = self._new(part_max, dtype=torch.float32)
         gate_max = B * max(b['mid'] for blocks in stages for b in blocks)
         gate = self._new(gate_max, dtype=torch.float32)
@@ -196,12 +200,24 @@ class Engine(object):
                     taps = self._f32(self._dw_taps(m.conv_dw.weight))
                     s2, t2 = self._f32(s2), self._f32(t2)
                     nblk = lib.effdet_mbconv_tiles_per_image(dt, h, w, b['cin'], b['mid'], b['k'], b['s'])
-                    plan.append((lib.effdet_mbconv_expand_dw,
-                                 (dt, cur.data_ptr(), dbuf.data_ptr(), w1.data_ptr(), s1.data_ptr(), t1.data_ptr(),
-                                  taps.data_ptr(), s2.data_ptr(), t2.data_ptr(), partial.data_ptr(),
-                                  B, h, w, b['cin'], b['mid'], b['k'], b['s']), what + '.conv_pw+conv_dw',
-                                 dict(kind='mbconv', bytes=B * (h * w * b['cin'] + ho * wo * b['mid']) * es + b['mid'] * b['cin'] * es,
-                                      flops=2 * B * (h * w * b['cin'] * b['mid'] + b['k'] * b['k'] * ho * wo * b['mid']))))
+                    if nblk > 0:
+                        plan.append((lib.effdet_mbconv_expand_dw,
+                                     (dt, cur.data_ptr(), dbuf.data_ptr(), w1.data_ptr(), s1.data_ptr(), t1.data_ptr(),
+                                      taps.data_ptr(), s2.data_ptr(), t2.data_ptr(), partial.data_ptr(),
+                                      B, h, w, b['cin'], b['mid'], b['k'], b['s']), what + '.conv_pw+conv_dw',
+                                     dict(kind='mbconv', bytes=B * (h * w * b['cin'] + ho * wo * b['mid']) * es + b['mid'] * b['cin'] * es,
+                                          flops=2 * B * (h * w * b['cin'] * b['mid'] + b['k'] * b['k'] * ho * wo * b['mid']))))
+                    else:
+                        nblk = lib.effdet_dwconv_blocks_per_image(ho, wo, b['mid'])
+                        plan.append((lib.effdet_pw_gemm_bn_act,
+                                     (dt, cur.data_ptr(), B * h * w, b['cin'], w1.data_ptr(), b['mid'], s1.data_ptr(),
+                                      t1.data_ptr(), 1, None, None, 0, ebuf.data_ptr(), 0, 0), what + '.conv_pw',
+                                     self._gemm_meta(B * h * w, b['cin'], b['mid'])))
+                        plan.append((lib.effdet_dwconv_bn_act,
+                                     (dt, ebuf.data_ptr(), dbuf.data_ptr(), taps.data_ptr(), s2.data_ptr(), t2.data_ptr(), 1,
+                                      partial.data_ptr(), B, h, w, b['mid'], b['k'], b['s']), what + '.conv_dw',
+                                     dict(kind='dwconv', bytes=B * (h * w + ho * wo) * b['mid'] * es,
+                                          flops=2 * b['k'] * b['k'] * B * ho * wo * b['mid'])))
                     pw_out, bn_out = m.conv_pwl, m.bn3
                 elif si == 0 and bi == 0 and self._fuse_stem:
                     nblk = lib.effdet_stem_dw_tiles_per_image(H, W)       # launched by run_backbone (takes x)

@@ -150,3 +150,20 @@ def test_d1_channels_88():
     cls_o, box_o = m(x.to(DEV))
     for a, r in zip(list(cls_o) + list(box_o), list(cls_r) + list(box_r)):
         assert _linf(a, r) <= 1e-4 * max(1.0, float(r.abs().max()))
+
+
+@pytest.mark.parametrize('name,size,ncls', [('tf_efficientdet_d2', 256, 7), ('tf_efficientdet_d4', 256, 4)])
+def test_d2_d4_small(name, size, ncls):
+    """BASELINE configs 3 / 4 use d2 and d4: fpn 112 / 224 channels, 5 / 7 BiFPN cells, 4 head repeats, deeper backbones"""
+    model, cfg, nodes, sd = seeded_model(name, size, ncls, seed=6)
+    x = torch.from_numpy(seeded_array(6, 'input', (1, 3, size, size)))
+    with torch.no_grad():
+        cls_r, box_r = om.efficientdet_forward(sd, cfg, x, nodes)
+    m = model.to(DEV).float()
+    cls_o, box_o = m(x.to(DEV))
+    for a, r in zip(list(cls_o) + list(box_o), list(cls_r) + list(box_r)):
+        assert a.shape == r.shape
+        assert _linf(a, r) <= 2e-4 * max(1.0, float(r.abs().max()))
+    mb = model.to(torch.bfloat16)
+    cls_b, box_b = mb(x.to(DEV).to(torch.bfloat16))
+    assert all(bool(torch.isfinite(t.float()).all()) for t in list(cls_b) + list(box_b))
