@@ -139,6 +139,29 @@ int effdet_gather_ood(void* stream, const int* keep_src, const long long* indice
                       const float* maxlogit, long long n_anchors, int B, int k, int max_det,
                       float* out_energy, float* out_maxlogit);
 
+/* ---- training-side operators -------------------------------------------------- */
+
+/* loss_fn (effdet/loss.py:224-298): alpha-weighted BCE-with-logits on one-hot targets (gamma unused, as in the
+ * fork), label smoothing, `target != -2` mask, Huber box loss on targets != 0, normaliser sum(num_positives)+1.
+ * cls [B,N,C], box [B,N,4] (dtype), cls_t [B,N] int64 (class index, -1 background, -2 ignore), box_t [B,N,4] fp32.
+ * out3 = {total, class_loss, box_loss}; grad_cls / grad_box (dtype, optional) = d total / d head outputs. */
+long long effdet_detection_loss_workspace_floats(int B, long long N, int C);
+int effdet_detection_loss(void* stream, int dtype, const void* cls, const void* box, const long long* cls_t,
+                          const float* box_t, const float* num_positives, int B, long long N, int C,
+                          float alpha, float delta, float box_loss_weight, float label_smoothing,
+                          float* out3, void* grad_cls, void* grad_box, float* workspace, long long workspace_floats);
+
+/* AnchorLabeler.batch_label_anchors (effdet/anchors.py:384-438): IoU (region_similarity_calculator.py:24-73),
+ * ArgMaxMatcher thresholds (t, t) with force_match_for_each_row (argmax_matcher.py:116-146), class target =
+ * label - 1 (background -1), FasterRcnnBoxCoder.encode (box_coder.py:81-110).  gt_boxes [B,Mmax,4] yxyx,
+ * gt_cls [B,Mmax] int64 (rows with class <= -1 are padding / filtered), anchors [N,4] yxyx.
+ * Outputs cls_t [B,N] int64, box_t [B,N,4], num_positives [B], match [B,N] int64 (optional; index into the
+ * valid rows, -1 unmatched).  Mmax <= 512. */
+long long effdet_label_anchors_workspace_bytes(int B, int Mmax, long long N);
+int effdet_label_anchors(void* stream, const float* anchors, const float* gt_boxes, const long long* gt_cls,
+                         int B, int Mmax, long long N, float match_threshold, long long* cls_t, float* box_t,
+                         float* num_positives, long long* match, void* workspace, long long workspace_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,7 +5,7 @@ Mirrors the reference's effdet/anchors.py: `get_feat_sizes` (:175), `Anchors` (:
 Anchor generation is init-time host arithmetic (numpy float64 -> float32, like the reference);
 everything per-image runs in libeffdet_hip.so - there is no CPU fallback.
 
-`AnchorLabeler` (:305-438) belongs to the training path ("next").
+`AnchorLabeler` (:305-438) labels anchors for training with `effdet_label_anchors`.
 """
 from typing import Optional, Sequence, Tuple
 
@@ -155,3 +155,63 @@ def generate_detections(cls_outputs, box_outputs, anchor_boxes, indices, classes
                                        indices.reshape(1, -1), classes.reshape(1, -1), sc, sz,
                                        max_det_per_image=max_det_per_image, soft_nms=soft_nms)
     return det[0, :int(count[0].item())]
+
+
+class AnchorLabeler(object):
+    """Labeler for multiscale anchor boxes (reference: effdet/anchors.py:305-438) on `effdet_label_anchors`:
+    IoU similarity -> ArgMaxMatcher(match_threshold, match_threshold, force_match_for_each_row) -> class targets
+    (label - 1, background -1) and FasterRcnnBoxCoder box targets, unpacked per pyramid level."""
+
+    def __init__(self, anchors, num_classes: int, match_threshold: float = 0.5):
+        self.anchors = anchors
+        self.match_threshold = match_threshold
+        self.num_classes = num_classes
+        self.indices_cache = {}
+
+    def _unpack(self, cls_t, box_t):
+        B = cls_t.shape[0]
+        A = self.anchors.get_anchors_per_location()
+        cls_out, box_out, count = [], [], 0
+        for level in range(self.anchors.min_level, self.anchors.max_level + 1):
+            h, w = self.anchors.feat_sizes[level]
+            steps = h * w * A
+            cls_out.append(cls_t[:, count:count + steps].reshape(B, h, w, A))
+            box_out.append(box_t[:, count:count + steps].reshape(B, h, w, A * 4))
+            count += steps
+        return cls_out, box_out
+
+    def batch_label_anchors(self, gt_boxes, gt_classes, filter_valid=True, task_cls=None):
+        if task_cls is not None:
+            raise NotImplementedError('task_cls relabelling (effdet/anchors.py:397-404) is not built')
+        lib = _lib.load()
+        boxes = self.anchors.boxes
+        if boxes.device.type != 'cuda':
+            raise RuntimeError('AnchorLabeler needs its Anchors on the GPU (no CPU fallback)')
+        dev = boxes.device
+        B = len(gt_boxes)
+        assert B == len(gt_classes)
+        Mmax = max([int(b.shape[0]) for b in gt_boxes] + [1])
+        gb = torch.zeros(B, Mmax, 4, dtype=torch.float32, device=dev)
+        gc = torch.full((B, Mmax), -1, dtype=torch.int64, device=dev)
+        for i in range(B):
+            m = int(gt_boxes[i].shape[0])
+            if m:
+                gb[i, :m] = gt_boxes[i].to(device=dev, dtype=torch.float32)
+                c = gt_classes[i].to(device=dev, dtype=torch.int64).reshape(-1)
+                gc[i, :m] = c if filter_valid else c.clamp(min=0)
+        N = boxes.shape[0]
+        cls_t = torch.empty(B, N, dtype=torch.int64, device=dev)
+        box_t = torch.empty(B, N, 4, dtype=torch.float32, device=dev)
+        npos = torch.empty(B, dtype=torch.float32, device=dev)
+        nbytes = lib.effdet_label_anchors_workspace_bytes(B, Mmax, N)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        anchors_f = boxes.float().contiguous()
+        _lib.check(lib.effdet_label_anchors(_stream(boxes), anchors_f.data_ptr(), gb.data_ptr(), gc.data_ptr(), B, Mmax, N,
+                                            float(self.match_threshold), cls_t.data_ptr(), box_t.data_ptr(), npos.data_ptr(),
+                                            None, ws.data_ptr(), nbytes), 'effdet_label_anchors')
+        cls_out, box_out = self._unpack(cls_t, box_t)
+        return cls_out, box_out, npos
+
+    def label_anchors(self, gt_boxes, gt_classes, filter_valid=True):
+        cls_out, box_out, npos = self.batch_label_anchors([gt_boxes], [gt_classes], filter_valid=filter_valid)
+        return [c[0] for c in cls_out], [b[0] for b in box_out], npos[0]

@@ -108,12 +108,51 @@ class DetBenchPredict(nn.Module):
 
 
 class DetBenchTrain(nn.Module):
-    """Training bench (effdet/bench.py:106-145): loss + anchor labelling are the pretrain path, which is
-    scheduled after the inference path (DESIGN.md 'next'); constructing it fails loudly."""
+    """Training bench (effdet/bench.py:106-145): forward + anchor labelling + detection loss, all on HIP.
+    `output['loss']` carries gradients w.r.t. the head outputs only: the backward pass through the network
+    (pretrain.py:236) is not built yet (DESIGN.md 'next'), so `loss.backward()` does not reach the weights."""
 
     def __init__(self, model, create_labeler=True):
         super().__init__()
-        raise NotImplementedError('DetBenchTrain (DetectionLoss / AnchorLabeler on HIP) is not built yet - see DESIGN.md')
+        from .anchors import AnchorLabeler
+        from .loss import DetectionLoss
+        self.model = model
+        self.config = model.config
+        self.num_levels = model.config.num_levels
+        self.num_classes = model.config.num_classes
+        self.anchors = Anchors.from_config(model.config)
+        self.max_detection_points = model.config.max_detection_points
+        self.max_det_per_image = model.config.max_det_per_image
+        self.soft_nms = model.config.soft_nms
+        self.anchor_labeler = None
+        if create_labeler:
+            self.anchor_labeler = AnchorLabeler(self.anchors, self.num_classes, match_threshold=0.5)
+        self.loss_fn = DetectionLoss(model.config)
+
+    def forward(self, x, target: Dict[str, torch.Tensor]):
+        class_out, box_out = self.model(x)
+        if self.anchor_labeler is None:
+            assert 'label_num_positives' in target
+            cls_targets = [target['label_cls_%d' % l] for l in range(self.num_levels)]
+            box_targets = [target['label_bbox_%d' % l] for l in range(self.num_levels)]
+            num_positives = target['label_num_positives']
+        else:
+            cls_targets, box_targets, num_positives = self.anchor_labeler.batch_label_anchors(
+                target['bbox'], target['cls'])
+        loss, class_loss, box_loss = self.loss_fn(class_out, box_out, cls_targets, box_targets, num_positives)
+        output = {'loss': loss, 'class_loss': class_loss, 'box_loss': box_loss}
+        if not self.training:
+            cls_topk, box_topk, indices, classes = _post_process(
+                class_out, box_out, num_levels=self.num_levels, num_classes=self.num_classes,
+                max_detection_points=self.max_detection_points)
+            B, k = indices.shape
+            det, count, _ = batched_detections(
+                cls_topk.reshape(B, k), box_topk, self.anchors.boxes, indices, classes,
+                target.get('img_scale'), target.get('img_size'),
+                max_det_per_image=self.max_det_per_image, soft_nms=self.soft_nms)
+            output['detections'] = det
+            output['detection_counts'] = count
+        return output
 
 
 def unwrap_bench(model):

@@ -1,0 +1,97 @@
+"""Detection loss on the HIP kernel (reference: effdet/loss.py).
+
+`loss_fn` / `DetectionLoss` keep the reference signatures (loss.py:224-298, :355-401).  The fork's
+`new_focal_loss` ignores gamma (its modulating factor is commented out, loss.py:77-79), so the class loss is
+alpha-weighted BCE-with-logits with optional label smoothing; `legacy_focal` / `jit_loss` are not built.
+The op is differentiable w.r.t. the class / box head outputs (the kernel emits both the loss and d total / d
+outputs); there is no CPU fallback.
+"""
+from typing import List, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+
+class _DetectionLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cls_all, box_all, cls_t, box_t, num_positives, alpha, delta, box_loss_weight, label_smoothing):
+        lib = _lib.load()
+        if cls_all.device.type != 'cuda':
+            raise RuntimeError('DetectionLoss runs on the GPU only (no CPU fallback)')
+        if cls_all.dtype != box_all.dtype or cls_all.dtype not in (torch.float32, torch.bfloat16):
+            raise RuntimeError('head outputs must both be float32 or bfloat16')
+        B, N, C = cls_all.shape
+        dev = cls_all.device
+        cls_c, box_c = cls_all.contiguous(), box_all.contiguous()
+        cls_t = cls_t.to(device=dev, dtype=torch.int64).contiguous()
+        box_t = box_t.to(device=dev, dtype=torch.float32).contiguous()
+        npos = num_positives.to(device=dev, dtype=torch.float32).contiguous()
+        out3 = torch.empty(3, dtype=torch.float32, device=dev)
+        g_cls, g_box = torch.empty_like(cls_c), torch.empty_like(box_c)
+        nws = lib.effdet_detection_loss_workspace_floats(B, N, C)
+        ws = torch.empty(nws, dtype=torch.float32, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.effdet_detection_loss(st, 0 if cls_c.dtype == torch.float32 else 1, cls_c.data_ptr(), box_c.data_ptr(),
+                                             cls_t.data_ptr(), box_t.data_ptr(), npos.data_ptr(), B, N, C, alpha, delta,
+                                             box_loss_weight, label_smoothing, out3.data_ptr(), g_cls.data_ptr(),
+                                             g_box.data_ptr(), ws.data_ptr(), nws), 'effdet_detection_loss')
+        ctx.save_for_backward(g_cls, g_box)
+        ctx.mark_non_differentiable(out3)
+        return out3[0].clone(), out3
+
+    @staticmethod
+    def backward(ctx, g_total, _g_parts):
+        g_cls, g_box = ctx.saved_tensors
+        return (g_cls * g_total.to(g_cls.dtype), g_box * g_total.to(g_box.dtype), None, None, None, None, None, None, None)
+
+
+def _pack(outs, width):
+    """per-level [B, A*width, H, W] -> [B, N, width] (a view when the tensors are the engine's own)"""
+    B = outs[0].shape[0]
+    base = outs[0]._base
+    if base is not None and base.dim() == 3 and base.shape[0] == B and base.shape[2] == width and base.is_contiguous() \
+            and all(o._base is base for o in outs) and not any(o.requires_grad for o in outs):
+        n = sum(o.shape[1] * o.shape[2] * o.shape[3] for o in outs) // width
+        if base.shape[1] == n:
+            return base
+    return torch.cat([o.permute(0, 2, 3, 1).reshape(B, -1, width) for o in outs], 1)
+
+
+def loss_fn(cls_outputs: List[torch.Tensor], box_outputs: List[torch.Tensor], cls_targets: List[torch.Tensor],
+            box_targets: List[torch.Tensor], num_positives: torch.Tensor, num_classes: int, alpha: float, gamma: float,
+            delta: float, box_loss_weight: float, label_smoothing: float = 0.,
+            legacy_focal: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    if legacy_focal:
+        raise NotImplementedError('legacy_focal loss is not built (the fork runs new_focal_loss)')
+    B = cls_outputs[0].shape[0]
+    cls_all = _pack(list(cls_outputs), num_classes)
+    box_all = _pack(list(box_outputs), 4)
+    cls_t = torch.cat([t.reshape(B, -1) for t in cls_targets], 1)
+    box_t = torch.cat([t.reshape(B, -1, 4) for t in box_targets], 1)
+    total, parts = _DetectionLossFn.apply(cls_all, box_all, cls_t, box_t, num_positives, float(alpha), float(delta),
+                                          float(box_loss_weight), float(label_smoothing))
+    return total, parts[1], parts[2]
+
+
+class DetectionLoss(nn.Module):
+    __constants__ = ['num_classes']
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.num_classes = config.num_classes
+        self.alpha = config.alpha
+        self.gamma = config.gamma
+        self.delta = config.delta
+        self.box_loss_weight = config.box_loss_weight
+        self.label_smoothing = config.label_smoothing
+        self.legacy_focal = config.legacy_focal
+        self.use_jit = config.jit_loss
+
+    def forward(self, cls_outputs, box_outputs, cls_targets, box_targets, num_positives):
+        return loss_fn(cls_outputs, box_outputs, cls_targets, box_targets, num_positives,
+                       num_classes=self.num_classes, alpha=self.alpha, gamma=self.gamma, delta=self.delta,
+                       box_loss_weight=self.box_loss_weight, label_smoothing=self.label_smoothing,
+                       legacy_focal=self.legacy_focal)

@@ -417,3 +417,86 @@ def test_empty_and_edge_cases():
     assert count.tolist() == [0, 1] and float(det[0].abs().sum()) == 0.0
     det, count, keep = batched_detections(logits, box, anchors, idx, cls_id, None, None, 100, True)
     assert count.tolist() == [0, 3]                      # soft-NMS rescales duplicates instead of dropping them
+
+
+# ------------------------------------------------------------------------------------ training-side ops
+@pytest.mark.parametrize('tag,alpha,w,ls', [('pre', 0.15, 50.0, 0.0), ('inf', 0.25, 5.0, 0.0), ('ls', 0.25, 5.0, 0.1)])
+def test_detection_loss_golden(golden, tag, alpha, w, ls):
+    """loss values and autograd gradients vs the reference's loss_fn (effdet/loss.py:224-298)"""
+    from _seeded import seeded_array
+    from ood_object_detection_amd.effdet.loss import loss_fn
+    g = golden('loss')
+    B, C, A = [int(v) for v in g['meta'][:3]]
+    sizes = [int(v) for v in g['meta'][3:]]
+    cls_out = [torch.from_numpy(seeded_array(4, 'c%d' % i, (B, A * C, s, s), scale=1.5)).to(DEV).requires_grad_() for i, s in enumerate(sizes)]
+    box_out = [torch.from_numpy(seeded_array(4, 'b%d' % i, (B, A * 4, s, s), scale=0.3)).to(DEV).requires_grad_() for i, s in enumerate(sizes)]
+    cls_t = [torch.from_numpy(g['cls_t%d' % i]).to(DEV) for i in range(5)]
+    box_t = [torch.from_numpy(g['box_t%d' % i]).to(DEV) for i in range(5)]
+    npos = torch.from_numpy(g['npos']).to(DEV)
+    total, cl, bl = loss_fn(cls_out, box_out, cls_t, box_t, npos, num_classes=C, alpha=alpha, gamma=1.5, delta=0.1,
+                            box_loss_weight=w, label_smoothing=ls)
+    ref = g[tag + '_loss']
+    got = torch.stack([total, cl, bl]).detach().cpu().numpy()
+    assert np.allclose(got, ref, rtol=2e-5, atol=1e-6), (got, ref)
+    grads = torch.autograd.grad(total, cls_out + box_out)
+    for i in range(5):
+        assert np.allclose(grads[i].cpu().numpy(), g['%s_gc%d' % (tag, i)], rtol=1e-4, atol=1e-7)
+        assert np.allclose(grads[5 + i].cpu().numpy(), g['%s_gb%d' % (tag, i)], rtol=1e-4, atol=1e-7)
+
+
+def test_anchor_labeler_golden(golden):
+    """class / box targets, matches and num_positives vs the reference's TargetAssigner.assign"""
+    from ood_object_detection_amd import _lib
+    from ood_object_detection_amd.effdet.anchors import Anchors, AnchorLabeler
+    import _hip
+    g = golden('labeler')
+    anchors = Anchors(3, 7, 3, [(1.0, 1.0), (1.4, 0.7), (0.7, 1.4)], 4.0, (128, 128)).to(DEV)
+    lab = AnchorLabeler(anchors, num_classes=6, match_threshold=0.5)
+    gt_boxes = [torch.from_numpy(g['gt_boxes%d' % i]) for i in range(4)]
+    gt_cls = [torch.from_numpy(g['gt_cls%d' % i]) for i in range(4)]
+    cls_l, box_l, npos = lab.batch_label_anchors(gt_boxes, gt_cls)
+    assert np.array_equal(npos.cpu().numpy(), g['npos'])
+    N = anchors.boxes.shape[0]
+    cls_flat = torch.cat([c.reshape(4, -1) for c in cls_l], 1).cpu().numpy()
+    box_flat = torch.cat([b.reshape(4, -1, 4) for b in box_l], 1).cpu().numpy()
+    for i in range(4):
+        assert np.array_equal(cls_flat[i], g['cls_flat%d' % i])
+        assert np.abs(box_flat[i] - g['box_flat%d' % i]).max() <= 2e-6
+    # level shapes like the reference's unpack (anchors.py:421-433)
+    assert [tuple(c.shape) for c in cls_l] == [(4, s, s, 9) for s in (16, 8, 4, 2, 1)]
+    assert [tuple(b.shape) for b in box_l] == [(4, s, s, 36) for s in (16, 8, 4, 2, 1)]
+    # raw C-ABI call: the match vector itself
+    lib = _lib.load()
+    B, Mmax = 4, 7
+    gb = torch.zeros(B, Mmax, 4, device=DEV); gc = torch.full((B, Mmax), -1, dtype=torch.int64, device=DEV)
+    for i in range(4):
+        m = gt_boxes[i].shape[0]
+        if m:
+            gb[i, :m] = gt_boxes[i].to(DEV); gc[i, :m] = gt_cls[i].to(DEV)
+    cls_t = torch.empty(B, N, dtype=torch.int64, device=DEV); box_t = torch.empty(B, N, 4, device=DEV)
+    npos2 = torch.empty(B, device=DEV); match = torch.empty(B, N, dtype=torch.int64, device=DEV)
+    nb = lib.effdet_label_anchors_workspace_bytes(B, Mmax, N)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    af = anchors.boxes.float().contiguous()
+    rc = lib.effdet_label_anchors(_hip.stream(DEV), af.data_ptr(), gb.data_ptr(), gc.data_ptr(), B, Mmax, N, 0.5, cls_t.data_ptr(),
+                                  box_t.data_ptr(), npos2.data_ptr(), match.data_ptr(), ws.data_ptr(), nb)
+    assert rc == 0
+    for i in range(4):
+        assert np.array_equal(match[i].cpu().numpy(), g['match%d' % i])
+
+
+def test_det_bench_train_runs():
+    from _models import seeded_model
+    from ood_object_detection_amd.effdet.bench import DetBenchTrain
+    model, cfg, nodes, sd = seeded_model('tf_efficientdet_d0', 128, 6, seed=8)
+    bench = DetBenchTrain(model.to(DEV).float(), create_labeler=True)
+    bench.anchors.to(DEV)
+    bench.anchor_labeler.anchors = bench.anchors.to(DEV)
+    bench.eval()
+    x = torch.randn(2, 3, 128, 128, device=DEV)
+    target = {'bbox': [torch.tensor([[10., 12., 60., 70.], [30., 40., 100., 90.]]), torch.tensor([[5., 5., 50., 120.]])],
+              'cls': [torch.tensor([1, 3]), torch.tensor([6])]}
+    out = bench(x, target)
+    assert all(bool(torch.isfinite(out[k]).all()) for k in ('loss', 'class_loss', 'box_loss'))
+    assert out['detections'].shape == (2, 100, 6)
+    assert abs(float(out['loss']) - float(out['class_loss']) - cfg.box_loss_weight * float(out['box_loss'])) < 1e-4 * max(1.0, float(out['loss']))
