@@ -6,7 +6,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from ood_object_detection_amd.sharding import gather_detections, max_over_ranks, shard_range
+from ood_object_detection_amd.sharding import allreduce_gradients, gather_detections, max_over_ranks, shard_range
 
 
 def _free_port():
@@ -27,7 +27,12 @@ def _worker(rank, world, port, q):
     counts = torch.arange(n, dtype=torch.int32)
     det, cnt = gather_detections(full[lo:hi], counts[lo:hi])
     t = max_over_ranks(1.0 + rank)
-    q.put((rank, lo, hi, bool(torch.equal(det, full)), bool(torch.equal(cnt, counts)), t))
+    # gradient exchange: three tensors, bucket size small enough to force two buckets
+    grads = [torch.full((5, 3), float(rank + 1)), torch.arange(7, dtype=torch.float32) * (rank + 1), torch.ones(2) * rank]
+    allreduce_gradients(grads, bucket_bytes=64)
+    g_ok = bool(torch.allclose(grads[0], torch.full((5, 3), 1.5)) and torch.allclose(grads[1], torch.arange(7.) * 1.5)
+                and torch.allclose(grads[2], torch.ones(2) * 0.5))
+    q.put((rank, lo, hi, bool(torch.equal(det, full)), bool(torch.equal(cnt, counts)), t, g_ok))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -56,3 +61,4 @@ def test_two_ranks_gloo():
     assert [(o[1], o[2]) for o in out] == [(0, 4), (4, 8)]
     assert all(o[3] and o[4] for o in out)
     assert all(o[5] == 2.0 for o in out)           # max over ranks of (1.0, 2.0)
+    assert all(o[6] for o in out)                  # bucketed gradient all-reduce (mean)
