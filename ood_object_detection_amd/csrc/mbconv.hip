@@ -49,8 +49,19 @@ DEV void store4(T* p, float a, float b, float c, float d) {
     }
 }
 
-template <typename T, int KS, int S, int PPT>
-__global__ __launch_bounds__(256) void mbconv_front_kernel(MbArgs p) {
+// Spatial-tile form.  512 threads (8 waves) per workgroup: with the LDS footprint allowing two workgroups per
+// CU this keeps 4 waves per SIMD in flight, which the VALU-heavy epilogues (SiLU on every expanded element)
+// need to fill their issue slots.  Expanded channels are processed SM_MC = 48 at a time: mid = 6 * Cin with
+// Cin a multiple of 8, so 48 always divides mid and no pass runs half empty.
+constexpr int SM_T = 512;                       // threads
+constexpr int SM_NJ = 3;                        // 16-channel MFMA tiles per pass
+constexpr int SM_MC = 16 * SM_NJ;               // 48 expanded channels per pass
+constexpr int SM_CG = SM_MC / 8;                // 6 channel groups in the depthwise phase
+constexpr int SM_PG = SM_T / SM_CG;             // 85 pixel-group threads per channel group (510 threads work)
+template <typename T> struct ERowS { static constexpr int value = SM_MC + 16 / (int)sizeof(T); };
+
+template <typename T, int KS, int S>
+__global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fpiece = lane >> 4;
@@ -62,27 +73,27 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(MbArgs p) {
     const int cbytes = Cin * (int)sizeof(T);
     const int nkc = (cbytes + 63) / 64;
     const int arow = p.arow;
+    constexpr int EROW = ERowS<T>::value;
+    constexpr int NPAR = 4 + KS * KS;
     // LDS carve
     char* At = lds;                                         // [HPpad][arow]
-    char* Wc = At + p.HPpad * arow;                         // [MC][arow]
-    constexpr int EROW = ERow<T>::value;
-    T* E = reinterpret_cast<T*>(Wc + MC * arow);            // [HP][EROW]
-    float* red = reinterpret_cast<float*>(E);               // [256][8] pool scratch: reuses E after the depthwise pass
+    char* Wc = At + p.HPpad * arow;                         // [SM_MC][arow]
+    T* E = reinterpret_cast<T*>(Wc + SM_MC * arow);         // [HP][EROW]
+    float* red = reinterpret_cast<float*>(E);               // [SM_T][8] pool scratch: reuses E after the depthwise pass
+    float* cpar = reinterpret_cast<float*>(reinterpret_cast<char*>(E) + p.e_bytes);   // [s1|t1|s2|t2|taps][SM_MC]
 
-    // ---- input halo tile -> LDS (zero rows outside the image, zero K padding)
+    // ---- input halo tile -> LDS (zero rows outside the image); loads batched ahead of their LDS stores
     const T* X = reinterpret_cast<const T*>(p.X) + (long long)b * p.H * p.W * Cin;
     const int ppr = cbytes / 16;                            // 16-byte pieces per LDS row
-    // (loads are issued four at a time before their LDS stores: a load -> store loop with a runtime trip
-    //  count is not pipelined by the compiler and would expose one memory round trip per iteration)
-    for (int i0 = tid; i0 < p.HPpad * ppr; i0 += 1024) {
-        u32x4 v[4];
+    for (int i0 = tid; i0 < p.HPpad * ppr; i0 += 2 * SM_T) {
+        u32x4 v[2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + 256 * u;
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + SM_T * u;
             v[u] = u32x4{0u, 0u, 0u, 0u};
             if (i < p.HPpad * ppr) {
                 const int hp = i / ppr, piece = i % ppr;
-                if (hp < p.HP && piece * 16 < cbytes) {
+                if (hp < p.HP) {
                     const int y = iy0 + hp / p.IW, x = ix0 + hp % p.IW;
                     if (y >= 0 && y < p.H && x >= 0 && x < p.W)
                         v[u] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(X + ((long long)y * p.W + x) * Cin) + piece * 16);
@@ -90,101 +101,85 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(MbArgs p) {
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + 256 * u;
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + SM_T * u;
             if (i < p.HPpad * ppr) *reinterpret_cast<u32x4*>(At + (i / ppr) * arow + (i % ppr) * 16) = v[u];
         }
     }
 
     T* Y = reinterpret_cast<T*>(p.Y) + (long long)b * p.Ho * p.Wo * mid;
     const int n_msub = p.HPpad / 16;
-    const int npix = p.TH * p.TW;
 
-    // Per-pass constants live in LDS: cpar = [s1 | t1 | s2 | t2 | taps k*k][MC].  W1 and the constants of pass
-    // c+1 are fetched into registers at the start of pass c and committed at the start of pass c+1, so their
-    // latency hides behind the expand + depthwise work.
-    constexpr int NPAR = 4 + KS * KS;
-    float* cpar = reinterpret_cast<float*>(reinterpret_cast<char*>(E) + p.e_bytes);
-    constexpr int WPC = 4, PPC = (NPAR * MC + 255) / 256;    // prefetch registers per thread
-    const bool w_pref = MC * ppr <= 256 * WPC;
+    // W1 and the per-channel constants of pass c+1 are fetched into registers at the start of pass c and
+    // committed to LDS at the start of pass c+1: their latency hides behind the expand + depthwise work.
+    constexpr int WPC = 2, PPC = (NPAR * SM_MC + SM_T - 1) / SM_T;
+    const bool w_pref = SM_MC * ppr <= SM_T * WPC;
     u32x4 wpre[WPC];
     float ppre[PPC];
     auto fetch = [&](int c0n) {
-        const int cnn = (mid - c0n) < MC ? (mid - c0n) : MC;
         if (w_pref) {
 #pragma unroll
             for (int q = 0; q < WPC; ++q) {
-                const int i = tid + 256 * q;
+                const int i = tid + SM_T * q;
                 wpre[q] = u32x4{0u, 0u, 0u, 0u};
-                if (i < MC * ppr) {
-                    const int row = i / ppr, piece = i % ppr;
-                    if (row < cnn && piece * 16 < cbytes)
-                        wpre[q] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.W1) + (long long)(c0n + row) * cbytes + piece * 16);
-                }
+                if (i < SM_MC * ppr)
+                    wpre[q] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.W1) + (long long)(c0n + i / ppr) * cbytes + (i % ppr) * 16);
             }
         }
 #pragma unroll
         for (int q = 0; q < PPC; ++q) {
-            const int i = tid + 256 * q;
+            const int i = tid + SM_T * q;
             float v = 0.f;
-            if (i < NPAR * MC) {
-                const int r = i / MC, c = i % MC;
-                if (c < cnn) {
-                    const float* src = r == 0 ? p.s1 : r == 1 ? p.t1 : r == 2 ? p.s2 : r == 3 ? p.t2 : p.taps + (long long)(r - 4) * mid;
-                    v = src[c0n + c];
-                }
+            if (i < NPAR * SM_MC) {
+                const int r = i / SM_MC, c = i % SM_MC;
+                const float* src = r == 0 ? p.s1 : r == 1 ? p.t1 : r == 2 ? p.s2 : r == 3 ? p.t2 : p.taps + (long long)(r - 4) * mid;
+                v = src[c0n + c];
             }
             ppre[q] = v;
         }
     };
     auto commit = [&](int c0n) {
-        const int cnn = (mid - c0n) < MC ? (mid - c0n) : MC;
         if (w_pref) {
 #pragma unroll
             for (int q = 0; q < WPC; ++q) {
-                const int i = tid + 256 * q;
-                if (i < MC * ppr) *reinterpret_cast<u32x4*>(Wc + (i / ppr) * arow + (i % ppr) * 16) = wpre[q];
+                const int i = tid + SM_T * q;
+                if (i < SM_MC * ppr) *reinterpret_cast<u32x4*>(Wc + (i / ppr) * arow + (i % ppr) * 16) = wpre[q];
             }
         } else {
-            for (int i = tid; i < MC * ppr; i += 256) {
-                const int row = i / ppr, piece = i % ppr;
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (row < cnn && piece * 16 < cbytes)
-                    v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.W1) + (long long)(c0n + row) * cbytes + piece * 16);
-                *reinterpret_cast<u32x4*>(Wc + row * arow + piece * 16) = v;
-            }
+            for (int i = tid; i < SM_MC * ppr; i += SM_T)
+                *reinterpret_cast<u32x4*>(Wc + (i / ppr) * arow + (i % ppr) * 16) =
+                    *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.W1) + (long long)(c0n + i / ppr) * cbytes + (i % ppr) * 16);
         }
 #pragma unroll
         for (int q = 0; q < PPC; ++q) {
-            const int i = tid + 256 * q;
-            if (i < NPAR * MC) cpar[i] = ppre[q];
+            const int i = tid + SM_T * q;
+            if (i < NPAR * SM_MC) cpar[i] = ppre[q];
         }
     };
     fetch(0);
 
-    for (int c0 = 0; c0 < mid; c0 += MC) {
-        const int cn = (mid - c0) < MC ? (mid - c0) : MC;   // valid channels in this pass (multiple of 8)
+    for (int c0 = 0; c0 < mid; c0 += SM_MC) {
         __syncthreads();                                    // previous pass done with Wc / E / red / cpar
         commit(c0);
         __syncthreads();
-        if (c0 + MC < mid) fetch(c0 + MC);
+        if (c0 + SM_MC < mid) fetch(c0 + SM_MC);
         // ---- expand: rows of the accumulator = channels, columns = halo pixels
-        f32x4 sc[4], sh[4];
+        f32x4 sc[SM_NJ], sh[SM_NJ];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            sc[j] = *reinterpret_cast<const f32x4*>(cpar + 16 * j + 4 * fpiece);          // zero past cn
-            sh[j] = *reinterpret_cast<const f32x4*>(cpar + MC + 16 * j + 4 * fpiece);
+        for (int j = 0; j < SM_NJ; ++j) {
+            sc[j] = *reinterpret_cast<const f32x4*>(cpar + 16 * j + 4 * fpiece);
+            sh[j] = *reinterpret_cast<const f32x4*>(cpar + SM_MC + 16 * j + 4 * fpiece);
         }
-        for (int ms = wave; ms < n_msub; ms += 4) {
-            f32x4 acc[4];
+        for (int ms = wave; ms < n_msub; ms += SM_T / 64) {
+            f32x4 acc[SM_NJ];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < SM_NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int kc = 0; kc < nkc; ++kc) {
                 const int off = kc * 64 + fpiece * 16;        // rows hold exactly cbytes (+16 pad): guard the tail
                 Frag<T> xf;
                 if (off < cbytes) xf = ld_frag<T>(At + (16 * ms + frow) * arow + off); else xf.v = decltype(xf.v){};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < SM_NJ; ++j) {
                     Frag<T> wf;
                     if (off < cbytes) wf = ld_frag<T>(Wc + (16 * j + frow) * arow + off); else wf.v = decltype(wf.v){};
                     mma_chunk(wf, xf, acc[j]);
@@ -195,7 +190,7 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(MbArgs p) {
                 const int y = iy0 + hp / p.IW, x = ix0 + hp % p.IW;
                 const bool inside = y >= 0 && y < p.H && x >= 0 && x < p.W;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < SM_NJ; ++j) {
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = inside ? silu_t<T>(acc[j][r] * sc[j][r] + sh[j][r]) : 0.f;
@@ -204,68 +199,51 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(MbArgs p) {
             }
         }
         __syncthreads();
-        // ---- depthwise out of LDS: a thread owns 8 channels x PPT x-adjacent outputs (sliding window)
-        const int cgn = cn / 8;
+        // ---- depthwise out of LDS: a thread owns 8 channels of one output pixel at a time
         F8 pool = f8_zero();
-        const int cg = tid & 7;                              // fixed per thread: 256 % 8 == 0
-        if (cg < cgn) {
-            const F8 s2 = load8<float>(cpar + 2 * MC + cg * 8), t2 = load8<float>(cpar + 3 * MC + cg * 8);
-            const int gpr = p.TW / PPT;                      // pixel groups per tile row
-            for (int pg = tid >> 3; pg < p.TH * gpr; pg += 32) {
-                const int ty = pg / gpr, tx0 = (pg % gpr) * PPT;
-                const int oy = oy0 + ty;
-                if (oy >= p.Ho || ox0 + tx0 >= p.Wo) continue;
-                F8 acc[PPT];
-#pragma unroll
-                for (int pi = 0; pi < PPT; ++pi) acc[pi] = f8_zero();
+        const int cg = tid % SM_CG, pg0 = tid / SM_CG;
+        if (pg0 < SM_PG) {
+            for (int px = pg0; px < p.TH * p.TW; px += SM_PG) {
+                const int ty = px / p.TW, tx = px % p.TW;
+                const int oy = oy0 + ty, ox = ox0 + tx;
+                if (oy >= p.Ho || ox >= p.Wo) continue;
+                F8 acc = f8_zero();
 #pragma unroll 1
-                for (int ky = 0; ky < KS; ++ky) {          // not unrolled: keeps one kernel row of taps live
-                    F8 w[KS];
+                for (int ky = 0; ky < KS; ++ky) {          // one tap / one LDS vector at a time: small register footprint
+                    const T* erow = E + ((ty * S + ky) * p.IW + tx * S) * EROW + cg * 8;
+                    const float* wrow = cpar + (4 + ky * KS) * SM_MC + cg * 8;
 #pragma unroll
-                    for (int kx = 0; kx < KS; ++kx) w[kx] = load8<float>(cpar + (4 + ky * KS + kx) * MC + cg * 8);
-                    const T* erow = E + ((ty * S + ky) * p.IW + tx0 * S) * EROW + cg * 8;
+                    for (int kx = 0; kx < KS; ++kx) {
+                        const F8 e = load8<T>(erow + kx * EROW);
+                        const F8 w = load8<float>(wrow + kx * SM_MC);
 #pragma unroll
-                    for (int c = 0; c < (PPT - 1) * S + KS; ++c) {
-                        const F8 e = load8<T>(erow + c * EROW);
-#pragma unroll
-                        for (int pi = 0; pi < PPT; ++pi) {
-                            const int kx = c - pi * S;
-                            if (kx >= 0 && kx < KS) {
-#pragma unroll
-                                for (int q = 0; q < 8; ++q) acc[pi].v[q] = fmaf(e.v[q], w[kx].v[q], acc[pi].v[q]);
-                            }
-                        }
+                        for (int q = 0; q < 8; ++q) acc.v[q] = fmaf(e.v[q], w.v[q], acc.v[q]);
                     }
                 }
+                const F8 s2 = load8<float>(cpar + 2 * SM_MC + cg * 8), t2 = load8<float>(cpar + 3 * SM_MC + cg * 8);
+                F8 o;
 #pragma unroll
-                for (int pi = 0; pi < PPT; ++pi) {
-                    const int ox = ox0 + tx0 + pi;
-                    if (ox >= p.Wo) continue;
-                    F8 o;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const float v = silu_t<T>(acc[pi].v[q] * s2.v[q] + t2.v[q]);
-                        o.v[q] = to_f<T>(from_f<T>(v));          // SE averages what the next layer reads
-                        pool.v[q] += o.v[q];
-                    }
-                    store8<T>(Y + ((long long)oy * p.Wo + ox) * mid + c0 + cg * 8, o);
+                for (int q = 0; q < 8; ++q) {
+                    const float v = silu_t<T>(acc.v[q] * s2.v[q] + t2.v[q]);
+                    o.v[q] = to_f<T>(from_f<T>(v));              // SE averages what the next layer reads
+                    pool.v[q] += o.v[q];
                 }
+                store8<T>(Y + ((long long)oy * p.Wo + ox) * mid + c0 + cg * 8, o);
             }
         }
         if (p.pool_partial != nullptr) {
             __syncthreads();                                // every thread is done reading E
             store8<float>(red + tid * 8, pool);
             __syncthreads();
-            if (tid < cn) {
+            if (tid < SM_MC) {
                 const int g = tid >> 3, q = tid & 7;
                 float s = 0.f;
-                for (int t = g; t < 256; t += 8) s += red[t * 8 + q];
+                for (int t = g; t < SM_CG * SM_PG; t += SM_CG) s += red[t * 8 + q];
                 p.pool_partial[((long long)b * (p.tiles_x * p.tiles_y) + tile) * mid + c0 + tid] = s;
             }
         }
     }
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // "Deep" decomposition for the late stages (small maps, many channels): a workgroup owns
@@ -499,10 +477,10 @@ Geometry pick_tile(int Ho, int Wo, int Cin, int k, int stride) {
         g.IH = (g.TH - 1) * stride + k; g.IW = (g.TW - 1) * stride + k;
         g.HP = g.IH * g.IW; g.HPpad = (g.HP + 15) / 16 * 16;
         g.arow = Cin * (int)sizeof(T) + 16;
-        g.e_bytes = g.HP * ERow<T>::value * (int)sizeof(T);
-        if (g.e_bytes < 256 * 8 * 4) g.e_bytes = 256 * 8 * 4;
+        g.e_bytes = g.HP * ERowS<T>::value * (int)sizeof(T);
+        if (g.e_bytes < SM_T * 8 * 4) g.e_bytes = SM_T * 8 * 4;
         g.e_bytes = (g.e_bytes + 15) / 16 * 16;
-        g.lds = (size_t)g.HPpad * g.arow + (size_t)MC * g.arow + (size_t)g.e_bytes + (size_t)(4 + k * k) * MC * 4;
+        g.lds = (size_t)g.HPpad * g.arow + (size_t)SM_MC * g.arow + (size_t)g.e_bytes + (size_t)(4 + k * k) * SM_MC * 4;
         best = g;
         // a tile much larger than the map wastes the workgroup; keep two workgroups per CU (<= 76 KiB each)
         const bool fits_map = (g.TH <= Ho || g.TH == 2) && (g.TW <= 2 * Wo);
@@ -534,12 +512,10 @@ int launch_mb(hipStream_t st, MbArgs& a) {
     if (g.lds > 160 * 1024) return EFFDET_EINVAL;
     a.TH = g.TH; a.TW = g.TW; a.IH = g.IH; a.IW = g.IW; a.HP = g.HP; a.HPpad = g.HPpad; a.arow = g.arow; a.e_bytes = g.e_bytes;
     a.tiles_x = (a.Wo + g.TW - 1) / g.TW; a.tiles_y = (a.Ho + g.TH - 1) / g.TH;
-    dim3 grid(a.tiles_x * a.tiles_y, a.B), block(256);
-    // outputs per thread along x in the depthwise phase: keep all 256 threads busy on small tiles
-    const int npix = g.TH * g.TW;
-    const int ppt = npix >= 128 ? 4 : (npix >= 64 ? 2 : 1);
+    dim3 grid(a.tiles_x * a.tiles_y, a.B), block(SM_T);
+    if (a.mid % SM_MC) return EFFDET_EINVAL;               // mid = 6 * Cin: always a multiple of 48
     void (*kern)(MbArgs) = nullptr;
-#define MB_PICK(K_, S_) (ppt == 4 ? mbconv_front_kernel<T, K_, S_, 4> : ppt == 2 ? mbconv_front_kernel<T, K_, S_, 2> : mbconv_front_kernel<T, K_, S_, 1>)
+#define MB_PICK(K_, S_) mbconv_front_kernel<T, K_, S_>
     if (a.k == 3) kern = a.stride == 1 ? MB_PICK(3, 1) : MB_PICK(3, 2);
     else kern = a.stride == 1 ? MB_PICK(5, 1) : MB_PICK(5, 2);
 #undef MB_PICK
