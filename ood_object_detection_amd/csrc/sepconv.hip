@@ -70,13 +70,14 @@ DEV F8 fetch_input(const SepInput& in, int b, int y, int x, int F, int c) {
     return m;
 }
 
-template <typename T, int TH, int TW, int BN, bool OOD>
-__global__ __launch_bounds__(256, (OOD || sizeof(T) == 4) ? 2 : 3) void sepconv_kernel(SepArgs p) {
+template <typename T, int TH, int TW, int BN, bool OOD, int NTH>
+__global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((OOD || sizeof(T) == 4) ? 2 : 3)) void sepconv_kernel(SepArgs p) {
     // staging element: fp32 when the OOD reduction reads it back, else the output dtype (half the LDS)
     typedef typename std::conditional<OOD, float, T>::type ST;
     constexpr int BM = TH * TW;
     constexpr int HW_ = (TH + 2) * (TW + 2);
-    constexpr int WPT = BM / 64;                 // 16-row MFMA tiles per wave (BM/4 rows per wave)
+    constexpr int NWAVE = NTH / 64;
+    constexpr int WPT = BM / (16 * NWAVE);       // 16-row MFMA tiles per wave
     constexpr int NT = BN / 16;
     constexpr int SROW = BN + 24;                // + 8 columns the alignment shift can spill into, + bank spread
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -107,11 +108,11 @@ __global__ __launch_bounds__(256, (OOD || sizeof(T) == 4) ? 2 : 3) void sepconv_
     const int y0 = (t / L.tiles_x) * TH, x0 = (t % L.tiles_x) * TW;
     const int H = L.H, W = L.W;
 
-    for (int i = tid; i < 9 * F; i += 256) dww[i] = p.dw_w[i];
+    for (int i = tid; i < 9 * F; i += NTH) dww[i] = p.dw_w[i];
     // zero the K padding of the A tile rows once (columns [fbytes, nkc*64))
     if (nkc * 64 > fbytes) {
         const int padb = nkc * 64 - fbytes;
-        for (int i = tid; i < BM * (padb / 16); i += 256) {
+        for (int i = tid; i < BM * (padb / 16); i += NTH) {
             const int row = i / (padb / 16), piece = i % (padb / 16);
             *reinterpret_cast<u32x4*>(At + row * arow + fbytes + piece * 16) = u32x4{0u, 0u, 0u, 0u};
         }
@@ -124,12 +125,13 @@ __global__ __launch_bounds__(256, (OOD || sizeof(T) == 4) ? 2 : 3) void sepconv_
         __syncthreads();
         // two halo items per step: their input loads are all issued before the first use (the loop has a runtime
         // trip count, so the compiler would otherwise expose one memory round trip per item)
-        for (int it0 = tid; it0 < HW_ * fcg; it0 += 512) {
-            F8 xin[2][3];
-            bool ok[2];
+        constexpr int HU = NTH == 512 ? 1 : 2;              // halo items in flight per thread
+        for (int it0 = tid; it0 < HW_ * fcg; it0 += HU * NTH) {
+            F8 xin[HU][3];
+            bool ok[HU];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int it = it0 + 256 * u;
+            for (int u = 0; u < HU; ++u) {
+                const int it = it0 + NTH * u;
                 const int cgh = it % fcg, hp = it / fcg;
                 const int y = y0 + hp / (TW + 2) - 1, x = x0 + hp % (TW + 2) - 1;
                 ok[u] = it < HW_ * fcg && y >= 0 && y < H && x >= 0 && x < W;
@@ -141,8 +143,8 @@ __global__ __launch_bounds__(256, (OOD || sizeof(T) == 4) ? 2 : 3) void sepconv_
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int it = it0 + 256 * u;
+            for (int u = 0; u < HU; ++u) {
+                const int it = it0 + NTH * u;
                 if (it >= HW_ * fcg) continue;
                 const int cgh = it % fcg, hp = it / fcg;
                 F8 v = f8_zero();
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256, (OOD || sizeof(T) == 4) ? 2 : 3) void sepconv_
             }
         }
         __syncthreads();
-        for (int it = tid; it < BM * fcg; it += 256) {
+        for (int it = tid; it < BM * fcg; it += NTH) {
             const int cg = it % fcg, px = it / fcg;
             const int ty = px / TW, tx = px % TW;
             F8 acc = f8_zero();
@@ -215,13 +217,13 @@ __global__ __launch_bounds__(256, (OOD || sizeof(T) == 4) ? 2 : 3) void sepconv_
             n_count = N - n_begin; if (n_count > BN) n_count = BN;
         }
     };
-    const bool prefetch = BN * ppr <= 256 * WPC;
+    const bool prefetch = BN * ppr <= NTH * WPC;
     auto w_fetch = [&](int ch) {                        // global -> registers (in flight across the epilogue)
         int n_begin, n_count;
         chunk_range(ch, n_begin, n_count);
 #pragma unroll
         for (int q = 0; q < WPC; ++q) {
-            const int i = tid + 256 * q;
+            const int i = tid + NTH * q;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (i < BN * ppr) {
                 const int row = i / ppr, piece = i % ppr;
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(256, (OOD || sizeof(T) == 4) ? 2 : 3) void sepconv_
     auto w_commit = [&]() {
 #pragma unroll
         for (int q = 0; q < WPC; ++q) {
-            const int i = tid + 256 * q;
+            const int i = tid + NTH * q;
             if (i < BN * ppr) *reinterpret_cast<u32x4*>(Wt + (i / ppr) * arow + (i % ppr) * 16) = wpre[q];
         }
     };
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(256, (OOD || sizeof(T) == 4) ? 2 : 3) void sepconv_
     // puts staging column 8k on a 16-byte boundary in memory.
     constexpr int ALIGN_E = 16 / (int)sizeof(T);       // elements per 16 bytes
     constexpr int GPR = BN / 8;
-    constexpr int RPT = BM * GPR / 256;                // rows per thread in the store pass
+    constexpr int RPT = BM * GPR / NTH;                // rows per thread in the store pass
     const int base_mod = (int)((reinterpret_cast<uintptr_t>(out) / sizeof(T)) % ALIGN_E);
     int st_mod[WPT][4];                                // staging rows of this lane (MFMA layout)
 #pragma unroll
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(256, (OOD || sizeof(T) == 4) ? 2 : 3) void sepconv_
     const int cg = tid % GPR;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        const int row = (tid + 256 * k) / GPR;
+        const int row = (tid + NTH * k) / GPR;
         const int y = y0 + row / TW, x = x0 + row % TW;
         sp_in[k] = (y < H) && (x < W);
         sp_off[k] = (y * W + x) * N;
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256, (OOD || sizeof(T) == 4) ? 2 : 3) void sepconv_
         if (prefetch) {
             w_commit();
         } else {
-            for (int i = tid; i < BN * ppr; i += 256) {
+            for (int i = tid; i < BN * ppr; i += NTH) {
                 const int row = i / ppr, piece = i % ppr;
                 u32x4 v = {0u, 0u, 0u, 0u};
                 if (row < n_count && piece * 16 < fbytes)
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(256, (OOD || sizeof(T) == 4) ? 2 : 3) void sepconv_
             }
         }
         if (ood && (ch % subs) == 0) {
-            for (int i = tid; i < BM; i += 256) { run_m[i] = -INFINITY; run_s[i] = 0.f; }
+            for (int i = tid; i < BM; i += NTH) { run_m[i] = -INFINITY; run_s[i] = 0.f; }
         }
         __syncthreads();
         if (prefetch && ch + 1 < nchunks) w_fetch(ch + 1);
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(256, (OOD || sizeof(T) == 4) ? 2 : 3) void sepconv_
         constexpr float LOG2E = 1.4426950408889634f;
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            const int row = (tid + 256 * k) / GPR;
+            const int row = (tid + NTH * k) / GPR;
             const int dl = (sp_mod[k] + nb_mod) % ALIGN_E;
             T* drow = out + sp_off[k] + n_begin;
             const int c_lo = cg * 8 - dl;
@@ -455,7 +457,7 @@ size_t sep_lds_bytes(int F) {
     return (halo > stage ? halo : stage) + (size_t)BM * arow + (size_t)BN * arow + (size_t)9 * F * 4 + (size_t)2 * BN * 4;
 }
 
-template <typename T, int TH, int TW, int BN, bool OOD>
+template <typename T, int TH, int TW, int BN, bool OOD, int NTH>
 int launch_sep(hipStream_t st, SepArgs& a, int B) {
     int tiles = 0;
     for (int i = 0; i < a.nlevels; ++i) {
@@ -466,7 +468,7 @@ int launch_sep(hipStream_t st, SepArgs& a, int B) {
     }
     const size_t lds = sep_lds_bytes<T, TH, TW, BN, OOD>(a.F);
     if (lds > 160 * 1024) return EFFDET_EINVAL;
-    auto kern = sepconv_kernel<T, TH, TW, BN, OOD>;
+    auto kern = sepconv_kernel<T, TH, TW, BN, OOD, NTH>;
     if (lds > 64 * 1024) {
         static bool attr_done = false;           // one per template instantiation
         if (!attr_done) {
@@ -475,7 +477,7 @@ int launch_sep(hipStream_t st, SepArgs& a, int B) {
             attr_done = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(tiles, B), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(tiles, B), dim3(NTH), lds, st, a);
     return effdet_check_launch();
 }
 
@@ -538,6 +540,8 @@ extern "C" int effdet_sepconv_fused(
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool ood = a.ood_classes > 0;
-    if (dtype == 0) return ood ? launch_sep<float, 8, 8, 64, true>(st, a, B) : launch_sep<float, 8, 8, 64, false>(st, a, B);
-    return ood ? launch_sep<bf16_t, 8, 16, 64, true>(st, a, B) : launch_sep<bf16_t, 8, 16, 64, false>(st, a, B);
+    if (dtype == 0) return ood ? launch_sep<float, 8, 8, 64, true, 256>(st, a, B) : launch_sep<float, 8, 8, 64, false, 256>(st, a, B);
+    // bf16: 512 threads per 8x16 tile - the LDS footprint allows two workgroups per CU, so this doubles the waves
+    // that share the VALU-heavy staging / store passes
+    return ood ? launch_sep<bf16_t, 8, 16, 64, true, 512>(st, a, B) : launch_sep<bf16_t, 8, 16, 64, false, 512>(st, a, B);
 }
