@@ -86,23 +86,39 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs p) {
 
     u32x4 a_reg[A_PER_THREAD];
     u32x4 w_reg[W_PER_THREAD];
+    f32x4 g_reg[A_PER_THREAD][2];                     // SE gate of the A pieces (8 floats each), applied at store time
 
+    // per-thread constants of its A rows, hoisted out of the K loop (the image index needs an integer division)
+    const char* a_src[A_PER_THREAD];
+    const float* a_gate[A_PER_THREAD];
+    bool a_ok[A_PER_THREAD];
+#pragma unroll
+    for (int q = 0; q < A_PER_THREAD; ++q) {
+        const int idx = tid + 256 * q;
+        const long long m = m0 + idx / PPR;
+        a_ok[q] = m < p.M;
+        a_src[q] = Ab + (a_ok[q] ? m : 0) * pitch;
+        a_gate[q] = p.gate != nullptr ? p.gate + (long long)((unsigned int)(a_ok[q] ? m : 0) / (unsigned int)p.rows_per_image) * K : nullptr;
+    }
+
+    // load_stage only ISSUES loads (A piece, its gate vector, W piece): nothing here may consume them, or the
+    // prefetch would stall on its own data instead of overlapping the MFMA work of the current stage
     auto load_stage = [&](int stg) {
 #pragma unroll
         for (int q = 0; q < A_PER_THREAD; ++q) {
             const int idx = tid + 256 * q;
-            const int piece = idx % PPR, row = idx / PPR;
-            const long long m = m0 + row;
+            const int piece = idx % PPR;
             const int ke = stg * KCH * KPC + piece * EPC;    // element offset along K
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (m < p.M && ke < K) {
-                v = *reinterpret_cast<const u32x4*>(Ab + m * pitch + (long long)ke * sizeof(T));
+            f32x4 g0 = {1.f, 1.f, 1.f, 1.f}, g1 = g0;
+            if (a_ok[q] && ke < K) {
+                v = *reinterpret_cast<const u32x4*>(a_src[q] + (long long)ke * sizeof(T));
                 if (p.gate != nullptr) {
-                    const long long b = m / p.rows_per_image;
-                    v = apply_gate<T>(v, p.gate + b * K + ke);
+                    g0 = *reinterpret_cast<const f32x4*>(a_gate[q] + ke);
+                    if constexpr (sizeof(T) == 2) g1 = *reinterpret_cast<const f32x4*>(a_gate[q] + ke + 4);
                 }
             }
-            a_reg[q] = v;
+            a_reg[q] = v; g_reg[q][0] = g0; g_reg[q][1] = g1;
         }
 #pragma unroll
         for (int q = 0; q < W_PER_THREAD; ++q) {
@@ -124,7 +140,14 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs p) {
 #pragma unroll
         for (int q = 0; q < A_PER_THREAD; ++q) {
             const int idx = tid + 256 * q;
-            *reinterpret_cast<u32x4*>(Ad + (idx / PPR) * ROWB + (idx % PPR) * 16) = a_reg[q];
+            u32x4 v = a_reg[q];
+            if (p.gate != nullptr) {
+                float g[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { g[e] = g_reg[q][0][e]; g[4 + e] = g_reg[q][1][e]; }
+                v = apply_gate<T>(v, g);
+            }
+            *reinterpret_cast<u32x4*>(Ad + (idx / PPR) * ROWB + (idx % PPR) * 16) = v;
         }
 #pragma unroll
         for (int q = 0; q < W_PER_THREAD; ++q) {
@@ -186,8 +209,9 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs p) {
         const long long m = m0 + row;
         const int n = n0 + cg * 8;
         if (m >= p.M || n >= p.N) continue;
-        const long long b = m / p.rows_per_image, pix = m % p.rows_per_image;
-        T* dst = Cb + b * p.c_image_stride + pix * p.ldc + n;
+        const unsigned int bimg = (unsigned int)m / (unsigned int)p.rows_per_image;      // M < 2^31: 32-bit division
+        const unsigned int pix = (unsigned int)m - bimg * (unsigned int)p.rows_per_image;
+        T* dst = Cb + (long long)bimg * p.c_image_stride + (long long)pix * p.ldc + n;
         const int nvalid = (p.N - n) < 8 ? (p.N - n) : 8;
         float v[8];
         const f32x4 va = *reinterpret_cast<const f32x4*>(S + row * SROW + cg * 8);        // aligned: SROW % 4 == 0
@@ -242,7 +266,7 @@ extern "C" int effdet_pw_gemm_bn_act(void* stream, int dtype,
                                      void* C, long long c_image_stride, long long ldc) {
     EFFDET_ENTER();
     if (!A || !W || !C || !shift || M <= 0 || K <= 0 || N <= 0) return EFFDET_EINVAL;
-    if (K % 8 != 0) return EFFDET_EINVAL;                 // 16-byte pieces along K
+    if (K % 8 != 0 || M > 0x7fffffffLL) return EFFDET_EINVAL;   // 16-byte pieces along K; 32-bit row arithmetic
     if (act != 0 && act != 1) return EFFDET_EINVAL;
     if (rows_per_image <= 0) { rows_per_image = (int)(M > 0x7fffffffLL ? 0x7fffffff : M); }
     if (gate && (M % rows_per_image) != 0) return EFFDET_EINVAL;

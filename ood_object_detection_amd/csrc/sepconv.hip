@@ -108,7 +108,15 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((OOD || sizeof(T) == 4) ? 2 
     const int y0 = (t / L.tiles_x) * TH, x0 = (t % L.tiles_x) * TW;
     const int H = L.H, W = L.W;
 
-    for (int i = tid; i < 9 * F; i += NTH) dww[i] = p.dw_w[i];
+    // depthwise taps: fetched into registers now, committed to LDS after the halo loads have been issued
+    constexpr int DPC = (9 * 128 + NTH - 1) / NTH;        // taps per thread when F <= 128 (else copied later)
+    const bool d_pref = 9 * F <= DPC * NTH;
+    float dpre[DPC];
+#pragma unroll
+    for (int q = 0; q < DPC; ++q) {
+        const int i = tid + NTH * q;
+        dpre[q] = (d_pref && i < 9 * F) ? p.dw_w[i] : 0.f;
+    }
     // zero the K padding of the A tile rows once (columns [fbytes, nkc*64))
     if (nkc * 64 > fbytes) {
         const int padb = nkc * 64 - fbytes;
@@ -171,6 +179,17 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((OOD || sizeof(T) == 4) ? 2 
                     }
                 }
                 store8<T>(reinterpret_cast<T*>(halo) + hp * FC + cgh * 8, v);
+            }
+        }
+        if (fc0 == 0) {
+            if (d_pref) {
+#pragma unroll
+                for (int q = 0; q < DPC; ++q) {
+                    const int i = tid + NTH * q;
+                    if (i < 9 * F) dww[i] = dpre[q];
+                }
+            } else {
+                for (int i = tid; i < 9 * F; i += NTH) dww[i] = p.dw_w[i];
             }
         }
         __syncthreads();
