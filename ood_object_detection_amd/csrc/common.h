@@ -132,6 +132,31 @@ DEV float wave_reduce_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Per-channel sum of per-thread 8-channel partials.  Thread t (< nact) holds the partial sums of channel group
+// (t % cgn); all NT threads must call this.  red: [NT][8] floats, red2: [NT] floats (LDS).  Two levels, so that
+// no thread walks more than nact/(cgn*P) + P values; fixed order -> bitwise reproducible.  Returns, for
+// tid < cgn*8, the total of channel `tid`.
+template <int NT>
+DEV float pool_reduce(const F8& pool, float* red, float* red2, int tid, int cgn, int nact) {
+    store8<float>(red + tid * 8, pool);
+    __syncthreads();
+    const int C_ = cgn * 8;
+    const int P = NT / C_ > 0 ? NT / C_ : 1;
+    if (tid < P * C_) {
+        const int part = tid / C_, c = tid % C_;
+        const int g = c >> 3, q = c & 7;
+        float s = 0.f;
+        for (int t = g + cgn * part; t < nact; t += cgn * P) s += red[t * 8 + q];
+        red2[part * C_ + c] = s;
+    }
+    __syncthreads();
+    float tot = 0.f;
+    if (tid < C_) {
+        for (int part = 0; part < P; ++part) tot += red2[part * C_ + tid];
+    }
+    return tot;
+}
+
 DEV float wave_reduce_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

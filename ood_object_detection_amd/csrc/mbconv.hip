@@ -13,6 +13,7 @@
 //     depthwise taps out of LDS, BN2 + SiLU, 16-byte NHWC stores, pool partials.
 // HBM traffic per tile = input halo + output tile (+ weights from L2).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -27,6 +28,7 @@ struct MbArgs {
     int TH, TW, IH, IW, HP, HPpad, tiles_x, tiles_y;
     int arow;                                   // LDS pitch of X / W1 rows (bytes)
     int e_bytes;                                // size of the expanded tile (also hosts the pool scratch)
+    int dbg;                                    // ablation switch (EFFDET_DEBUG_SKIP), 0 in production
 };
 
 constexpr int MC = 64;                          // expanded channels per pass
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
             sc[j] = *reinterpret_cast<const f32x4*>(cpar + 16 * j + 4 * fpiece);
             sh[j] = *reinterpret_cast<const f32x4*>(cpar + SM_MC + 16 * j + 4 * fpiece);
         }
-        for (int ms = wave; ms < n_msub; ms += SM_T / 64) {
+        for (int ms = wave; ms < ((p.dbg & 1) ? 0 : n_msub); ms += SM_T / 64) {
             f32x4 acc[SM_NJ];
 #pragma unroll
             for (int j = 0; j < SM_NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
         // ---- depthwise out of LDS: a thread owns 8 channels of one output pixel at a time
         F8 pool = f8_zero();
         const int cg = tid % SM_CG, pg0 = tid / SM_CG;
-        if (pg0 < SM_PG) {
+        if (pg0 < SM_PG && !(p.dbg & 2)) {
             for (int px = pg0; px < p.TH * p.TW; px += SM_PG) {
                 const int ty = px / p.TW, tx = px % p.TW;
                 const int oy = oy0 + ty, ox = ox0 + tx;
@@ -233,14 +235,8 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
         }
         if (p.pool_partial != nullptr) {
             __syncthreads();                                // every thread is done reading E
-            store8<float>(red + tid * 8, pool);
-            __syncthreads();
-            if (tid < SM_MC) {
-                const int g = tid >> 3, q = tid & 7;
-                float s = 0.f;
-                for (int t = g; t < SM_CG * SM_PG; t += SM_CG) s += red[t * 8 + q];
-                p.pool_partial[((long long)b * (p.tiles_x * p.tiles_y) + tile) * mid + c0 + tid] = s;
-            }
+            const float tot = pool_reduce<SM_T>(pool, red, red + SM_T * 8, tid, SM_CG, SM_CG * SM_PG);
+            if (tid < SM_MC) p.pool_partial[((long long)b * (p.tiles_x * p.tiles_y) + tile) * mid + c0 + tid] = tot;
         }
     }
 }
@@ -258,6 +254,7 @@ struct MbDeepArgs {
     float* pool_partial;
     int B, H, W, Cin, mid, Ho, Wo, pad_t, pad_l;
     int band_rows, nbands, nchunks, arow, e_rows_max;
+    int dbg;
 };
 
 template <typename T, int KS, int S, int PPT>
@@ -281,17 +278,31 @@ __global__ __launch_bounds__(256) void mbconv_deep_kernel(MbDeepArgs p) {
 
     char* Wc = lds;                                            // [MC][arow]; reused as pool scratch
     float* red = reinterpret_cast<float*>(lds);
-    const int wc_bytes = (MC * arow > 256 * 8 * 4) ? MC * arow : 256 * 8 * 4;
+    const int wc_bytes = (MC * arow > 256 * 9 * 4) ? MC * arow : 256 * 9 * 4;
     constexpr int EROW = ERow<T>::value;
     T* E = reinterpret_cast<T*>(lds + wc_bytes);               // [npx][EROW]
 
     const int ppr = nkc * 4;
-    for (int i = tid; i < MC * ppr; i += 256) {
-        const int row = i / ppr, piece = i % ppr;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (row < cn && piece * 16 < cbytes)
-            v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.W1) + (long long)(c0 + row) * cbytes + piece * 16);
-        *reinterpret_cast<u32x4*>(Wc + row * arow + piece * 16) = v;
+    {   // W1 slice -> LDS: all of a thread's pieces are loaded before the first LDS store (ppr <= 16 pieces per row)
+        constexpr int WPT_MAX = 4;
+        for (int i0 = tid; i0 < MC * ppr; i0 += 256 * WPT_MAX) {
+            u32x4 v[WPT_MAX];
+#pragma unroll
+            for (int u = 0; u < WPT_MAX; ++u) {
+                const int i = i0 + 256 * u;
+                v[u] = u32x4{0u, 0u, 0u, 0u};
+                if (i < MC * ppr) {
+                    const int row = i / ppr, piece = i % ppr;
+                    if (row < cn && piece * 16 < cbytes)
+                        v[u] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.W1) + (long long)(c0 + row) * cbytes + piece * 16);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < WPT_MAX; ++u) {
+                const int i = i0 + 256 * u;
+                if (i < MC * ppr) *reinterpret_cast<u32x4*>(Wc + (i / ppr) * arow + (i % ppr) * 16) = v[u];
+            }
+        }
     }
     f32x4 sc[4], sh[4];
 #pragma unroll
@@ -321,7 +332,7 @@ __global__ __launch_bounds__(256) void mbconv_deep_kernel(MbDeepArgs p) {
     // ---- expand the band: two 16-pixel sub-tiles per step share every W fragment read
     const char* Xb = reinterpret_cast<const char*>(p.X) + ((long long)b * p.H * W + (long long)iy_lo * W) * cbytes;
     const int n_pair = (npx + 31) / 32;
-    for (int mp = wave; mp < n_pair; mp += 4) {
+    for (int mp = wave; mp < ((p.dbg & 1) ? 0 : n_pair); mp += 4) {
         f32x4 acc[2][4];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
@@ -378,7 +389,7 @@ __global__ __launch_bounds__(256) void mbconv_deep_kernel(MbDeepArgs p) {
     const int cgn = cn / 8;
     F8 pool = f8_zero();
     const int cg = tid & 7;
-    if (cg < cgn) {
+    if (cg < cgn && !(p.dbg & 2)) {
         const F8 s2 = load8<float>(cpar + cg * 8), t2 = load8<float>(cpar + MC + cg * 8);
         const int gpr = (p.Wo + PPT - 1) / PPT;
         for (int pg = tid >> 3; pg < (oy_e - oy_b) * gpr; pg += 32) {
@@ -426,15 +437,9 @@ __global__ __launch_bounds__(256) void mbconv_deep_kernel(MbDeepArgs p) {
         }
     }
     if (p.pool_partial != nullptr) {
-        __syncthreads();                                       // every wave is done reading Wc
-        store8<float>(red + tid * 8, pool);
-        __syncthreads();
-        if (tid < cn) {
-            const int g = tid >> 3, q = tid & 7;
-            float s = 0.f;
-            for (int t = g; t < 256; t += 8) s += red[t * 8 + q];
-            p.pool_partial[((long long)b * p.nbands + band) * mid + c0 + tid] = s;
-        }
+        __syncthreads();                                       // every wave is done reading the W slot
+        const float tot = pool_reduce<256>(pool, red, red + 256 * 8, tid, 8, 256);    // cg = tid & 7; idle groups hold zeros
+        if (tid < cn) p.pool_partial[((long long)b * p.nbands + band) * mid + c0 + tid] = tot;
     }
 }
 
@@ -447,7 +452,7 @@ DeepGeometry pick_deep(int H, int W, int Cin, int mid, int k, int stride) {
     const int nkc = (Cin * (int)sizeof(T) + 63) / 64;
     g.arow = nkc * 64 + 16;
     g.nchunks = (mid + MC - 1) / MC;
-    const size_t wc = (size_t)MC * g.arow > 8192 ? (size_t)MC * g.arow : 8192;
+    const size_t wc = (size_t)MC * g.arow > 9216 ? (size_t)MC * g.arow : 9216;
     const size_t budget = 78 * 1024;      // two workgroups per CU (160 KiB LDS)
     g.use = false;
     if (Cin * (int)sizeof(T) < 128 || wc + (size_t)k * W * ERow<T>::value * sizeof(T) > budget) return g;   // wide inputs, narrow maps only
@@ -478,7 +483,7 @@ Geometry pick_tile(int Ho, int Wo, int Cin, int k, int stride) {
         g.HP = g.IH * g.IW; g.HPpad = (g.HP + 15) / 16 * 16;
         g.arow = Cin * (int)sizeof(T) + 16;
         g.e_bytes = g.HP * ERowS<T>::value * (int)sizeof(T);
-        if (g.e_bytes < SM_T * 8 * 4) g.e_bytes = SM_T * 8 * 4;
+        if (g.e_bytes < SM_T * 9 * 4) g.e_bytes = SM_T * 9 * 4;       // also hosts the pool-reduction scratch
         g.e_bytes = (g.e_bytes + 15) / 16 * 16;
         g.lds = (size_t)g.HPpad * g.arow + (size_t)SM_MC * g.arow + (size_t)g.e_bytes + (size_t)(4 + k * k) * SM_MC * 4;
         best = g;
@@ -492,7 +497,7 @@ Geometry pick_tile(int Ho, int Wo, int Cin, int k, int stride) {
 template <typename T>
 int launch_deep(hipStream_t st, const MbArgs& a, const DeepGeometry& g) {
     MbDeepArgs d{a.X, a.Y, a.W1, a.s1, a.t1, a.taps, a.s2, a.t2, a.pool_partial, a.B, a.H, a.W, a.Cin, a.mid, a.Ho, a.Wo,
-                 a.pad_t, a.pad_l, g.band_rows, g.nbands, g.nchunks, g.arow, g.e_rows_max};
+                 a.pad_t, a.pad_l, g.band_rows, g.nbands, g.nchunks, g.arow, g.e_rows_max, a.dbg};
     void (*kern)(MbDeepArgs) = nullptr;
     if (a.k == 3) kern = a.stride == 1 ? mbconv_deep_kernel<T, 3, 1, 4> : mbconv_deep_kernel<T, 3, 2, 4>;
     else kern = a.stride == 1 ? mbconv_deep_kernel<T, 5, 1, 4> : mbconv_deep_kernel<T, 5, 2, 4>;
@@ -551,6 +556,8 @@ extern "C" int effdet_mbconv_expand_dw(void* stream, int dtype, const void* X, v
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.mid = mid; a.k = k; a.stride = stride;
     a.Ho = same_out(H, stride); a.Wo = same_out(W, stride);
     a.pad_t = same_pad_before(H, k, stride); a.pad_l = same_pad_before(W, k, stride);
+    static const int dbg = getenv("EFFDET_DEBUG_SKIP") ? atoi(getenv("EFFDET_DEBUG_SKIP")) : 0;
+    a.dbg = dbg;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return dtype == 0 ? launch_mb<float>(st, a) : launch_mb<bf16_t>(st, a);
 }

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(SdArgs p) {
     char* Wl = lds + ((IN_ELEMS * (int)sizeof(T) + 15) / 16) * 16;           // [cpad][WROW]
     T* E = reinterpret_cast<T*>(Wl + cpad * WROW);                           // [HP][erow]
     float* red = reinterpret_cast<float*>(reinterpret_cast<char*>(E) + ((SD_HP * erow * (int)sizeof(T) + 15) / 16) * 16);
-    float* par = red + 256 * 8;                                              // [13][C] per-channel constants
+    float* par = red + 256 * 9;                                              // [13][C] per-channel constants
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fpiece = lane >> 4;
@@ -94,15 +94,28 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(SdArgs p) {
             v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.Wk) + row * 32 * sizeof(T) + piece * 16);
         *reinterpret_cast<u32x4*>(Wl + row * WROW + piece * 16) = v;
     }
-    // per-channel constants of both convs -> LDS once: taps [9][C], s1, t1, s2, t2
-    for (int i = tid; i < 13 * C; i += 256) {
-        float v;
-        if (i < 9 * C) v = p.taps[i];
-        else if (i < 10 * C) v = p.s1[i - 9 * C];
-        else if (i < 11 * C) v = p.t1[i - 10 * C];
-        else if (i < 12 * C) v = p.s2[i - 11 * C];
-        else v = p.t2[i - 12 * C];
-        par[i] = v;
+    // per-channel constants of both convs -> LDS once: taps [9][C], s1, t1, s2, t2 (13 * C <= 832 values:
+    // up to four per thread, all loaded before the first LDS store)
+    {
+        float pv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + 256 * q;
+            float v = 0.f;
+            if (i < 13 * C) {
+                if (i < 9 * C) v = p.taps[i];
+                else if (i < 10 * C) v = p.s1[i - 9 * C];
+                else if (i < 11 * C) v = p.t1[i - 10 * C];
+                else if (i < 12 * C) v = p.s2[i - 11 * C];
+                else v = p.t2[i - 12 * C];
+            }
+            pv[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + 256 * q;
+            if (i < 13 * C) par[i] = pv[q];
+        }
     }
     // per-lane im2col offsets (relative to the pixel's top-left input element); k >= 27 -> the zero slot
     int koff[NKC][EPC];
@@ -206,14 +219,8 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(SdArgs p) {
         }
     }
     if (p.pool_partial != nullptr) {
-        store8<float>(red + tid * 8, pool);
-        __syncthreads();
-        if (tid < C) {
-            const int g = tid >> 3, q = tid & 7;
-            float s = 0.f;
-            for (int t = g; t < cgn * PG; t += cgn) s += red[t * 8 + q];
-            p.pool_partial[((long long)b * (p.tiles_x * p.tiles_y) + tile) * C + tid] = s;
-        }
+        const float tot = pool_reduce<256>(pool, red, red + 256 * 8, tid, cgn, cgn * PG);
+        if (tid < C) p.pool_partial[((long long)b * (p.tiles_x * p.tiles_y) + tile) * C + tid] = tot;
     }
 }
 
@@ -225,7 +232,7 @@ size_t sd_lds_bytes(int C) {
     size_t n = ((3 * SD_IH * SD_IW + 8) * sizeof(T) + 15) / 16 * 16;
     n += (size_t)cpad * WROW;
     n += ((size_t)SD_HP * erow * sizeof(T) + 15) / 16 * 16;
-    n += 256 * 8 * 4;
+    n += 256 * 9 * 4;
     n += (size_t)13 * C * 4;
     return n;
 }
