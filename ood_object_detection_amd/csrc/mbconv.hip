@@ -82,7 +82,11 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
     char* Wc = At + p.HPpad * arow;                         // [SM_MC][arow]
     T* E = reinterpret_cast<T*>(Wc + SM_MC * arow);         // [HP][EROW]
     float* red = reinterpret_cast<float*>(E);               // [SM_T][8] pool scratch: reuses E after the depthwise pass
-    float* cpar = reinterpret_cast<float*>(reinterpret_cast<char*>(E) + p.e_bytes);   // [s1|t1|s2|t2|taps][SM_MC]
+    float* cpar = reinterpret_cast<float*>(reinterpret_cast<char*>(E) + p.e_bytes);   // [s1|t1|s2|t2][SM_MC] fp32, then taps
+    float* ctap = cpar + 4 * SM_MC;                         // [KS*KS][SM_MC] fp32: the depthwise loop is VALU-bound, so no converts
+    float* msk = cpar + NPAR * SM_MC;                       // [HPpad] 1 inside the image, 0 outside / padding rows
+    const char* zslot = reinterpret_cast<const char*>(msk + p.HPpad);   // 16 zero bytes: operand of lanes past the row end
+    if (tid < 4) reinterpret_cast<unsigned*>(msk + p.HPpad)[tid] = 0u;
 
     // ---- input halo tile -> LDS (zero rows outside the image); loads batched ahead of their LDS stores
     const T* X = reinterpret_cast<const T*>(p.X) + (long long)b * p.H * p.W * Cin;
@@ -95,11 +99,14 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
             v[u] = u32x4{0u, 0u, 0u, 0u};
             if (i < p.HPpad * ppr) {
                 const int hp = i / ppr, piece = i % ppr;
+                bool inside = false;
                 if (hp < p.HP) {
                     const int y = iy0 + hp / p.IW, x = ix0 + hp % p.IW;
-                    if (y >= 0 && y < p.H && x >= 0 && x < p.W)
+                    inside = y >= 0 && y < p.H && x >= 0 && x < p.W;
+                    if (inside)
                         v[u] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(X + ((long long)y * p.W + x) * Cin) + piece * 16);
                 }
+                if (piece == 0) msk[hp] = inside ? 1.f : 0.f;
             }
         }
 #pragma unroll
@@ -114,10 +121,10 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
 
     // W1 and the per-channel constants of pass c+1 are fetched into registers at the start of pass c and
     // committed to LDS at the start of pass c+1: their latency hides behind the expand + depthwise work.
-    constexpr int WPC = 2, PPC = (NPAR * SM_MC + SM_T - 1) / SM_T;
+    constexpr int WPC = 1, PPC = (KS * KS * SM_MC + SM_T - 1) / SM_T;
     const bool w_pref = SM_MC * ppr <= SM_T * WPC;
     u32x4 wpre[WPC];
-    float ppre[PPC];
+    float ppre[PPC], bnpre;
     auto fetch = [&](int c0n) {
         if (w_pref) {
 #pragma unroll
@@ -128,16 +135,20 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
                     wpre[q] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.W1) + (long long)(c0n + i / ppr) * cbytes + (i % ppr) * 16);
             }
         }
+        // taps: one base pointer + a 32-bit offset per lane; the four BN vectors: one predicated load each
 #pragma unroll
         for (int q = 0; q < PPC; ++q) {
             const int i = tid + SM_T * q;
+            ppre[q] = i < KS * KS * SM_MC ? p.taps[(i / SM_MC) * mid + c0n + i % SM_MC] : 0.f;
+        }
+        {
+            const int r = tid / SM_MC, c = c0n + tid % SM_MC;
             float v = 0.f;
-            if (i < NPAR * SM_MC) {
-                const int r = i / SM_MC, c = i % SM_MC;
-                const float* src = r == 0 ? p.s1 : r == 1 ? p.t1 : r == 2 ? p.s2 : r == 3 ? p.t2 : p.taps + (long long)(r - 4) * mid;
-                v = src[c0n + c];
-            }
-            ppre[q] = v;
+            if (r == 0) v = p.s1[c];
+            if (r == 1) v = p.t1[c];
+            if (r == 2) v = p.s2[c];
+            if (r == 3) v = p.t2[c];
+            bnpre = v;
         }
     };
     auto commit = [&](int c0n) {
@@ -155,10 +166,25 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
 #pragma unroll
         for (int q = 0; q < PPC; ++q) {
             const int i = tid + SM_T * q;
-            if (i < NPAR * SM_MC) cpar[i] = ppre[q];
+            if (i < KS * KS * SM_MC) ctap[i] = ppre[q];
         }
+        if (tid < 4 * SM_MC) cpar[tid] = bnpre;
     };
     fetch(0);
+
+    // Operand addresses of the expand GEMM are lane-invariant: a lane whose 16-byte piece lies past the end of
+    // the (tight) row reads the zero slot instead, so the loop carries no per-lane branches.
+    constexpr int HK = KS == 3 ? 2 : 1;                                   // K-chunks whose W fragments are held in registers
+    const bool hoist = nkc <= HK;
+    const int fo = fpiece * 16;
+    const char* xa[HK];
+    int xs[HK];
+#pragma unroll
+    for (int kc = 0; kc < HK; ++kc) {
+        const bool ok = kc * 64 + fo < cbytes;
+        xa[kc] = ok ? At + (16 * wave + frow) * arow + kc * 64 + fo : zslot;
+        xs[kc] = ok ? 16 * (SM_T / 64) * arow : 0;
+    }
 
     for (int c0 = 0; c0 < mid; c0 += SM_MC) {
         __syncthreads();                                    // previous pass done with Wc / E / red / cpar
@@ -166,38 +192,53 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
         __syncthreads();
         if (c0 + SM_MC < mid) fetch(c0 + SM_MC);
         // ---- expand: rows of the accumulator = channels, columns = halo pixels
-        f32x4 sc[SM_NJ], sh[SM_NJ];
+        Frag<T> wreg[HK][SM_NJ];
+        if (hoist) {
 #pragma unroll
-        for (int j = 0; j < SM_NJ; ++j) {
-            sc[j] = *reinterpret_cast<const f32x4*>(cpar + 16 * j + 4 * fpiece);
-            sh[j] = *reinterpret_cast<const f32x4*>(cpar + SM_MC + 16 * j + 4 * fpiece);
+            for (int kc = 0; kc < HK; ++kc)
+#pragma unroll
+                for (int j = 0; j < SM_NJ; ++j)
+                    wreg[kc][j] = ld_frag<T>(kc * 64 + fo < cbytes ? Wc + (16 * j + frow) * arow + kc * 64 + fo : zslot);
         }
+        const char* xp[HK];
+#pragma unroll
+        for (int kc = 0; kc < HK; ++kc) xp[kc] = xa[kc];
         for (int ms = wave; ms < ((p.dbg & 1) ? 0 : n_msub); ms += SM_T / 64) {
             f32x4 acc[SM_NJ];
 #pragma unroll
             for (int j = 0; j < SM_NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int kc = 0; kc < nkc; ++kc) {
-                const int off = kc * 64 + fpiece * 16;        // rows hold exactly cbytes (+16 pad): guard the tail
-                Frag<T> xf;
-                if (off < cbytes) xf = ld_frag<T>(At + (16 * ms + frow) * arow + off); else xf.v = decltype(xf.v){};
+            const int hp = 16 * ms + frow;
+            const float m = msk[hp];
+            if (hoist) {
 #pragma unroll
-                for (int j = 0; j < SM_NJ; ++j) {
-                    Frag<T> wf;
-                    if (off < cbytes) wf = ld_frag<T>(Wc + (16 * j + frow) * arow + off); else wf.v = decltype(wf.v){};
-                    mma_chunk(wf, xf, acc[j]);
+                for (int kc = 0; kc < HK; ++kc) {
+                    if (kc < nkc) {
+                        const Frag<T> xf = ld_frag<T>(xp[kc]);
+#pragma unroll
+                        for (int j = 0; j < SM_NJ; ++j) mma_chunk(wreg[kc][j], xf, acc[j]);
+                    }
+                    xp[kc] += xs[kc];
+                }
+            } else {
+                for (int kc = 0; kc < nkc; ++kc) {
+                    const int off = kc * 64 + fo;
+                    const Frag<T> xf = ld_frag<T>(off < cbytes ? At + hp * arow + off : zslot);
+#pragma unroll
+                    for (int j = 0; j < SM_NJ; ++j) {
+                        const Frag<T> wf = ld_frag<T>(off < cbytes ? Wc + (16 * j + frow) * arow + off : zslot);
+                        mma_chunk(wf, xf, acc[j]);
+                    }
                 }
             }
-            const int hp = 16 * ms + frow;
-            if (hp < p.HP) {
-                const int y = iy0 + hp / p.IW, x = ix0 + hp % p.IW;
-                const bool inside = y >= 0 && y < p.H && x >= 0 && x < p.W;
+            // BN + SiLU on all 12 values at once (independent chains), zeroed outside the image by the mask
 #pragma unroll
-                for (int j = 0; j < SM_NJ; ++j) {
-                    float v[4];
+            for (int j = 0; j < SM_NJ; ++j) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(cpar + 16 * j + 4 * fpiece);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(cpar + SM_MC + 16 * j + 4 * fpiece);
+                float v[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = inside ? silu_t<T>(acc[j][r] * sc[j][r] + sh[j][r]) : 0.f;
-                    store4<T>(E + hp * EROW + 16 * j + 4 * fpiece, v[0], v[1], v[2], v[3]);
-                }
+                for (int r = 0; r < 4; ++r) v[r] = silu_t<T>(acc[j][r] * sc[r] + sh[r]) * m;
+                store4<T>(E + hp * EROW + 16 * j + 4 * fpiece, v[0], v[1], v[2], v[3]);
             }
         }
         __syncthreads();
@@ -211,17 +252,17 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
                 if (oy >= p.Ho || ox >= p.Wo) continue;
                 F8 acc = f8_zero();
 #pragma unroll 1
-                for (int ky = 0; ky < KS; ++ky) {          // one tap / one LDS vector at a time: small register footprint
-                    const T* erow = E + ((ty * S + ky) * p.IW + tx * S) * EROW + cg * 8;
-                    const float* wrow = cpar + (4 + ky * KS) * SM_MC + cg * 8;
+                    for (int ky = 0; ky < KS; ++ky) {      // one tap / one LDS vector at a time: small register footprint
+                        const T* erow = E + ((ty * S + ky) * p.IW + tx * S) * EROW + cg * 8;
+                        const float* wrow = ctap + (ky * KS) * SM_MC + cg * 8;
 #pragma unroll
-                    for (int kx = 0; kx < KS; ++kx) {
-                        const F8 e = load8<T>(erow + kx * EROW);
-                        const F8 w = load8<float>(wrow + kx * SM_MC);
+                        for (int kx = 0; kx < KS; ++kx) {
+                            const F8 e = load8<T>(erow + kx * EROW);
+                            const F8 w = load8<float>(wrow + kx * SM_MC);
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) acc.v[q] = fmaf(e.v[q], w.v[q], acc.v[q]);
+                            for (int q = 0; q < 8; ++q) acc.v[q] = fmaf(e.v[q], w.v[q], acc.v[q]);
+                        }
                     }
-                }
                 const F8 s2 = load8<float>(cpar + 2 * SM_MC + cg * 8), t2 = load8<float>(cpar + 3 * SM_MC + cg * 8);
                 F8 o;
 #pragma unroll
@@ -317,7 +358,7 @@ __global__ __launch_bounds__(256) void mbconv_deep_kernel(MbDeepArgs p) {
     // depthwise constants of this channel slice: fetched now, parked in the W slot once the expand is done
     constexpr int NPAR = 2 + KS * KS;                         // s2 | t2 | taps
     constexpr int PPC = (NPAR * MC + 255) / 256;
-    float ppre[PPC];
+    float ppre[PPC], bnpre;
 #pragma unroll
     for (int q = 0; q < PPC; ++q) {
         const int i = tid + 256 * q;
@@ -482,10 +523,11 @@ Geometry pick_tile(int Ho, int Wo, int Cin, int k, int stride) {
         g.IH = (g.TH - 1) * stride + k; g.IW = (g.TW - 1) * stride + k;
         g.HP = g.IH * g.IW; g.HPpad = (g.HP + 15) / 16 * 16;
         g.arow = Cin * (int)sizeof(T) + 16;
-        g.e_bytes = g.HP * ERowS<T>::value * (int)sizeof(T);
+        g.e_bytes = g.HPpad * ERowS<T>::value * (int)sizeof(T);
         if (g.e_bytes < SM_T * 9 * 4) g.e_bytes = SM_T * 9 * 4;       // also hosts the pool-reduction scratch
         g.e_bytes = (g.e_bytes + 15) / 16 * 16;
-        g.lds = (size_t)g.HPpad * g.arow + (size_t)SM_MC * g.arow + (size_t)g.e_bytes + (size_t)(4 + k * k) * SM_MC * 4;
+        g.lds = (size_t)g.HPpad * g.arow + (size_t)SM_MC * g.arow + (size_t)g.e_bytes + (size_t)(4 + k * k) * SM_MC * 4
+              + (size_t)g.HPpad * 4 + 16;               // + inside-mask + zero slot
         best = g;
         // a tile much larger than the map wastes the workgroup; keep two workgroups per CU (<= 76 KiB each)
         const bool fits_map = (g.TH <= Ho || g.TH == 2) && (g.TW <= 2 * Wo);
