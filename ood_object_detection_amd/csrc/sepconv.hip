@@ -13,8 +13,10 @@
 // A workgroup owns a TH x TW pixel tile of one level of one image:
 //   phase 1  fused+activated (TH+2) x (TW+2) halo tile -> LDS, 64 channels at a time
 //   phase 2  depthwise 3x3 out of LDS -> A tile [TH*TW][F] in LDS
-//   phase 3  A x Wpw^T by 16x16 MFMA tiles, BN output columns at a time; accumulators staged through
-//            LDS, affine/activation applied, whole 16-byte row pieces stored to HBM
+//   phase 3  Wpw x A^T by 16x16 MFMA tiles, BN output channels at a time.  The accumulator rows are output
+//            channels and its columns pixels, and the W rows are permuted on their way into LDS so that one lane
+//            ends up with 8 CONSECUTIVE channels of one pixel per pair of tiles: affine / activation / the OOD
+//            reduction all happen in registers and each lane stores 16 bytes straight to HBM (no staging pass).
 // so every feature map is read once and written once per node/layer.
 #include "common.h"
 #include <type_traits>
@@ -36,6 +38,8 @@ struct SepArgs {
     int nlevels; SepLevel lv[5];
     int n_in, fuse_mode;                       // fuse_mode 0: single input; 1: (x*w)/den; 2: x*w
     float fw[3]; float fden;
+    float fwn[3];                              // fw / fden (throughput mode multiplies instead of dividing)
+    int vec_ok;                                // output rows are dword aligned: 8-channel pieces go out as vectors
     int pre_act, post_act;
     const float* dw_w;                         // [9][F]
     const void* pw_w;                          // [N][F]
@@ -48,11 +52,12 @@ struct SepArgs {
 constexpr int FC = 64;    // channels per halo pass
 
 
+
+// 8 channels of input `in` (already offset to the image) at output-grid position (y, x)
 template <typename T>
-DEV F8 fetch_input(const SepInput& in, int b, int y, int x, int F, int c) {
-    const T* base = reinterpret_cast<const T*>(in.ptr) + (long long)b * in.image_stride;
-    if (in.mode == 0) return load8<T>(base + ((long long)y * in.W + x) * F + c);
-    if (in.mode == 1) return load8<T>(base + ((long long)(y >> 1) * in.W + (x >> 1)) * F + c);
+DEV F8 fetch_input(const T* base, const SepInput& in, int y, int x, int F, int c) {
+    if (in.mode == 0) return load8<T>(base + (y * in.W + x) * F + c);
+    if (in.mode == 1) return load8<T>(base + ((y >> 1) * in.W + (x >> 1)) * F + c);
     F8 m = f8_fill(-INFINITY);
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
@@ -62,7 +67,7 @@ DEV F8 fetch_input(const SepInput& in, int b, int y, int x, int F, int c) {
         for (int kx = 0; kx < 3; ++kx) {
             const int ix = 2 * x + kx - in.pad_l;
             if (ix < 0 || ix >= in.W) continue;
-            const F8 v = load8<T>(base + ((long long)iy * in.W + ix) * F + c);
+            const F8 v = load8<T>(base + (iy * in.W + ix) * F + c);
 #pragma unroll
             for (int e = 0; e < 8; ++e) m.v[e] = fmaxf(m.v[e], v.v[e]);
         }
@@ -70,33 +75,53 @@ DEV F8 fetch_input(const SepInput& in, int b, int y, int x, int F, int c) {
     return m;
 }
 
-template <typename T, int TH, int TW, int BN, bool OOD, int NTH>
-__global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((OOD || sizeof(T) == 4) ? 2 : 3)) void sepconv_kernel(SepArgs p) {
-    // staging element: fp32 when the OOD reduction reads it back, else the output dtype (half the LDS)
-    typedef typename std::conditional<OOD, float, T>::type ST;
+// 8 consecutive output channels -> memory.  Rows are only guaranteed dword aligned (e.g. 1620-byte class
+// rows), which global_store_dwordx4 accepts.
+template <typename T>
+DEV void store_piece(T* dst, const float (&v)[8], int nvalid, bool vec_ok) {
+    if (vec_ok && nvalid >= 8) {
+        if constexpr (sizeof(T) == 2) {
+            typedef unsigned u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+            bf16x8 a;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = (bf16_t)v[e];
+            *reinterpret_cast<u32x4_a4*>(dst) = __builtin_bit_cast(u32x4, a);
+        } else {
+            typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+            *reinterpret_cast<f32x4_a4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4_a4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (e < nvalid) dst[e] = from_f<T>(v[e]);
+    }
+}
+
+// FT: the channel count when known at compile time (all index arithmetic folds), 0 = read it from the arguments
+template <typename T, int TH, int TW, int BN, bool OOD, int NTH, int FT>
+__global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void sepconv_kernel(SepArgs p) {
     constexpr int BM = TH * TW;
     constexpr int HW_ = (TH + 2) * (TW + 2);
     constexpr int NWAVE = NTH / 64;
-    constexpr int WPT = BM / (16 * NWAVE);       // 16-row MFMA tiles per wave
-    constexpr int NT = BN / 16;
-    constexpr int SROW = BN + 24;                // + 8 columns the alignment shift can spill into, + bank spread
+    constexpr int WPT = BM / (16 * NWAVE);       // 16-pixel MFMA tiles per wave
+    constexpr int NT = BN / 16;                  // 16-channel tiles per chunk
+    constexpr int NP = NT / 2;                   // tile pairs = 32-channel groups
+    static_assert(NT % 2 == 0 && WPT >= 1, "tile shape");
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
-    const int F = p.F, N = p.N;
+    const int F = FT ? FT : p.F, N = p.N;
     const int fbytes = F * (int)sizeof(T);
     const int nkc = (fbytes + 63) / 64;
     const int arow = nkc * 64 + 16;              // A / W row pitch in bytes
-    // LDS carve (all multiples of 16)
+    // LDS carve (all multiples of 16): the halo tile (phases 1-2) and the W chunk (phase 3) share a region
     constexpr int HALO_BYTES = HW_ * FC * (int)sizeof(T);
-    constexpr int STAGE_BYTES = BM * SROW * (int)sizeof(ST) + (OOD ? BM * 8 : 0);
-    constexpr int R0 = HALO_BYTES > STAGE_BYTES ? HALO_BYTES : STAGE_BYTES;
-    char* halo = lds;                            // phase 1/2
-    ST* S = reinterpret_cast<ST*>(lds);          // phase 3 staging (aliases halo)
-    float* run_m = reinterpret_cast<float*>(lds + BM * SROW * sizeof(ST));   // running max / sum-exp per row (OOD)
-    float* run_s = run_m + BM;
-    char* At = lds + R0;
-    char* Wt = At + BM * arow;
-    float* dww = reinterpret_cast<float*>(Wt + BN * arow);   // [9][F]
+    const int r0 = HALO_BYTES > BN * arow ? HALO_BYTES : BN * arow;
+    char* halo = lds;
+    char* Wt = lds;
+    char* At = lds + r0;
+    float* dww = reinterpret_cast<float*>(At + BM * arow);   // [9][F]
+    float* cs = dww + 9 * F;                                  // [2][BN] scale | shift of the current chunk
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
@@ -125,15 +150,23 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((OOD || sizeof(T) == 4) ? 2 
             *reinterpret_cast<u32x4*>(At + row * arow + fbytes + piece * 16) = u32x4{0u, 0u, 0u, 0u};
         }
     }
+    const T* ib[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        ib[i] = i < p.n_in ? reinterpret_cast<const T*>(L.in[i].ptr) + (long long)b * L.in[i].image_stride : nullptr;
+    float fwm[3];                                         // per-input multiplier of the fused sum
+#pragma unroll
+    for (int i = 0; i < 3; ++i) fwm[i] = (sizeof(T) == 2 && p.fuse_mode == 1) ? p.fwn[i] : p.fw[i];
+    const bool divide = sizeof(T) == 4 && p.fuse_mode == 1;   // parity mode keeps the reference's (x*w)/sum order
 
     // ------------------------------------------------------------------ phases 1 + 2 per 64 channels
     for (int fc0 = 0; fc0 < F; fc0 += FC) {
         const int fcn = (F - fc0) < FC ? (F - fc0) : FC;
         const int fcg = fcn / 8;
         __syncthreads();
-        // two halo items per step: their input loads are all issued before the first use (the loop has a runtime
+        // HU halo items per step: their input loads are all issued before the first use (the loop has a runtime
         // trip count, so the compiler would otherwise expose one memory round trip per item)
-        constexpr int HU = NTH == 512 ? 1 : 2;              // halo items in flight per thread
+        constexpr int HU = NTH == 512 ? 1 : 2;
         for (int it0 = tid; it0 < HW_ * fcg; it0 += HU * NTH) {
             F8 xin[HU][3];
             bool ok[HU];
@@ -147,7 +180,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((OOD || sizeof(T) == 4) ? 2 
                     const int c = fc0 + cgh * 8;
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
-                        if (i < p.n_in) xin[u][i] = fetch_input<T>(L.in[i], b, y, x, F, c);
+                        if (i < p.n_in) xin[u][i] = fetch_input<T>(ib[i], L.in[i], y, x, F, c);
                 }
             }
 #pragma unroll
@@ -163,12 +196,12 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((OOD || sizeof(T) == 4) ? 2 
 #pragma unroll
                         for (int i = 0; i < 3; ++i) {
                             if (i < p.n_in) {
-                                if (p.fuse_mode == 1) {
+                                if (divide) {
 #pragma unroll
-                                    for (int e = 0; e < 8; ++e) v.v[e] += (xin[u][i].v[e] * p.fw[i]) / p.fden;
+                                    for (int e = 0; e < 8; ++e) v.v[e] += (xin[u][i].v[e] * fwm[i]) / p.fden;
                                 } else {
 #pragma unroll
-                                    for (int e = 0; e < 8; ++e) v.v[e] += xin[u][i].v[e] * p.fw[i];
+                                    for (int e = 0; e < 8; ++e) v.v[e] = fmaf(xin[u][i].v[e], fwm[i], v.v[e]);
                                 }
                             }
                         }
@@ -202,32 +235,29 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((OOD || sizeof(T) == 4) ? 2 
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const F8 xv = load8<T>(reinterpret_cast<const T*>(halo) + ((ty + ky) * (TW + 2) + tx + kx) * FC + cg * 8);
-                    const float* w = dww + (ky * 3 + kx) * F + fc0 + cg * 8;
+                    const F8 w = load8<float>(dww + (ky * 3 + kx) * F + fc0 + cg * 8);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc.v[e] = fmaf(xv.v[e], w[e], acc.v[e]);
+                    for (int e = 0; e < 8; ++e) acc.v[e] = fmaf(xv.v[e], w.v[e], acc.v[e]);
                 }
             store8<T>(reinterpret_cast<T*>(At + px * arow) + fc0 + cg * 8, acc);
         }
     }
-    __syncthreads();
 
-    // ------------------------------------------------------------------ phase 3: column chunks
+    // ------------------------------------------------------------------ phase 3: channel chunks
     const int frow = lane & 15, fpiece = lane >> 4;
     const int C = OOD ? p.ood_classes : 0;
-    constexpr bool ood = OOD;
-    const int subs = ood ? (C + BN - 1) / BN : 1;
-    const int nchunks = ood ? p.num_anchors * subs : (N + BN - 1) / BN;
+    const int subs = OOD ? (C + BN - 1) / BN : 1;
+    const int nchunks = OOD ? p.num_anchors * subs : (N + BN - 1) / BN;
     const float* scale = p.scale ? p.scale + (long long)L.affine_row * N : nullptr;
     const float* shift = p.shift + (long long)L.affine_row * N;
     T* out = reinterpret_cast<T*>(L.out) + (long long)b * L.out_image_stride;
-    float* cs = dww + 9 * F;                           // per-chunk scale[BN], shift[BN]
     const int ppr = nkc * 4;                           // 16-byte pieces per W row
-    constexpr int WPC = 4;                             // W pieces a thread may prefetch (BN * ppr <= 1024)
+    constexpr int WPC = (BN * 8 + NTH - 1) / NTH;      // W pieces a thread prefetches when a row has <= 8 pieces
     u32x4 wpre[WPC];
-    float cpre_s = 1.0f, cpre_t = 0.0f;                 // next chunk's scale / shift for column `tid`
+    float cpre_s = 1.0f, cpre_t = 0.0f;                // next chunk's scale / shift for channel `tid`
 
     auto chunk_range = [&](int ch, int& n_begin, int& n_count) {
-        if (ood) {
+        if (OOD) {
             const int a = ch / subs, sc = ch % subs;
             n_begin = a * C + sc * BN;
             n_count = C - sc * BN; if (n_count > BN) n_count = BN;
@@ -236,6 +266,8 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((OOD || sizeof(T) == 4) ? 2 
             n_count = N - n_begin; if (n_count > BN) n_count = BN;
         }
     };
+    // channel offset co of the chunk -> LDS row: tile 2J+jj, row 4*fp+r holds channel 32J + 8fp + 4jj + r
+    auto lds_row = [](int co) { return 16 * (2 * (co >> 5) + ((co >> 2) & 1)) + 4 * ((co >> 3) & 3) + (co & 3); };
     const bool prefetch = BN * ppr <= NTH * WPC;
     auto w_fetch = [&](int ch) {                        // global -> registers (in flight across the epilogue)
         int n_begin, n_count;
@@ -245,10 +277,10 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((OOD || sizeof(T) == 4) ? 2 
             const int i = tid + NTH * q;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (i < BN * ppr) {
-                const int row = i / ppr, piece = i % ppr;
-                if (row < n_count && piece * 16 < fbytes)
+                const int co = i / ppr, piece = i % ppr;
+                if (co < n_count && piece * 16 < fbytes)
                     v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.pw_w) +
-                                                        (long long)(n_begin + row) * fbytes + piece * 16);
+                                                        (long long)(n_begin + co) * fbytes + piece * 16);
             }
             wpre[q] = v;
         }
@@ -257,226 +289,155 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((OOD || sizeof(T) == 4) ? 2 
             cpre_t = tid < n_count ? shift[n_begin + tid] : 0.0f;
         }
     };
-    auto w_commit = [&]() {
-#pragma unroll
-        for (int q = 0; q < WPC; ++q) {
-            const int i = tid + NTH * q;
-            if (i < BN * ppr) *reinterpret_cast<u32x4*>(Wt + (i / ppr) * arow + (i % ppr) * 16) = wpre[q];
-        }
-    };
     if (prefetch) w_fetch(0);
 
-    // Per-row constants of this tile, computed once: element offset of the row inside the image's output
-    // (pixel * N) and its position on the 16-byte grid.  `rowmod + n_begin` (mod ALIGN_E) is the shift that
-    // puts staging column 8k on a 16-byte boundary in memory.
-    constexpr int ALIGN_E = 16 / (int)sizeof(T);       // elements per 16 bytes
-    constexpr int GPR = BN / 8;
-    constexpr int RPT = BM * GPR / NTH;                // rows per thread in the store pass
-    const int base_mod = (int)((reinterpret_cast<uintptr_t>(out) / sizeof(T)) % ALIGN_E);
-    int st_mod[WPT][4];                                // staging rows of this lane (MFMA layout)
+    // this lane's pixels (one per 16-pixel tile of the wave)
+    int pix_off[WPT];
+    bool pix_in[WPT];
 #pragma unroll
-    for (int i = 0; i < WPT; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * WPT * wave + 16 * i + 4 * fpiece + r;
-            const int pix = (y0 + row / TW) * W + (x0 + row % TW);
-            st_mod[i][r] = (base_mod + (int)(((long long)pix * N) % ALIGN_E)) % ALIGN_E;
-        }
-    int sp_off[RPT], sp_mod[RPT];                      // store-pass rows of this thread
-    bool sp_in[RPT];
-    const int cg = tid % GPR;
-#pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-        const int row = (tid + NTH * k) / GPR;
-        const int y = y0 + row / TW, x = x0 + row % TW;
-        sp_in[k] = (y < H) && (x < W);
-        sp_off[k] = (y * W + x) * N;
-        sp_mod[k] = (base_mod + (int)(((long long)(y * W + x) * N) % ALIGN_E)) % ALIGN_E;
+    for (int i = 0; i < WPT; ++i) {
+        const int prow = 16 * WPT * wave + 16 * i + frow;
+        const int y = y0 + prow / TW, x = x0 + prow % TW;
+        pix_in[i] = y < H && x < W;
+        pix_off[i] = (y * W + x) * N;
     }
+    float run_m[WPT], run_s[WPT];                      // running max / sum-exp over the sub-chunks of an anchor
+    constexpr float LOG2E = 1.4426950408889634f;
 
     for (int ch = 0; ch < nchunks; ++ch) {
         int n_begin, n_count;
         chunk_range(ch, n_begin, n_count);
+        __syncthreads();                               // halo / previous W chunk no longer read
         if (prefetch) {
-            w_commit();
+#pragma unroll
+            for (int q = 0; q < WPC; ++q) {
+                const int i = tid + NTH * q;
+                if (i < BN * ppr) *reinterpret_cast<u32x4*>(Wt + lds_row(i / ppr) * arow + (i % ppr) * 16) = wpre[q];
+            }
+            if (tid < BN) { cs[tid] = cpre_s; cs[BN + tid] = cpre_t; }
         } else {
             for (int i = tid; i < BN * ppr; i += NTH) {
-                const int row = i / ppr, piece = i % ppr;
+                const int co = i / ppr, piece = i % ppr;
                 u32x4 v = {0u, 0u, 0u, 0u};
-                if (row < n_count && piece * 16 < fbytes)
+                if (co < n_count && piece * 16 < fbytes)
                     v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.pw_w) +
-                                                        (long long)(n_begin + row) * fbytes + piece * 16);
-                *reinterpret_cast<u32x4*>(Wt + row * arow + piece * 16) = v;
+                                                        (long long)(n_begin + co) * fbytes + piece * 16);
+                *reinterpret_cast<u32x4*>(Wt + lds_row(co) * arow + piece * 16) = v;
             }
-        }
-        if (tid < BN) {
-            if (prefetch) { cs[tid] = cpre_s; cs[BN + tid] = cpre_t; }
-            else {
+            if (tid < BN) {
                 cs[tid] = (scale && tid < n_count) ? scale[n_begin + tid] : 1.0f;
                 cs[BN + tid] = tid < n_count ? shift[n_begin + tid] : 0.0f;
             }
         }
-        if (ood && (ch % subs) == 0) {
-            for (int i = tid; i < BM; i += NTH) { run_m[i] = -INFINITY; run_s[i] = 0.f; }
-        }
         __syncthreads();
         if (prefetch && ch + 1 < nchunks) w_fetch(ch + 1);
 
-        const int njt = (n_count + 15) / 16;               // 16-column tiles that hold real columns
+        const int njp = (n_count + 31) / 32;               // 32-channel groups that hold real channels
         f32x4 acc[WPT][NT];
 #pragma unroll
         for (int i = 0; i < WPT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int kc = 0; kc < nkc; ++kc) {
-            Frag<T> a[WPT];
+            Frag<T> xb[WPT];
 #pragma unroll
             for (int i = 0; i < WPT; ++i)
-                a[i] = ld_frag<T>(At + (16 * WPT * wave + 16 * i + frow) * arow + kc * 64 + fpiece * 16);
+                xb[i] = ld_frag<T>(At + (16 * WPT * wave + 16 * i + frow) * arow + kc * 64 + fpiece * 16);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                if (j < njt) {
-                    Frag<T> bf = ld_frag<T>(Wt + (16 * j + frow) * arow + kc * 64 + fpiece * 16);
+                if (j < 2 * njp) {
+                    const Frag<T> wf = ld_frag<T>(Wt + (16 * j + frow) * arow + kc * 64 + fpiece * 16);
 #pragma unroll
-                    for (int i = 0; i < WPT; ++i) mma_chunk(a[i], bf, acc[i][j]);
+                    for (int i = 0; i < WPT; ++i) mma_chunk(wf, xb[i], acc[i][j]);
                 }
             }
         }
-        // Stage the finished values (affine + activation applied here, in MFMA layout).  Row `row` is stored
-        // shifted right by delta(row) columns so that staging column 8k is the element on a 16-byte boundary
-        // IN MEMORY (rows may start anywhere, e.g. the 1620-byte class rows): the store pass then reads aligned
-        // 8-element windows and writes whole 16-byte pieces.
-        const int nb_mod = n_begin % ALIGN_E;
+
+        // Epilogue in registers: per 32-channel group J this lane holds channels [32J + 8fp, +8) of its pixel
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            if (j < njt) {
-                const float csc = cs[16 * j + frow], csh = cs[BN + 16 * j + frow];
+        for (int i = 0; i < WPT; ++i) {
+            float m = -INFINITY, ssum = 0.f;
+            float vals[NP][8];
 #pragma unroll
-                for (int i = 0; i < WPT; ++i)
+            for (int J = 0; J < NP; ++J) {
+                if (J < njp) {
+                    const int cb = 32 * J + 8 * fpiece;
+                    const f32x4 t0 = *reinterpret_cast<const f32x4*>(cs + BN + cb);
+                    const f32x4 t1 = *reinterpret_cast<const f32x4*>(cs + BN + cb + 4);
+                    f32x4 s0 = {1.f, 1.f, 1.f, 1.f}, s1 = {1.f, 1.f, 1.f, 1.f};
+                    if (scale) {
+                        s0 = *reinterpret_cast<const f32x4*>(cs + cb);
+                        s1 = *reinterpret_cast<const f32x4*>(cs + cb + 4);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float v = acc[i][j][r] * csc + csh;
-                        if (p.post_act) v = silu_t<T>(v);
-                        const int delta = (st_mod[i][r] + nb_mod) % ALIGN_E;
-                        S[(16 * WPT * wave + 16 * i + 4 * fpiece + r) * SROW + 16 * j + frow + delta] = (ST)v;
+                        float a0 = fmaf(acc[i][2 * J][r], s0[r], t0[r]);
+                        float a1 = fmaf(acc[i][2 * J + 1][r], s1[r], t1[r]);
+                        if (p.post_act) { a0 = silu_t<T>(a0); a1 = silu_t<T>(a1); }
+                        vals[J][r] = a0; vals[J][4 + r] = a1;
                     }
-            }
-        }
-        __syncthreads();
-
-        // Store pass: GPR threads per row; thread cg owns staging columns [8cg, 8cg+8); the last thread of the
-        // row also owns the window the shift spills into.
-        constexpr float LOG2E = 1.4426950408889634f;
+                    const int nvalid = n_count - cb;
+                    if (pix_in[i] && nvalid > 0) store_piece<T>(out + pix_off[i] + n_begin + cb, vals[J], nvalid, p.vec_ok != 0);
+                    if constexpr (OOD) {
 #pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-            const int row = (tid + NTH * k) / GPR;
-            const int dl = (sp_mod[k] + nb_mod) % ALIGN_E;
-            T* drow = out + sp_off[k] + n_begin;
-            const int c_lo = cg * 8 - dl;
-            float v[8];
-            if constexpr (sizeof(ST) == 4) {
-                const f32x4 va = *reinterpret_cast<const f32x4*>(S + row * SROW + cg * 8);
-                const f32x4 vb = *reinterpret_cast<const f32x4*>(S + row * SROW + cg * 8 + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = va[e]; v[4 + e] = vb[e]; }
-            } else {
-                const bf16x8 va = *reinterpret_cast<const bf16x8*>(S + row * SROW + cg * 8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (float)va[e];
-            }
-            const bool full = (c_lo >= 0) && (c_lo + 8 <= n_count);
-            float rm = -INFINITY, rs = 0.f;
-            if (full) {                                        // the common case: no masks
-                if (sp_in[k]) {
-                    F8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o.v[e] = v[e];
-                    store8<T>(drow + c_lo, o);
-                }
-                if constexpr (OOD) {
-                    rm = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
-                }
-            } else {
-                const int lo = c_lo < 0 ? -c_lo : 0;
-                int hi = n_count - c_lo; hi = hi > 8 ? 8 : hi;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const bool ok = e >= lo && e < hi;
-                    if (ok && sp_in[k]) drow[c_lo + e] = from_f<T>(v[e]);
-                    if (!ok) v[e] = -INFINITY;
-                    if constexpr (OOD) rm = fmaxf(rm, v[e]);
-                }
-            }
-            float v2[8];
-            bool spill = false;
-            if (cg == GPR - 1 && dl > 0) {                     // the spill window [BN, BN + dl)
-                spill = true;
-                const int c2 = BN - dl;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const bool ok = e < dl && c2 + e < n_count;
-                    v2[e] = ok ? (float)S[row * SROW + BN + e] : -INFINITY;
-                    if (ok && sp_in[k]) drow[c2 + e] = from_f<T>(v2[e]);
-                    if constexpr (OOD) rm = fmaxf(rm, v2[e]);
+                        for (int e = 0; e < 8; ++e) {
+                            if (e >= nvalid) vals[J][e] = -INFINITY;
+                            m = fmaxf(m, vals[J][e]);
+                        }
+                    }
                 }
             }
             if constexpr (OOD) {
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                const float tm = (m == -INFINITY) ? 0.f : m;
 #pragma unroll
-                for (int o = 1; o < GPR; o <<= 1) rm = fmaxf(rm, __shfl_xor(rm, o, 64));
-                const float t = (rm == -INFINITY) ? 0.f : rm;
-                if constexpr (sizeof(T) == 2) {
-                    const float tl = t * LOG2E;
+                for (int J = 0; J < NP; ++J) {
+                    if (J < njp) {
+                        if constexpr (sizeof(T) == 2) {
+                            const float tl = tm * LOG2E;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) rs += __builtin_amdgcn_exp2f(fmaf(v[e], LOG2E, -tl));   // exp2(-inf) = 0
-                    if (spill) {
+                            for (int e = 0; e < 8; ++e) ssum += __builtin_amdgcn_exp2f(fmaf(vals[J][e], LOG2E, -tl));   // exp2(-inf) = 0
+                        } else {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) rs += __builtin_amdgcn_exp2f(fmaf(v2[e], LOG2E, -tl));
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) rs += (v[e] == -INFINITY) ? 0.f : expf(v[e] - t);
-                    if (spill) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) rs += (v2[e] == -INFINITY) ? 0.f : expf(v2[e] - t);
+                            for (int e = 0; e < 8; ++e) ssum += (vals[J][e] == -INFINITY) ? 0.f : expf(vals[J][e] - tm);
+                        }
                     }
                 }
-#pragma unroll
-                for (int o = 1; o < GPR; o <<= 1) rs += __shfl_xor(rs, o, 64);
-                if (cg == 0) {
-                    float pm = run_m[row], ps = run_s[row];
-                    if (rm != -INFINITY) {
-                        const float nm = fmaxf(pm, rm);
-                        ps = (pm == -INFINITY ? 0.f : ps * exp_t<T>(pm - nm)) + rs * exp_t<T>(rm - nm);
-                        pm = nm;
-                    }
-                    run_m[row] = pm; run_s[row] = ps;
-                    if ((ch % subs) == subs - 1 && sp_in[k]) {
-                        const int a = ch / subs;
-                        const long long idx = (long long)b * p.ood_image_stride + L.ood_off +
-                                              (long long)(sp_off[k] / N) * p.num_anchors + a;
-                        p.ood_energy[idx] = -(pm + logf(ps));
-                        p.ood_maxlogit[idx] = pm;
-                    }
+                ssum += __shfl_xor(ssum, 16, 64);
+                ssum += __shfl_xor(ssum, 32, 64);
+                const int sc = ch % subs;
+                float pm = sc == 0 ? -INFINITY : run_m[i], ps = sc == 0 ? 0.f : run_s[i];
+                if (m != -INFINITY) {
+                    const float nm = fmaxf(pm, m);
+                    ps = (pm == -INFINITY ? 0.f : ps * exp_t<T>(pm - nm)) + ssum * exp_t<T>(m - nm);
+                    pm = nm;
+                }
+                run_m[i] = pm; run_s[i] = ps;
+                if (sc == subs - 1 && pix_in[i] && fpiece == 0) {
+                    const int a = ch / subs;
+                    const long long idx = (long long)b * p.ood_image_stride + L.ood_off +
+                                          (long long)(pix_off[i] / N) * p.num_anchors + a;
+                    p.ood_energy[idx] = -(pm + logf(ps));
+                    p.ood_maxlogit[idx] = pm;
                 }
             }
         }
-        __syncthreads();
     }
 }
 
-template <typename T, int TH, int TW, int BN, bool OOD>
+template <typename T, int TH, int TW, int BN>
 size_t sep_lds_bytes(int F) {
     constexpr int BM = TH * TW;
     constexpr int HW_ = (TH + 2) * (TW + 2);
-    constexpr int SROW = BN + 24;
     const int nkc = (F * (int)sizeof(T) + 63) / 64;
     const int arow = nkc * 64 + 16;
     const size_t halo = (size_t)HW_ * FC * sizeof(T);
-    const size_t stage = (size_t)BM * SROW * (OOD ? 4 : sizeof(T)) + (OOD ? BM * 8 : 0);
-    return (halo > stage ? halo : stage) + (size_t)BM * arow + (size_t)BN * arow + (size_t)9 * F * 4 + (size_t)2 * BN * 4;
+    const size_t wt = (size_t)BN * arow;
+    return (halo > wt ? halo : wt) + (size_t)BM * arow + (size_t)9 * F * 4 + (size_t)2 * BN * 4;
 }
 
-template <typename T, int TH, int TW, int BN, bool OOD, int NTH>
+template <typename T, int TH, int TW, int BN, bool OOD, int NTH, int FT>
 int launch_sep(hipStream_t st, SepArgs& a, int B) {
     int tiles = 0;
     for (int i = 0; i < a.nlevels; ++i) {
@@ -485,9 +446,9 @@ int launch_sep(hipStream_t st, SepArgs& a, int B) {
         a.lv[i].tile_begin = tiles;
         tiles += a.lv[i].tiles_x * a.lv[i].tiles_y;
     }
-    const size_t lds = sep_lds_bytes<T, TH, TW, BN, OOD>(a.F);
+    const size_t lds = sep_lds_bytes<T, TH, TW, BN>(a.F);
     if (lds > 160 * 1024) return EFFDET_EINVAL;
-    auto kern = sepconv_kernel<T, TH, TW, BN, OOD, NTH>;
+    auto kern = sepconv_kernel<T, TH, TW, BN, OOD, NTH, FT>;
     if (lds > 64 * 1024) {
         static bool attr_done = false;           // one per template instantiation
         if (!attr_done) {
@@ -498,6 +459,13 @@ int launch_sep(hipStream_t st, SepArgs& a, int B) {
     }
     hipLaunchKernelGGL(kern, dim3(tiles, B), dim3(NTH), lds, st, a);
     return effdet_check_launch();
+}
+
+template <typename T, int TH, int TW, int NTH>
+int dispatch_sep(hipStream_t st, SepArgs& a, int B) {
+    const bool ood = a.ood_classes > 0;
+    if (a.F == 64) return ood ? launch_sep<T, TH, TW, 96, true, NTH, 64>(st, a, B) : launch_sep<T, TH, TW, 64, false, NTH, 64>(st, a, B);
+    return ood ? launch_sep<T, TH, TW, 96, true, NTH, 0>(st, a, B) : launch_sep<T, TH, TW, 64, false, NTH, 0>(st, a, B);
 }
 
 }  // namespace
@@ -531,6 +499,9 @@ extern "C" int effdet_sepconv_fused(
     SepArgs a;
     a.nlevels = nlevels; a.n_in = n_in; a.fuse_mode = fuse_mode; a.fden = fuse_den;
     for (int i = 0; i < 3; ++i) a.fw[i] = (fuse_mode != 0 && i < n_in) ? fuse_w[i] : 0.f;
+    for (int i = 0; i < 3; ++i) a.fwn[i] = fuse_mode == 1 ? a.fw[i] / fuse_den : a.fw[i];
+    const size_t esz = dtype == 0 ? 4 : 2;
+    a.vec_ok = ((size_t)N * esz) % 4 == 0 && (ood_classes <= 0 || ((size_t)ood_classes * esz) % 4 == 0);
     a.pre_act = pre_act; a.post_act = post_act; a.dw_w = dw_w; a.pw_w = pw_w; a.scale = scale; a.shift = shift;
     a.F = F; a.N = N; a.ood_classes = ood_classes > 0 ? ood_classes : 0; a.num_anchors = num_anchors;
     a.ood_energy = ood_energy; a.ood_maxlogit = ood_maxlogit; a.ood_image_stride = ood_image_stride;
@@ -542,6 +513,7 @@ extern "C" int effdet_sepconv_fused(
         L.out = out_ptr[l]; L.out_image_stride = out_image_stride[l];
         L.ood_off = (ood_classes > 0) ? ood_level_off[l] : 0;
         if (!L.out) return EFFDET_EINVAL;
+        if (reinterpret_cast<uintptr_t>(L.out) % 16 || ((size_t)L.out_image_stride * esz) % 4) a.vec_ok = 0;
         for (int i = 0; i < n_in; ++i) {
             SepInput& I = L.in[i];
             I.ptr = in_ptr[l * n_in + i]; I.image_stride = in_image_stride[l * n_in + i];
@@ -558,9 +530,8 @@ extern "C" int effdet_sepconv_fused(
         }
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const bool ood = a.ood_classes > 0;
-    if (dtype == 0) return ood ? launch_sep<float, 8, 8, 64, true, 256>(st, a, B) : launch_sep<float, 8, 8, 64, false, 256>(st, a, B);
-    // bf16: 512 threads per 8x16 tile - the LDS footprint allows two workgroups per CU, so this doubles the waves
-    // that share the VALU-heavy staging / store passes
-    return ood ? launch_sep<bf16_t, 8, 16, 64, true, 512>(st, a, B) : launch_sep<bf16_t, 8, 16, 64, false, 512>(st, a, B);
+    if (dtype == 0) return dispatch_sep<float, 8, 8, 256>(st, a, B);
+    // bf16: 512 threads per 8x16 tile - the LDS footprint allows two workgroups per CU, so four waves per SIMD
+    // share the VALU-heavy halo and epilogue phases
+    return dispatch_sep<bf16_t, 8, 16, 512>(st, a, B);
 }
