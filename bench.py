@@ -217,14 +217,16 @@ def main():
         xc = x.contiguous()
         stem_ms, _ = timed(lambda: eng._stem_call(xc))
         cls_o, box_o = eng.head_views(eng.cls_all, eng.C), eng.head_views(eng.box_all, 4)
-        ms_topk, pp = timed(lambda: _post_process(cls_o, box_o, cfg.num_levels, args.classes, cfg.max_detection_points))
+        ms_topk, pp = timed(lambda: _post_process(cls_o, box_o, cfg.num_levels, args.classes, cfg.max_detection_points,
+                                                  anchor_max=eng.ood_max_logit))
         ct, bt, idx, cl = pp
         ms_det, _ = timed(lambda: batched_detections(ct.reshape(B, -1), bt, bench.anchors.boxes, idx, cl, None, None,
                                                      cfg.max_det_per_image, bool(args.soft_nms)))
     Hs = args.image // 2
     prof.append(('backbone.conv_stem%s' % ('+blocks.0.0.conv_dw' if eng._fuse_stem else ''), eng._stem_meta['kind'],
                  eng._stem_meta['bytes'], eng._stem_meta['flops'], stem_ms))
-    prof.append(('_post_process top-k', 'topk', 2 * B * eng.N * args.classes * es, 0, ms_topk))
+    # algorithmic bytes of the prefiltered select: the per-anchor maxima + the class rows of ~k anchors (twice)
+    prof.append(('_post_process top-k', 'topk', B * eng.N * 4 + 2 * B * cfg.max_detection_points * args.classes * es, 0, ms_topk))
     prof.append(('decode + NMS', 'nms', B * cfg.max_detection_points * 40, 0, ms_det))
     fam = {}
     for what, kind, nbytes, flops, ms in prof:

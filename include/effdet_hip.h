@@ -110,9 +110,11 @@ int effdet_sepconv_fused(void* stream, int dtype, int B, int nlevels, const int*
 
 /* _post_process (effdet/bench.py:12-56).  cls_all [B, n_anchors, C], box_all [B, n_anchors, 4] (dtype);
  * outputs out_cls [B,k], out_box [B,k,4] (dtype), out_indices / out_classes [B,k] int64.
- * Descending by logit, ties by lower flat index.  k <= 16384. */
-long long effdet_topk_workspace_bytes(int B);
-int effdet_topk_select(void* stream, int dtype, const void* cls_all, int B, long long n_anchors, int C,
+ * Descending by logit, ties by lower flat index.  k <= 16384.
+ * anchor_max: optional [B, n_anchors] fp32 maximum logit of every anchor (the class head's OOD max-logit
+ * output); lets the select skip the anchors that cannot reach the top k.  NULL: computed internally. */
+long long effdet_topk_workspace_bytes(int B, long long n_anchors);
+int effdet_topk_select(void* stream, int dtype, const void* cls_all, const float* anchor_max, int B, long long n_anchors, int C,
                        const void* box_all, int k, void* out_cls, void* out_box,
                        long long* out_indices, long long* out_classes, void* workspace, long long workspace_bytes);
 

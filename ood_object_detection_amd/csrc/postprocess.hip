@@ -17,8 +17,16 @@
 // ~index), 11 bits per pass.  After each pass the per-image state knows how many elements lie in and
 // above the bin that holds the k-th key; as soon as that candidate set fits the 16384-entry LDS sort
 // buffer the remaining passes return at once, the candidates are compacted and one workgroup per
-// image bitonic-sorts them.  For ordinary logit distributions this is one histogram read + one
-// compaction read of the logits.
+// image bitonic-sorts them.
+//
+// Anchor prefilter (used when there are many more anchors than k).  Let M_a be the largest logit of anchor
+// a and t the k-th largest M_a.  The k anchors with M_a >= t each own a pair (a, argmax) with logit >= t, so
+// the k-th largest PAIR is >= t, hence every pair of the exact top-k belongs to an anchor with M_a >= t.
+// Stage 1 radix-selects that anchor set on the [B, n_anchors] row maxima (22 key bits: a superset is fine),
+// stage 2 runs the exact select above on the C logits of those ~k anchors only, with the original flat
+// indices in the keys, so results (ties included) are identical to the dense select while the full logits
+// tensor is never scanned.  M_a comes for free from the class head (the OOD max-logit output); without it
+// one row-max pass over the logits computes it.
 #include "common.h"
 
 namespace {
@@ -77,15 +85,94 @@ DEV void for_each_element(const T* row, long long seg0, long long seg1, int tid,
     for (long long i = v0 + nvec * EPC + tid; i < seg1; i += nthreads) fn(to_f<T>(row[i]), (unsigned int)i);
 }
 
+// Element sources of the select: count(b) elements per image, each a (value, flat index) pair.
 template <typename T>
-__global__ __launch_bounds__(256) void topk_hist_kernel(const T* X, long long L, int pass,
-                                                        TopkState* state, unsigned int* hist) {
+struct DenseSrc {                      // every logit of the image
+    const T* X; long long L;
+    DEV long long count(int) const { return L; }
+    template <typename Fn> DEV void for_each(int b, long long seg0, long long seg1, int tid, int nth, Fn fn) const {
+        for_each_element<T>(X + (long long)b * L, seg0, seg1, tid, nth, fn);
+    }
+};
+template <bool ROUND_BF16>
+struct RowMaxSrc {                     // per-anchor maxima (fp32), rounded like the stored logits
+    const float* M; long long n_anchors;
+    DEV long long count(int) const { return n_anchors; }
+    DEV static float val(float f) { return ROUND_BF16 ? (float)(bf16_t)f : f; }
+    template <typename Fn> DEV void for_each(int b, long long seg0, long long seg1, int tid, int nth, Fn fn) const {
+        const float* row = M + (long long)b * n_anchors;
+        for (long long i0 = seg0; i0 < seg1; i0 += 4LL * nth) {      // 4 loads in flight per thread
+            float x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const long long i = i0 + tid + (long long)u * nth; x[u] = i < seg1 ? row[i] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const long long i = i0 + tid + (long long)u * nth; if (i < seg1) fn(val(x[u]), (unsigned int)i); }
+        }
+    }
+};
+template <typename T>
+struct PairSrc {                       // the C logits of every selected anchor
+    const T* X; long long L; const int* asel; const TopkState* st1; long long n_anchors; int C;
+    DEV long long count(int b) const {
+        long long n = st1[b].cand_count; if (n > n_anchors) n = n_anchors;
+        return n * C;
+    }
+    template <typename Fn> DEV void for_each(int b, long long seg0, long long seg1, int tid, int nth, Fn fn) const {
+        // Row-oriented: a wave walks whole anchor rows (the row's first element decides which segment owns it),
+        // 4 rows at a time so that the anchor-index loads and then all row loads are in flight together.
+        const T* img = X + (long long)b * L;
+        const int* al = asel + (long long)b * n_anchors;
+        const long long rb = (seg0 + C - 1) / C, re = (seg1 + C - 1) / C;
+        const int lane = tid & 63, wave = tid >> 6, nw = nth >> 6;
+        constexpr int RB = 4, CL = 2;                         // rows per batch; 64-lane column strips (C <= 128 fast path)
+        for (long long r0 = rb + wave * RB; r0 < re; r0 += (long long)nw * RB) {
+            unsigned int a[RB];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) a[u] = r0 + u < re ? (unsigned int)al[r0 + u] : 0xFFFFFFFFu;
+            T x[RB][CL];
+#pragma unroll
+            for (int u = 0; u < RB; ++u)
+#pragma unroll
+                for (int q = 0; q < CL; ++q) {
+                    const int c = lane + 64 * q;
+                    if (a[u] != 0xFFFFFFFFu && c < C) x[u][q] = img[(long long)a[u] * C + c];
+                }
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                if (a[u] == 0xFFFFFFFFu) continue;            // uniform per wave
+#pragma unroll
+                for (int q = 0; q < CL; ++q) {
+                    const int c = lane + 64 * q;
+                    if (c < C) fn(to_f<T>(x[u][q]), a[u] * (unsigned int)C + (unsigned int)c);
+                }
+                for (int c = lane + 64 * CL; c < C; c += 64)   // wider rows: the rest, unbatched
+                    fn(to_f<T>(img[(long long)a[u] * C + c]), a[u] * (unsigned int)C + (unsigned int)c);
+            }
+        }
+    }
+};
+
+// Append slot for the lanes of a wave whose `pred` holds: one atomic per wave instead of one per element
+DEV unsigned int wave_append(unsigned int* counter, bool pred) {
+    const unsigned long long m = __ballot(pred);
+    if (m == 0ull) return 0u;                                 // uniform: nothing to append in this wave
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned int base = 0;
+    if (pred && lane == leader) base = atomicAdd(counter, (unsigned int)__popcll(m));
+    base = __shfl(base, leader < 0 ? 0 : leader, 64);
+    return base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+template <typename Src>
+__global__ __launch_bounds__(256) void topk_hist_kernel(Src src, int pass, TopkState* state, unsigned int* hist) {
     const int b = blockIdx.y;
     const TopkState st = state[b];
     if (st.done) return;
     __shared__ unsigned int h[HIST_BINS];
     for (int i = threadIdx.x; i < HIST_BINS; i += 256) h[i] = 0;
     __syncthreads();
+    const long long L = src.count(b);
     const long long per = (L + gridDim.x - 1) / gridDim.x;
     const long long seg0 = per * blockIdx.x;
     long long seg1 = seg0 + per; if (seg1 > L) seg1 = L;
@@ -97,7 +184,7 @@ __global__ __launch_bounds__(256) void topk_hist_kernel(const T* X, long long L,
         // logits cluster in a handful of bins: run-length aggregate per thread so that identical consecutive
         // bins cost one LDS atomic instead of one per element (same-address LDS atomics serialise)
         unsigned int last_bin = 0xFFFFFFFFu, run = 0;
-        for_each_element<T>(X + (long long)b * L, seg0, seg1, threadIdx.x, 256, [&](float f, unsigned int idx) {
+        src.for_each(b, seg0, seg1, threadIdx.x, 256, [&](float f, unsigned int idx) {
             const unsigned long long key = comp_key(f, idx);
             if (pass == 0 || (key >> pshift) == prefix) {
                 const unsigned int bin = (unsigned int)(key >> shift) & mask;
@@ -112,7 +199,7 @@ __global__ __launch_bounds__(256) void topk_hist_kernel(const T* X, long long L,
     for (int i = threadIdx.x; i < HIST_BINS; i += 256) if (h[i]) atomicAdd(&gh[i], h[i]);
 }
 
-__global__ __launch_bounds__(256) void topk_find_kernel(int pass, int k, TopkState* state, unsigned int* hist) {
+__global__ __launch_bounds__(256) void topk_find_kernel(int pass, int last_pass, int k, unsigned int cap, TopkState* state, unsigned int* hist) {
     const int b = blockIdx.x, tid = threadIdx.x;
     TopkState st = state[b];
     if (st.done) return;
@@ -123,15 +210,20 @@ __global__ __launch_bounds__(256) void topk_find_kernel(int pass, int k, TopkSta
     unsigned int loc[8], s = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { loc[e] = gh[tid * 8 + e]; s += loc[e]; gh[tid * 8 + e] = 0; }
-    part[tid] = s;
+    // exclusive suffix sums over the 256 per-thread totals (Hillis-Steele, 8 steps)
+    unsigned int incl = s;
+    part[tid] = incl;
     __syncthreads();
-    if (tid == 0) {                      // 256-entry suffix scan, serial: trivial work
-        unsigned int run = 0;
-        for (int t = 255; t >= 0; --t) { const unsigned int v = part[t]; part[t] = run; run += v; }
+#pragma unroll
+    for (int off = 1; off < 256; off <<= 1) {
+        const unsigned int add = tid + off < 256 ? part[tid + off] : 0u;
+        __syncthreads();
+        incl += add;
+        part[tid] = incl;
+        __syncthreads();
     }
-    __syncthreads();
     const unsigned int need = (unsigned int)k - st.c_hi;
-    unsigned int above = part[tid];      // elements in bins owned by higher threads
+    unsigned int above = incl - s;       // elements in bins owned by higher threads
     if (above < need && above + s >= need) {
         for (int e = 7; e >= 0; --e) {
             if (above + loc[e] >= need) { sel[0] = tid * 8 + e; sel[1] = above; sel[2] = loc[e]; break; }
@@ -145,30 +237,135 @@ __global__ __launch_bounds__(256) void topk_find_kernel(int pass, int k, TopkSta
         st.bits_done += bits;
         st.c_hi += sel[1];
         st.cand_total = st.c_hi + sel[2];
-        if (st.cand_total <= (unsigned int)TOPK_CAP || pass == NPASS - 1) st.done = 1;
+        if (st.cand_total <= cap || pass == last_pass) st.done = 1;
         state[b] = st;
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void topk_collect_kernel(const T* X, long long L, TopkState* state,
-                                                           unsigned long long* cand) {
-    const int b = blockIdx.y;
-    TopkState* sp = state + b;
-    const int pshift = 64 - sp->bits_done;
-    const unsigned long long prefix = sp->prefix;
+// Compaction: candidates are gathered in LDS and flushed with ONE global reservation per workgroup
+// (thousands of same-address global atomics per image would serialise at the L2).
+constexpr int COLLECT_BUF = 1024;
+
+template <typename Src, typename Item, typename Make>
+DEV void collect_common(const Src& src, const TopkState* thr, TopkState* sp, int b, Item* out, unsigned int out_cap, Make make) {
+    __shared__ Item buf[COLLECT_BUF];
+    __shared__ unsigned int cnt, base;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const int pshift = 64 - thr->bits_done;
+    const unsigned long long prefix = thr->prefix;
+    const long long L = src.count(b);
     const long long per = (L + gridDim.x - 1) / gridDim.x;
     const long long seg0 = per * blockIdx.x;
     long long seg1 = seg0 + per; if (seg1 > L) seg1 = L;
-    if (seg0 >= seg1) return;
-    unsigned long long* out = cand + (long long)b * TOPK_CAP;
-    for_each_element<T>(X + (long long)b * L, seg0, seg1, threadIdx.x, 256, [&](float f, unsigned int idx) {
-        const unsigned long long key = comp_key(f, idx);
-        if ((key >> pshift) >= prefix) {
-            const unsigned int pos = atomicAdd(&sp->cand_count, 1u);
-            if (pos < (unsigned int)TOPK_CAP) out[pos] = key;
+    if (seg0 < seg1) {
+        src.for_each(b, seg0, seg1, threadIdx.x, 256, [&](float f, unsigned int idx) {
+            const unsigned long long key = comp_key(f, idx);
+            const bool take = (key >> pshift) >= prefix;
+            const unsigned int pos = wave_append(&cnt, take);
+            if (take) {
+                if (pos < (unsigned int)COLLECT_BUF) buf[pos] = make(key, idx);
+                else {                                         // buffer full: straight to memory
+                    const unsigned int g = atomicAdd(&sp->cand_count, 1u);
+                    if (g < out_cap) out[g] = make(key, idx);
+                }
+            }
+        });
+    }
+    __syncthreads();
+    const unsigned int n = cnt < (unsigned int)COLLECT_BUF ? cnt : (unsigned int)COLLECT_BUF;
+    if (threadIdx.x == 0 && n) base = atomicAdd(&sp->cand_count, n);
+    __syncthreads();
+    for (unsigned int i = threadIdx.x; i < n; i += 256) if (base + i < out_cap) out[base + i] = buf[i];
+}
+
+template <typename Src>
+__global__ __launch_bounds__(256) void topk_collect_kernel(Src src, const TopkState* thr, TopkState* state, unsigned long long* cand) {
+    const int b = blockIdx.y;
+    collect_common(src, thr + b, state + b, b, cand + (long long)b * TOPK_CAP, (unsigned int)TOPK_CAP,
+                   [](unsigned long long key, unsigned int) { return key; });
+}
+
+// Stage 1 compaction: indices of the anchors whose row maximum reaches the selected prefix (any order)
+template <typename Src>
+__global__ __launch_bounds__(256) void anchor_collect_kernel(Src src, TopkState* state, int* asel) {
+    const int b = blockIdx.y;
+    const long long L = src.count(b);
+    collect_common(src, state + b, state + b, b, asel + (long long)b * L, (unsigned int)L,
+                   [](unsigned long long, unsigned int idx) { return (int)idx; });
+}
+
+// After the fast stage-2 compaction (every pair whose key reaches the stage-1 threshold): when the candidates
+// fit the sort buffer they already contain the exact top k.  Otherwise (massive ties) this workgroup redoes
+// the image with the full multi-pass radix select over the gathered rows - slow, but only degenerate inputs
+// get here.
+template <typename T>
+__global__ __launch_bounds__(1024) void pair_finish_kernel(PairSrc<T> src, int k, TopkState* state, unsigned long long* cand) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    TopkState* sp = state + b;
+    __shared__ unsigned int h[HIST_BINS];
+    __shared__ unsigned long long s_prefix;
+    __shared__ unsigned int s_chi, s_total, s_cnt;
+    __shared__ int s_bits, s_done;
+    if (sp->cand_count <= (unsigned int)TOPK_CAP) {                 // uniform across the workgroup
+        if (tid == 0) { sp->cand_total = sp->cand_count; sp->done = 1; }
+        return;
+    }
+    if (tid == 0) { s_prefix = 0; s_chi = 0; s_bits = 0; s_done = 0; s_cnt = 0; }
+    __syncthreads();
+    const long long L = src.count(b);
+    for (int pass = 0; pass < NPASS; ++pass) {
+        for (int i = tid; i < HIST_BINS; i += 1024) h[i] = 0;
+        __syncthreads();
+        const int shift = kPassShift[pass];
+        const unsigned int mask = (1u << kPassBits[pass]) - 1u;
+        const int pshift = 64 - s_bits;
+        const unsigned long long prefix = s_prefix;
+        src.for_each(b, 0, L, tid, 1024, [&](float f, unsigned int idx) {
+            const unsigned long long key = comp_key(f, idx);
+            if (pass == 0 || (key >> pshift) == prefix) atomicAdd(&h[(unsigned int)(key >> shift) & mask], 1u);
+        });
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned int need = (unsigned int)k - s_chi;
+            unsigned int above = 0;
+            int bin = (int)mask;
+            for (; bin > 0; --bin) { if (above + h[bin] >= need) break; above += h[bin]; }
+            s_prefix = (s_prefix << kPassBits[pass]) | (unsigned long long)bin;
+            s_bits += kPassBits[pass];
+            s_chi += above;
+            s_total = s_chi + h[bin];
+            if (s_total <= (unsigned int)TOPK_CAP || pass == NPASS - 1) s_done = 1;
         }
-    });
+        __syncthreads();
+        if (s_done) break;
+    }
+    {
+        const int pshift = 64 - s_bits;
+        const unsigned long long prefix = s_prefix;
+        unsigned long long* out = cand + (long long)b * TOPK_CAP;
+        src.for_each(b, 0, L, tid, 1024, [&](float f, unsigned int idx) {
+            const unsigned long long key = comp_key(f, idx);
+            if ((key >> pshift) >= prefix) {
+                const unsigned int pos = atomicAdd(&s_cnt, 1u);
+                if (pos < (unsigned int)TOPK_CAP) out[pos] = key;
+            }
+        });
+    }
+    __syncthreads();
+    if (tid == 0) { sp->cand_total = s_total; sp->done = 1; }
+}
+
+// Row maxima of the logits, for callers that do not have them: one wave per anchor row
+template <typename T>
+__global__ __launch_bounds__(256) void row_max_kernel(const T* X, long long rows, int C, float* M) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float m = -INFINITY;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, to_f<T>(X[r * C + c]));
+    m = wave_reduce_max(m);
+    if (lane == 0) M[r] = m;
 }
 
 template <typename T>
@@ -176,28 +373,62 @@ __global__ __launch_bounds__(1024) void topk_sort_kernel(const TopkState* state,
                                                          int k, int C, const T* cls_all, const T* box_all,
                                                          long long L, long long n_anchors,
                                                          T* out_cls, T* out_box, long long* out_idx, long long* out_cls_id) {
+    // Merge sort, descending, TOPK_CAP slots (unused ones hold key 0, below every real key): every thread sorts
+    // its 16 keys in registers, then ten merge rounds double the run length.  In a round a thread owns 16
+    // consecutive output slots: a merge-path binary search finds where they start in the two input runs, a
+    // 16-step sequential merge reads the heads from LDS, and the outputs are written back in place after
+    // the barrier.  O(n log n) compare work instead of the bitonic network's O(n log^2 n).
     extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
     const int b = blockIdx.x, tid = threadIdx.x;
     unsigned int n = state[b].cand_total;
     if (n > (unsigned int)TOPK_CAP) n = TOPK_CAP;
-    int P = 1024;
-    while (P < (int)n) P <<= 1;
+    constexpr int E = TOPK_CAP / 1024;                       // 16 keys per thread
+    auto slot = [](int i) { return i + (i >> 4); };          // one pad slot per 16: the per-thread 128-byte rows spread over the banks
     const unsigned long long* src = cand + (long long)b * TOPK_CAP;
-    for (int i = tid; i < P; i += 1024) keys[i] = i < (int)n ? src[i] : 0ull;
+    unsigned long long v[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) { const int i = tid * E + m; v[m] = i < (int)n ? src[i] : 0ull; }
+#pragma unroll
+    for (int size = 2; size <= E; size <<= 1)
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1)
+#pragma unroll
+            for (int m = 0; m < E; ++m)
+                if ((m & stride) == 0) {
+                    const bool desc = (m & size) == 0;
+                    const unsigned long long x = v[m], y = v[m | stride];
+                    const bool sw = (x < y) == desc;
+                    v[m] = sw ? y : x; v[m | stride] = sw ? x : y;
+                }
+#pragma unroll
+    for (int m = 0; m < E; ++m) keys[slot(tid * E + m)] = v[m];
     __syncthreads();
-    for (int size = 2; size <= P; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < (P >> 1); i += 1024) {
-                const int pos = 2 * i - (i & (stride - 1));
-                const unsigned long long a = keys[pos], c = keys[pos + stride];
-                const bool desc = (pos & size) == 0;          // final order: descending
-                if ((a < c) == desc) { keys[pos] = c; keys[pos + stride] = a; }
-            }
-            __syncthreads();
+    for (int run = E; run < TOPK_CAP; run <<= 1) {
+        const int o0 = tid * E;                               // first output slot of this thread
+        const int pair0 = o0 & ~(2 * run - 1);                // start of the X run; Y follows at pair0 + run
+        const int d = o0 - pair0;                             // outputs of this pair that precede ours
+        const int X0 = pair0, Y0 = pair0 + run;
+        int lo = d > run ? d - run : 0, hi = d < run ? d : run;
+        while (lo < hi) {                                     // xi = how many of the first d outputs come from X
+            const int mid = (lo + hi) >> 1;
+            if (keys[slot(X0 + mid)] > keys[slot(Y0 + d - 1 - mid)]) lo = mid + 1; else hi = mid;
         }
+        int xi = lo, yi = d - lo;
+        unsigned long long hx = xi < run ? keys[slot(X0 + xi)] : 0ull, hy = yi < run ? keys[slot(Y0 + yi)] : 0ull;
+#pragma unroll
+        for (int o = 0; o < E; ++o) {
+            const bool takex = yi >= run || (xi < run && hx > hy);
+            v[o] = takex ? hx : hy;
+            if (takex) { ++xi; hx = xi < run ? keys[slot(X0 + xi)] : 0ull; }
+            else       { ++yi; hy = yi < run ? keys[slot(Y0 + yi)] : 0ull; }
+        }
+        __syncthreads();                                      // every thread has read its inputs
+#pragma unroll
+        for (int o = 0; o < E; ++o) keys[slot(o0 + o)] = v[o];
+        __syncthreads();
     }
     for (int i = tid; i < k; i += 1024) {
-        const unsigned long long key = keys[i];
+        const unsigned long long key = keys[slot(i)];
         const unsigned int flat = 0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull);
         const long long o = (long long)b * k + i;
         const long long anchor = flat / (unsigned int)C;
@@ -475,6 +706,15 @@ __global__ void gather_ood_kernel(const int* keep_src, const long long* indices,
     out_energy[i] = e; out_maxlogit[i] = m;
 }
 
+// Sources that walk scalar elements (row maxima, gathered anchor rows) are latency bound per thread: give
+// every thread only a few elements
+inline int sparse_segments(long long L) {
+    long long s = (L + 4095) / 4096;                  // 16 elements per thread
+    if (s < 1) s = 1;
+    if (s > 65535) s = 65535;
+    return (int)s;
+}
+
 inline int topk_segments(int B, long long L) {
     long long s = 2048 / (B > 0 ? B : 1);
     const long long by_work = (L + 16383) / 16384;
@@ -485,13 +725,73 @@ inline int topk_segments(int B, long long L) {
 
 }  // namespace
 
-extern "C" long long effdet_topk_workspace_bytes(int B) {
-    if (B <= 0) return EFFDET_EINVAL;
-    return (long long)B * (sizeof(TopkState) + HIST_BINS * 4 + (long long)TOPK_CAP * 8);
+extern "C" long long effdet_topk_workspace_bytes(int B, long long n_anchors) {
+    if (B <= 0 || n_anchors <= 0) return EFFDET_EINVAL;
+    // 2 states | histogram | candidate keys | selected anchors | row maxima (when the caller has none)
+    return (long long)B * (2 * sizeof(TopkState) + HIST_BINS * 4 + (long long)TOPK_CAP * 8 + n_anchors * 8);
 }
 
-extern "C" int effdet_topk_select(void* stream, int dtype, const void* cls_all, int B, long long n_anchors, int C,
-                                  const void* box_all, int k,
+namespace {
+
+template <typename T>
+int topk_run(hipStream_t st, const T* cls_all, const float* anchor_max, int B, long long n_anchors, int C,
+             const T* box_all, int k, T* out_cls, T* out_box, long long* out_indices, long long* out_classes, char* ws) {
+    const long long L = n_anchors * (long long)C;
+    TopkState* state1 = reinterpret_cast<TopkState*>(ws);
+    TopkState* state2 = state1 + B;
+    char* q = ws + (size_t)B * 2 * sizeof(TopkState);
+    unsigned int* hist = reinterpret_cast<unsigned int*>(q);               q += (size_t)B * HIST_BINS * 4;
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(q);   q += (size_t)B * TOPK_CAP * 8;
+    int* asel = reinterpret_cast<int*>(q);                                 q += (size_t)B * n_anchors * 4;
+    float* rowmax = reinterpret_cast<float*>(q);
+    if (hipMemsetAsync(ws, 0, (size_t)B * (2 * sizeof(TopkState) + HIST_BINS * 4), st) != hipSuccess) return EFFDET_ELAUNCH;
+    // the sort buffer needs cand_total <= TOPK_CAP; stopping the radix passes at the next power of two >= k
+    // keeps the bitonic network as small as the request allows
+    unsigned int cap = 1024; while (cap < (unsigned int)k) cap <<= 1;
+    const bool prefilter = n_anchors >= 4LL * k;
+    if (prefilter) {
+        if (!anchor_max) {
+            hipLaunchKernelGGL(row_max_kernel<T>, dim3((unsigned int)(((long long)B * n_anchors + 3) / 4)), dim3(256), 0, st,
+                               cls_all, (long long)B * n_anchors, C, rowmax);
+            anchor_max = rowmax;
+        }
+        RowMaxSrc<sizeof(T) == 2> src1{anchor_max, n_anchors};
+        const int S1 = sparse_segments(n_anchors);
+        for (int pass = 0; pass < 2; ++pass) {
+            hipLaunchKernelGGL(topk_hist_kernel<decltype(src1)>, dim3(S1, B), dim3(256), 0, st, src1, pass, state1, hist);
+            hipLaunchKernelGGL(topk_find_kernel, dim3(B), dim3(256), 0, st, pass, 1, k, (unsigned int)k + 1024u, state1, hist);
+        }
+        hipLaunchKernelGGL(anchor_collect_kernel<decltype(src1)>, dim3(S1, B), dim3(256), 0, st, src1, state1, asel);
+        // stage 2, fast path: every pair of the selected anchors that reaches the stage-1 threshold
+        PairSrc<T> src2{cls_all, L, asel, state1, n_anchors, C};
+        const int S2 = sparse_segments(2LL * k * C);
+        hipLaunchKernelGGL(topk_collect_kernel<PairSrc<T>>, dim3(S2, B), dim3(256), 0, st, src2, (const TopkState*)state1, state2, cand);
+        hipLaunchKernelGGL(pair_finish_kernel<T>, dim3(B), dim3(1024), 0, st, src2, k, state2, cand);
+    } else {
+        DenseSrc<T> src{cls_all, L};
+        const int S = topk_segments(B, L);
+        for (int pass = 0; pass < NPASS; ++pass) {
+            hipLaunchKernelGGL(topk_hist_kernel<DenseSrc<T>>, dim3(S, B), dim3(256), 0, st, src, pass, state2, hist);
+            hipLaunchKernelGGL(topk_find_kernel, dim3(B), dim3(256), 0, st, pass, NPASS - 1, k, cap, state2, hist);
+        }
+        hipLaunchKernelGGL(topk_collect_kernel<DenseSrc<T>>, dim3(S, B), dim3(256), 0, st, src, (const TopkState*)state2, state2, cand);
+    }
+    const size_t sort_lds = (size_t)(TOPK_CAP + TOPK_CAP / 16) * 8;
+    static bool attr_done = false;               // one per T
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(topk_sort_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds) != hipSuccess)
+            return EFFDET_ELAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(topk_sort_kernel<T>, dim3(B), dim3(1024), sort_lds, st, state2, cand, k, C, cls_all, box_all, L, n_anchors,
+                       out_cls, out_box, out_indices, out_classes);
+    return effdet_check_launch();
+}
+
+}  // namespace
+
+extern "C" int effdet_topk_select(void* stream, int dtype, const void* cls_all, const float* anchor_max, int B,
+                                  long long n_anchors, int C, const void* box_all, int k,
                                   void* out_cls, void* out_box, long long* out_indices, long long* out_classes,
                                   void* workspace, long long workspace_bytes) {
     EFFDET_ENTER();
@@ -499,36 +799,14 @@ extern "C" int effdet_topk_select(void* stream, int dtype, const void* cls_all, 
     if (!cls_all || !out_cls || !out_indices || !out_classes || !workspace || B <= 0 || C <= 0 || n_anchors <= 0) return EFFDET_EINVAL;
     if (k <= 0 || k > TOPK_CAP || k > L || L > 0x7fffffffLL || (dtype & ~1)) return EFFDET_EINVAL;
     if (box_all && !out_box) return EFFDET_EINVAL;
-    if (workspace_bytes < effdet_topk_workspace_bytes(B)) return EFFDET_EINVAL;
+    if (workspace_bytes < effdet_topk_workspace_bytes(B, n_anchors)) return EFFDET_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     char* ws = reinterpret_cast<char*>(workspace);
-    TopkState* state = reinterpret_cast<TopkState*>(ws);
-    unsigned int* hist = reinterpret_cast<unsigned int*>(ws + (size_t)B * sizeof(TopkState));
-    unsigned long long* cand = reinterpret_cast<unsigned long long*>(ws + (size_t)B * (sizeof(TopkState) + HIST_BINS * 4));
-    if (hipMemsetAsync(ws, 0, (size_t)B * (sizeof(TopkState) + HIST_BINS * 4), st) != hipSuccess) return EFFDET_ELAUNCH;
-    const int S = topk_segments(B, L);
-    for (int pass = 0; pass < NPASS; ++pass) {
-        if (dtype == 0) hipLaunchKernelGGL(topk_hist_kernel<float>, dim3(S, B), dim3(256), 0, st, (const float*)cls_all, L, pass, state, hist);
-        else hipLaunchKernelGGL(topk_hist_kernel<bf16_t>, dim3(S, B), dim3(256), 0, st, (const bf16_t*)cls_all, L, pass, state, hist);
-        hipLaunchKernelGGL(topk_find_kernel, dim3(B), dim3(256), 0, st, pass, k, state, hist);
-    }
-    const size_t sort_lds = (size_t)TOPK_CAP * 8;
-    if (dtype == 0) {
-        static bool attr_done = false;
-        if (!attr_done) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(topk_sort_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds) != hipSuccess) return EFFDET_ELAUNCH; attr_done = true; }
-        hipLaunchKernelGGL(topk_collect_kernel<float>, dim3(S, B), dim3(256), 0, st, (const float*)cls_all, L, state, cand);
-        hipLaunchKernelGGL(topk_sort_kernel<float>, dim3(B), dim3(1024), sort_lds, st, state, cand, k, C,
-                           (const float*)cls_all, (const float*)box_all, L, n_anchors,
-                           (float*)out_cls, (float*)out_box, out_indices, out_classes);
-    } else {
-        static bool attr_done = false;
-        if (!attr_done) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(topk_sort_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds) != hipSuccess) return EFFDET_ELAUNCH; attr_done = true; }
-        hipLaunchKernelGGL(topk_collect_kernel<bf16_t>, dim3(S, B), dim3(256), 0, st, (const bf16_t*)cls_all, L, state, cand);
-        hipLaunchKernelGGL(topk_sort_kernel<bf16_t>, dim3(B), dim3(1024), sort_lds, st, state, cand, k, C,
-                           (const bf16_t*)cls_all, (const bf16_t*)box_all, L, n_anchors,
-                           (bf16_t*)out_cls, (bf16_t*)out_box, out_indices, out_classes);
-    }
-    return effdet_check_launch();
+    if (dtype == 0)
+        return topk_run<float>(st, (const float*)cls_all, anchor_max, B, n_anchors, C, (const float*)box_all, k,
+                               (float*)out_cls, (float*)out_box, out_indices, out_classes, ws);
+    return topk_run<bf16_t>(st, (const bf16_t*)cls_all, anchor_max, B, n_anchors, C, (const bf16_t*)box_all, k,
+                            (bf16_t*)out_cls, (bf16_t*)out_box, out_indices, out_classes, ws);
 }
 
 extern "C" int effdet_decode_threshold(void* stream, int dtype, const void* cls_topk, const void* box_topk,

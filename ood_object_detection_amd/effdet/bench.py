@@ -16,8 +16,12 @@ from .anchors import Anchors, batched_detections
 
 
 def _post_process(cls_outputs: List[torch.Tensor], box_outputs: List[torch.Tensor], num_levels: int,
-                  num_classes: int, max_detection_points: int = 5000):
+                  num_classes: int, max_detection_points: int = 5000, anchor_max: Optional[torch.Tensor] = None):
     """Top-k over all class logits (effdet/bench.py:12-56); ties go to the lower flat index.
+
+    `anchor_max` (extension): the [B, N] float32 per-anchor maximum logit the class head already produced
+    (`model.ood_max_logit`); the select then only scans the anchors that can reach the top k.  Results are
+    identical with and without it.
 
     Accepts the per-level [B, A*C, H, W] / [B, A*4, H, W] lists.  When they are the engine's own
     NHWC-backed views the concatenation is free; other tensors are packed with one copy.
@@ -36,10 +40,15 @@ def _post_process(cls_outputs: List[torch.Tensor], box_outputs: List[torch.Tenso
     out_box = torch.empty(B, k, 4, dtype=cls_all.dtype, device=c0.device)
     idx = torch.empty(B, k, dtype=torch.int64, device=c0.device)
     cls_id = torch.empty(B, k, dtype=torch.int64, device=c0.device)
-    ws_bytes = lib.effdet_topk_workspace_bytes(B)
+    if anchor_max is not None:
+        if anchor_max.dtype != torch.float32 or tuple(anchor_max.shape) != (B, n_anchors) or anchor_max.device != c0.device:
+            raise RuntimeError('anchor_max must be a float32 [B, N] tensor on the logits\' device')
+        anchor_max = anchor_max.contiguous()
+    ws_bytes = lib.effdet_topk_workspace_bytes(B, n_anchors)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=c0.device)
     st = torch.cuda.current_stream(c0.device).cuda_stream
-    _lib.check(lib.effdet_topk_select(st, dt, cls_all.data_ptr(), B, n_anchors, num_classes, box_all.data_ptr(), k,
+    _lib.check(lib.effdet_topk_select(st, dt, cls_all.data_ptr(), anchor_max.data_ptr() if anchor_max is not None else None,
+                                      B, n_anchors, num_classes, box_all.data_ptr(), k,
                                       out_cls.data_ptr(), out_box.data_ptr(), idx.data_ptr(), cls_id.data_ptr(),
                                       ws.data_ptr(), ws_bytes), 'effdet_topk_select')
     return out_cls, out_box, idx, cls_id
@@ -81,7 +90,7 @@ class DetBenchPredict(nn.Module):
         class_out, box_out = self.model(x)
         cls_topk, box_topk, indices, classes = _post_process(
             class_out, box_out, num_levels=self.num_levels, num_classes=self.num_classes,
-            max_detection_points=self.max_detection_points)
+            max_detection_points=self.max_detection_points, anchor_max=self.model.ood_max_logit)
         if img_info is None:
             img_scale, img_size = None, None
         else:

@@ -135,4 +135,5 @@ def test_c_abi_exports_every_declared_symbol():
     # pure-host helpers are callable without a GPU
     assert lib.effdet_dwconv_blocks_per_image(80, 80, 240) > 0
     lib.effdet_topk_workspace_bytes.restype = ctypes.c_longlong
-    assert lib.effdet_topk_workspace_bytes(4) > 4 * 16384 * 8
+    lib.effdet_topk_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_longlong]
+    assert lib.effdet_topk_workspace_bytes(4, 1000) > 4 * (16384 * 8 + 1000 * 8)

@@ -304,9 +304,14 @@ def _check_topk(cls, box, C, k, dtype=torch.float32):
     cls_q = [c.to(dtype) for c in cls]
     box_q = [b.to(dtype) for b in box]
     rc, rb, ri, rcl = op.post_process([c.float() for c in cls_q], [b.float() for b in box_q], len(cls), C, k)
-    gc, gb, gi, gcl = _post_process([c.to(DEV) for c in cls_q], [b.to(DEV) for b in box_q], len(cls), C, k)
-    assert torch.equal(gi.cpu(), ri) and torch.equal(gcl.cpu(), rcl)
-    assert torch.equal(gc.float().cpu(), rc) and torch.equal(gb.float().cpu(), rb)
+    B = cls[0].shape[0]
+    # per-anchor maxima of the UNROUNDED logits, as the class head emits them: rounding is monotonic, so the
+    # select must round them itself to agree with the stored logits
+    amax = torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1, C) for c in cls], 1).float().max(dim=2).values
+    for am in (None, amax.to(DEV)):
+        gc, gb, gi, gcl = _post_process([c.to(DEV) for c in cls_q], [b.to(DEV) for b in box_q], len(cls), C, k, anchor_max=am)
+        assert torch.equal(gi.cpu(), ri) and torch.equal(gcl.cpu(), rcl)
+        assert torch.equal(gc.float().cpu(), rc) and torch.equal(gb.float().cpu(), rb)
 
 
 def test_topk_golden(golden):
@@ -324,6 +329,7 @@ def test_topk_golden(golden):
 def test_topk_vs_oracle_with_ties(dtype):
     cls, box = _pp_case(7, 3, 11, [16, 8, 4, 2, 1])
     _check_topk(cls, box, 11, 1000, dtype)          # bf16: thousands of exact ties -> index order must hold
+    _check_topk(cls, box, 11, 500, dtype)           # 3069 anchors >= 4k: the anchor-prefilter path
 
 
 def test_topk_degenerate_all_equal_and_large():
@@ -333,9 +339,11 @@ def test_topk_degenerate_all_equal_and_large():
     cls = [torch.full((B, A * C, s, s), -4.59512) for s in sizes]
     box = [torch.zeros(B, A * 4, s, s) for s in sizes]
     _check_topk(cls, box, C, 5000)
+    _check_topk(cls, box, C, 1000)                  # prefilter with every anchor tied: the anchor set is all of them
     # heavy-tie block bigger than the LDS sort buffer (forces a second radix pass) + k == CAP boundary
     cls2, box2 = _pp_case(9, 1, 90, [40, 20, 10, 5, 3], cs=0.01, shift=4.6)
     _check_topk(cls2, box2, 90, 5000)
+    _check_topk(cls2, box2, 90, 4000)               # same through the anchor prefilter (19206 anchors >= 4k)
 
 
 @pytest.mark.parametrize('soft', [False, True])
