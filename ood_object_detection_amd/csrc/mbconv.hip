@@ -28,6 +28,8 @@ struct MbArgs {
     int TH, TW, IH, IW, HP, HPpad, tiles_x, tiles_y;
     int arow;                                   // LDS pitch of X / W1 rows (bytes)
     int e_bytes;                                // size of the expanded tile (also hosts the pool scratch)
+    FastDiv fd_ppr, fd_iw, fd_tx;               // / (16-byte pieces per input row), / IW, / tiles_x
+    int tw_shift;                               // TW = 1 << tw_shift
     int dbg;                                    // ablation switch (EFFDET_DEBUG_SKIP), 0 in production
 };
 
@@ -69,7 +71,8 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
     const int frow = lane & 15, fpiece = lane >> 4;
     const int b = blockIdx.y;
     const int tile = blockIdx.x;
-    const int oy0 = (tile / p.tiles_x) * p.TH, ox0 = (tile % p.tiles_x) * p.TW;
+    const int tile_y = fdiv(tile, p.fd_tx);
+    const int oy0 = tile_y * p.TH, ox0 = (tile - tile_y * p.tiles_x) * p.TW;
     const int iy0 = oy0 * S - p.pad_t, ix0 = ox0 * S - p.pad_l;
     const int Cin = p.Cin, mid = p.mid;
     const int cbytes = Cin * (int)sizeof(T);
@@ -98,10 +101,11 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
             const int i = i0 + SM_T * u;
             v[u] = u32x4{0u, 0u, 0u, 0u};
             if (i < p.HPpad * ppr) {
-                const int hp = i / ppr, piece = i % ppr;
+                const int hp = fdiv(i, p.fd_ppr), piece = i - hp * ppr;
                 bool inside = false;
                 if (hp < p.HP) {
-                    const int y = iy0 + hp / p.IW, x = ix0 + hp % p.IW;
+                    const int hy = fdiv(hp, p.fd_iw);
+                    const int y = iy0 + hy, x = ix0 + hp - hy * p.IW;
                     inside = y >= 0 && y < p.H && x >= 0 && x < p.W;
                     if (inside)
                         v[u] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(X + ((long long)y * p.W + x) * Cin) + piece * 16);
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int i = i0 + SM_T * u;
-            if (i < p.HPpad * ppr) *reinterpret_cast<u32x4*>(At + (i / ppr) * arow + (i % ppr) * 16) = v[u];
+            if (i < p.HPpad * ppr) { const int hp = fdiv(i, p.fd_ppr); *reinterpret_cast<u32x4*>(At + hp * arow + (i - hp * ppr) * 16) = v[u]; }
         }
     }
 
@@ -131,8 +135,10 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
             for (int q = 0; q < WPC; ++q) {
                 const int i = tid + SM_T * q;
                 wpre[q] = u32x4{0u, 0u, 0u, 0u};
-                if (i < SM_MC * ppr)
-                    wpre[q] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.W1) + (long long)(c0n + i / ppr) * cbytes + (i % ppr) * 16);
+                if (i < SM_MC * ppr) {
+                    const int r = fdiv(i, p.fd_ppr);
+                    wpre[q] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.W1) + (c0n + r) * cbytes + (i - r * ppr) * 16);
+                }
             }
         }
         // taps: one base pointer + a 32-bit offset per lane; the four BN vectors: one predicated load each
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
 #pragma unroll
             for (int q = 0; q < WPC; ++q) {
                 const int i = tid + SM_T * q;
-                if (i < SM_MC * ppr) *reinterpret_cast<u32x4*>(Wc + (i / ppr) * arow + (i % ppr) * 16) = wpre[q];
+                if (i < SM_MC * ppr) { const int r = fdiv(i, p.fd_ppr); *reinterpret_cast<u32x4*>(Wc + r * arow + (i - r * ppr) * 16) = wpre[q]; }
             }
         } else {
             for (int i = tid; i < SM_MC * ppr; i += SM_T)
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
         const int cg = tid % SM_CG, pg0 = tid / SM_CG;
         if (pg0 < SM_PG && !(p.dbg & 2)) {
             for (int px = pg0; px < p.TH * p.TW; px += SM_PG) {
-                const int ty = px / p.TW, tx = px % p.TW;
+                const int ty = px >> p.tw_shift, tx = px & (p.TW - 1);
                 const int oy = oy0 + ty, ox = ox0 + tx;
                 if (oy >= p.Ho || ox >= p.Wo) continue;
                 F8 acc = f8_zero();
@@ -296,10 +302,13 @@ struct MbDeepArgs {
     int B, H, W, Cin, mid, Ho, Wo, pad_t, pad_l;
     int band_rows, nbands, nchunks, arow, e_rows_max;
     int dbg;
+    int we;                                      // bf16: columns of the zero-haloed expanded band
+    FastDiv fd_w, fd_wo;
 };
 
-template <typename T, int KS, int S, int PPT>
-__global__ __launch_bounds__(256) void mbconv_deep_kernel(MbDeepArgs p) {
+// NTH: 512 threads in bf16 (two workgroups per CU -> four waves per SIMD to cover LDS / MFMA latencies)
+template <typename T, int KS, int S, int PPT, int NTH>
+__global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void mbconv_deep_kernel(MbDeepArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fpiece = lane >> 4;
@@ -321,16 +330,25 @@ __global__ __launch_bounds__(256) void mbconv_deep_kernel(MbDeepArgs p) {
     float* red = reinterpret_cast<float*>(lds);
     const int wc_bytes = (MC * arow > 256 * 9 * 4) ? MC * arow : 256 * 9 * 4;
     constexpr int EROW = ERow<T>::value;
-    T* E = reinterpret_cast<T*>(lds + wc_bytes);               // [npx][EROW]
+    T* E = reinterpret_cast<T*>(lds + wc_bytes);               // fp32: [npx][EROW]; bf16: [rows][we][EROW], zero halo
+    // bf16 runs the depthwise taps on the matrix cores, which want branch-free operand addresses: the band is
+    // stored with its TF-SAME zero padding (rows above / below the image and the left / right columns)
+    constexpr bool MF = sizeof(T) == 2;
+    const int iy_top = oy_b * S - p.pad_t;                     // first (possibly virtual) input row of the band
+    if constexpr (MF) {
+        const int e_rows = (oy_e - 1 - oy_b) * S + KS;
+        const int n16 = e_rows * p.we * EROW * (int)sizeof(T) / 16;
+        for (int i = tid; i < n16; i += NTH) reinterpret_cast<u32x4*>(E)[i] = u32x4{0u, 0u, 0u, 0u};
+    }
 
     const int ppr = nkc * 4;
     {   // W1 slice -> LDS: all of a thread's pieces are loaded before the first LDS store (ppr <= 16 pieces per row)
         constexpr int WPT_MAX = 4;
-        for (int i0 = tid; i0 < MC * ppr; i0 += 256 * WPT_MAX) {
+        for (int i0 = tid; i0 < MC * ppr; i0 += NTH * WPT_MAX) {
             u32x4 v[WPT_MAX];
 #pragma unroll
             for (int u = 0; u < WPT_MAX; ++u) {
-                const int i = i0 + 256 * u;
+                const int i = i0 + NTH * u;
                 v[u] = u32x4{0u, 0u, 0u, 0u};
                 if (i < MC * ppr) {
                     const int row = i / ppr, piece = i % ppr;
@@ -340,7 +358,7 @@ __global__ __launch_bounds__(256) void mbconv_deep_kernel(MbDeepArgs p) {
             }
 #pragma unroll
             for (int u = 0; u < WPT_MAX; ++u) {
-                const int i = i0 + 256 * u;
+                const int i = i0 + NTH * u;
                 if (i < MC * ppr) *reinterpret_cast<u32x4*>(Wc + (i / ppr) * arow + (i % ppr) * 16) = v[u];
             }
         }
@@ -357,11 +375,11 @@ __global__ __launch_bounds__(256) void mbconv_deep_kernel(MbDeepArgs p) {
     }
     // depthwise constants of this channel slice: fetched now, parked in the W slot once the expand is done
     constexpr int NPAR = 2 + KS * KS;                         // s2 | t2 | taps
-    constexpr int PPC = (NPAR * MC + 255) / 256;
+    constexpr int PPC = (NPAR * MC + NTH - 1) / NTH;
     float ppre[PPC], bnpre;
 #pragma unroll
     for (int q = 0; q < PPC; ++q) {
-        const int i = tid + 256 * q;
+        const int i = tid + NTH * q;
         float v = 0.f;
         if (i < NPAR * MC) {
             const int r = i / MC, c = i % MC;
@@ -373,7 +391,7 @@ __global__ __launch_bounds__(256) void mbconv_deep_kernel(MbDeepArgs p) {
     // ---- expand the band: two 16-pixel sub-tiles per step share every W fragment read
     const char* Xb = reinterpret_cast<const char*>(p.X) + ((long long)b * p.H * W + (long long)iy_lo * W) * cbytes;
     const int n_pair = (npx + 31) / 32;
-    for (int mp = wave; mp < ((p.dbg & 1) ? 0 : n_pair); mp += 4) {
+    for (int mp = wave; mp < ((p.dbg & 1) ? 0 : n_pair); mp += NTH / 64) {
         f32x4 acc[2][4];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
@@ -409,9 +427,14 @@ __global__ __launch_bounds__(256) void mbconv_deep_kernel(MbDeepArgs p) {
         for (int u = 0; u < 2; ++u) {
             const int hp = u == 0 ? hp0 : hp1;
             if (hp < npx) {
+                int ei = hp;
+                if constexpr (MF) {
+                    const int r = fdiv(hp, p.fd_w);
+                    ei = (iy_lo - iy_top + r) * p.we + (hp - r * W) + p.pad_l;
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    store4<T>(E + hp * EROW + 16 * j + 4 * fpiece,
+                    store4<T>(E + ei * EROW + 16 * j + 4 * fpiece,
                               silu_t<T>(acc[u][j][0] * sc[j][0] + sh[j][0]), silu_t<T>(acc[u][j][1] * sc[j][1] + sh[j][1]),
                               silu_t<T>(acc[u][j][2] * sc[j][2] + sh[j][2]), silu_t<T>(acc[u][j][3] * sc[j][3] + sh[j][3]));
             }
@@ -421,19 +444,102 @@ __global__ __launch_bounds__(256) void mbconv_deep_kernel(MbDeepArgs p) {
     float* cpar = reinterpret_cast<float*>(lds);               // reuses the W slot: [s2 | t2 | taps][MC]
 #pragma unroll
     for (int q = 0; q < PPC; ++q) {
-        const int i = tid + 256 * q;
+        const int i = tid + NTH * q;
         if (i < NPAR * MC) cpar[i] = ppre[q];
     }
     __syncthreads();
-    // ---- depthwise over the band, borders by index checks
     T* Y = reinterpret_cast<T*>(p.Y) + (long long)b * p.Ho * p.Wo * mid;
+    if constexpr (MF) {
+        // ---- depthwise on the matrix cores.  For a pair of taps (t0, t1) and a 16-channel tile:
+        //   A[m][k] (16 x 32) = diag(w[t0]) | diag(w[t1])      (k < 16: tap t0, k >= 16: tap t1)
+        //   B[n][k]           = E[pixel n shifted by t0][16 ch] | E[pixel n shifted by t1][16 ch]
+        // so one 16x16x32 MFMA accumulates two taps of 16 channels x 16 pixels.  The accumulator holds 4
+        // channels x 1 pixel per lane: BN + SiLU, the SE pool sums and the 8-byte store all stay in registers.
+        // Wave w owns channel tile w for the whole band, so its diagonal operands are built once.
+        constexpr int NH = NTH / 256;                              // waves that share one channel tile
+        const int j = wave & 3, half = wave >> 2;
+        float* pl_x = reinterpret_cast<float*>(lds) + (NPAR * MC);  // [NH-1][64] pool sums handed to the first wave of a tile
+        float plr[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool ch_ok = 16 * j + 4 * fpiece < cn;
+        if (16 * j < cn && !(p.dbg & 2)) {
+            constexpr int NTAP = KS * KS, NPAIR = (NTAP + 1) / 2;
+            const int hi = fpiece >> 1;
+            const bool active = (fpiece & 1) == (frow >> 3);
+            const int dq = (frow & 7) >> 1;
+            Frag<T> afr[NPAIR];
+            int toff[NPAIR];
+#pragma unroll
+            for (int pr = 0; pr < NPAIR; ++pr) {
+                const int t = 2 * pr + hi;                                   // this lane's tap of the pair
+                const bool on = active && t < NTAP;
+                const float wv = on ? cpar[(2 + (t < NTAP ? t : 0)) * MC + 16 * j + frow] : 0.f;
+                const unsigned bits = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)wv) << (16 * (frow & 1));
+                const u32x4 fr = {dq == 0 ? bits : 0u, dq == 1 ? bits : 0u, dq == 2 ? bits : 0u, dq == 3 ? bits : 0u};
+                afr[pr].v = __builtin_bit_cast(bf16x8, fr);
+                const int tt = t < NTAP ? t : 0;
+                toff[pr] = ((tt / KS) * p.we + (tt % KS)) * EROW * (int)sizeof(T);
+            }
+            const f32x4 s2v = *reinterpret_cast<const f32x4*>(cpar + 16 * j + 4 * fpiece);
+            const f32x4 t2v = *reinterpret_cast<const f32x4*>(cpar + MC + 16 * j + 4 * fpiece);
+            float pl[4] = {0.f, 0.f, 0.f, 0.f};
+            const int n_out = (oy_e - oy_b) * p.Wo;
+            const char* Eb = reinterpret_cast<const char*>(E) + (16 * j + 8 * (fpiece & 1)) * (int)sizeof(T);
+            for (int q0 = 16 * half; q0 < n_out; q0 += 16 * NH) {
+                const int q = q0 + frow;
+                const bool qv = q < n_out;
+                const int qq = qv ? q : 0;
+                const int oyr = fdiv(qq, p.fd_wo), ox = qq - oyr * p.Wo;
+                const char* base = Eb + ((oyr * S) * p.we + ox * S) * (EROW * (int)sizeof(T));
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int pr = 0; pr < NPAIR; ++pr) mma_chunk(afr[pr], ld_frag<T>(base + toff[pr]), acc);
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = to_f<T>(from_f<T>(silu_t<T>(acc[r] * s2v[r] + t2v[r])));
+                if (qv && ch_ok) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pl[r] += o[r];
+                    store4<T>(Y + ((long long)(oy_b + oyr) * p.Wo + ox) * mid + c0 + 16 * j + 4 * fpiece, o[0], o[1], o[2], o[3]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = pl[r];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                plr[r] = v;
+            }
+        }
+        if (p.pool_partial != nullptr) {
+            if constexpr (NH > 1) {                                // second-half waves hand their sums over through LDS
+                __syncthreads();                                   // every wave is done reading the constants
+                if (half > 0 && frow == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pl_x[(half - 1) * 64 + 16 * j + 4 * fpiece + r] = plr[r];
+                }
+                __syncthreads();
+                if (half == 0) {
+#pragma unroll
+                    for (int h = 1; h < NH; ++h)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) plr[r] += pl_x[(h - 1) * 64 + 16 * j + 4 * fpiece + r];
+                }
+            }
+            if (half == 0 && frow == 0 && ch_ok && 16 * j < cn) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    p.pool_partial[((long long)b * p.nbands + band) * mid + c0 + 16 * j + 4 * fpiece + r] = plr[r];
+            }
+        }
+        return;
+    }
+    // ---- float32: depthwise on the vector ALU over the band, borders by index checks
     const int cgn = cn / 8;
     F8 pool = f8_zero();
     const int cg = tid & 7;
     if (cg < cgn && !(p.dbg & 2)) {
         const F8 s2 = load8<float>(cpar + cg * 8), t2 = load8<float>(cpar + MC + cg * 8);
         const int gpr = (p.Wo + PPT - 1) / PPT;
-        for (int pg = tid >> 3; pg < (oy_e - oy_b) * gpr; pg += 32) {
+        for (int pg = tid >> 3; pg < (oy_e - oy_b) * gpr; pg += NTH / 8) {
             const int oy = oy_b + pg / gpr, ox0 = (pg % gpr) * PPT;
             F8 acc[PPT];
 #pragma unroll
@@ -479,12 +585,12 @@ __global__ __launch_bounds__(256) void mbconv_deep_kernel(MbDeepArgs p) {
     }
     if (p.pool_partial != nullptr) {
         __syncthreads();                                       // every wave is done reading the W slot
-        const float tot = pool_reduce<256>(pool, red, red + 256 * 8, tid, 8, 256);    // cg = tid & 7; idle groups hold zeros
+        const float tot = pool_reduce<NTH>(pool, red, red + NTH * 8, tid, 8, NTH);    // cg = tid & 7; idle groups hold zeros
         if (tid < cn) p.pool_partial[((long long)b * p.nbands + band) * mid + c0 + tid] = tot;
     }
 }
 
-struct DeepGeometry { bool use; int band_rows, nbands, nchunks, arow, e_rows_max; size_t lds; };
+struct DeepGeometry { bool use; int band_rows, nbands, nchunks, arow, e_rows_max, we; size_t lds; };
 
 template <typename T>
 DeepGeometry pick_deep(int H, int W, int Cin, int mid, int k, int stride) {
@@ -496,14 +602,26 @@ DeepGeometry pick_deep(int H, int W, int Cin, int mid, int k, int stride) {
     const size_t wc = (size_t)MC * g.arow > 9216 ? (size_t)MC * g.arow : 9216;
     const size_t budget = 78 * 1024;      // two workgroups per CU (160 KiB LDS)
     g.use = false;
-    if (Cin * (int)sizeof(T) < 128 || wc + (size_t)k * W * ERow<T>::value * sizeof(T) > budget) return g;   // wide inputs, narrow maps only
-    int rows = Ho;
-    for (;;) {
-        const int in_rows = (rows - 1) * stride + k < H ? (rows - 1) * stride + k : H;
-        const size_t lds = wc + (size_t)in_rows * W * ERow<T>::value * sizeof(T);
+    // bf16 stores the band with its zero padding: (Wo-1)*stride + k columns and unclipped rows
+    const bool mf = sizeof(T) == 2;
+    const int Wo = same_out(W, stride);
+    g.we = mf ? (Wo - 1) * stride + k : W;
+    const size_t row_bytes = (size_t)g.we * ERow<T>::value * sizeof(T);
+    if (Cin * (int)sizeof(T) < 128 || wc + (size_t)k * row_bytes > budget) return g;   // wide inputs, narrow maps only
+    for (int rows = Ho; rows >= 1; --rows) {
+        int in_rows = (rows - 1) * stride + k;
+        if (!mf && in_rows > H) in_rows = H;
+        const size_t lds = wc + (size_t)in_rows * row_bytes;
         if (lds <= budget) { g.band_rows = rows; g.e_rows_max = in_rows; g.lds = lds; break; }
         if (rows == 1) return g;
-        rows = (rows + 1) / 2;
+    }
+    // equal bands: no nearly empty last band
+    g.nbands = (Ho + g.band_rows - 1) / g.band_rows;
+    g.band_rows = (Ho + g.nbands - 1) / g.nbands;
+    {
+        int in_rows = (g.band_rows - 1) * stride + k;
+        if (!mf && in_rows > H) in_rows = H;
+        g.e_rows_max = in_rows; g.lds = wc + (size_t)in_rows * row_bytes;
     }
     if (g.band_rows < 3 && g.band_rows < Ho) return g;          // too much halo recompute: use spatial tiles
     g.nbands = (Ho + g.band_rows - 1) / g.band_rows;
@@ -539,15 +657,17 @@ Geometry pick_tile(int Ho, int Wo, int Cin, int k, int stride) {
 template <typename T>
 int launch_deep(hipStream_t st, const MbArgs& a, const DeepGeometry& g) {
     MbDeepArgs d{a.X, a.Y, a.W1, a.s1, a.t1, a.taps, a.s2, a.t2, a.pool_partial, a.B, a.H, a.W, a.Cin, a.mid, a.Ho, a.Wo,
-                 a.pad_t, a.pad_l, g.band_rows, g.nbands, g.nchunks, g.arow, g.e_rows_max, a.dbg};
+                 a.pad_t, a.pad_l, g.band_rows, g.nbands, g.nchunks, g.arow, g.e_rows_max, a.dbg, g.we,
+                 make_fastdiv(a.W), make_fastdiv(a.Wo)};
     void (*kern)(MbDeepArgs) = nullptr;
-    if (a.k == 3) kern = a.stride == 1 ? mbconv_deep_kernel<T, 3, 1, 4> : mbconv_deep_kernel<T, 3, 2, 4>;
-    else kern = a.stride == 1 ? mbconv_deep_kernel<T, 5, 1, 4> : mbconv_deep_kernel<T, 5, 2, 4>;
+    constexpr int NTH = sizeof(T) == 2 ? 512 : 256;
+    if (a.k == 3) kern = a.stride == 1 ? mbconv_deep_kernel<T, 3, 1, 4, NTH> : mbconv_deep_kernel<T, 3, 2, 4, NTH>;
+    else kern = a.stride == 1 ? mbconv_deep_kernel<T, 5, 1, 4, NTH> : mbconv_deep_kernel<T, 5, 2, 4, NTH>;
     if (g.lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return EFFDET_ELAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3(g.nchunks * g.nbands, a.B), dim3(256), g.lds, st, d);
+    hipLaunchKernelGGL(kern, dim3(g.nchunks * g.nbands, a.B), dim3(NTH), g.lds, st, d);
     return effdet_check_launch();
 }
 
@@ -559,6 +679,8 @@ int launch_mb(hipStream_t st, MbArgs& a) {
     if (g.lds > 160 * 1024) return EFFDET_EINVAL;
     a.TH = g.TH; a.TW = g.TW; a.IH = g.IH; a.IW = g.IW; a.HP = g.HP; a.HPpad = g.HPpad; a.arow = g.arow; a.e_bytes = g.e_bytes;
     a.tiles_x = (a.Wo + g.TW - 1) / g.TW; a.tiles_y = (a.Ho + g.TH - 1) / g.TH;
+    a.fd_ppr = make_fastdiv(a.Cin * (int)sizeof(T) / 16); a.fd_iw = make_fastdiv(g.IW); a.fd_tx = make_fastdiv(a.tiles_x);
+    a.tw_shift = 0; while ((1 << a.tw_shift) < g.TW) ++a.tw_shift;             // candidates have TW in {4, 8, 16}
     dim3 grid(a.tiles_x * a.tiles_y, a.B), block(SM_T);
     if (a.mid % SM_MC) return EFFDET_EINVAL;               // mid = 6 * Cin: always a multiple of 48
     void (*kern)(MbArgs) = nullptr;

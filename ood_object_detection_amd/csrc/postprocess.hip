@@ -429,7 +429,10 @@ __global__ __launch_bounds__(1024) void topk_sort_kernel(const TopkState* state,
     }
     for (int i = tid; i < k; i += 1024) {
         const unsigned long long key = keys[slot(i)];
-        const unsigned int flat = 0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull);
+        // fewer than k candidates can only happen with NaN logits (the per-anchor maxima skip NaNs, the key order
+        // does not): stay in bounds and emit element 0 for the missing ranks
+        unsigned int flat = 0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull);
+        if (i >= (int)n || (long long)flat >= L) flat = 0u;
         const long long o = (long long)b * k + i;
         const long long anchor = flat / (unsigned int)C;
         out_idx[o] = anchor;
