@@ -55,13 +55,15 @@ DEV void store4(T* p, float a, float b, float c, float d) {
 
 // Spatial-tile form.  512 threads (8 waves) per workgroup: with the LDS footprint allowing two workgroups per
 // CU this keeps 4 waves per SIMD in flight, which the VALU-heavy epilogues (SiLU on every expanded element)
-// need to fill their issue slots.  Expanded channels are processed SM_MC = 48 at a time: mid = 6 * Cin with
-// Cin a multiple of 8, so 48 always divides mid and no pass runs half empty.
+// need to fill their issue slots (6 waves per workgroup measured 1.5x slower).  Expanded channels are processed
+// SM_MC = 48 at a time: mid = 6 * Cin with Cin a multiple of 8, so 48 always divides mid and no pass runs half
+// empty.  In the bf16 depthwise phase waves 0-5 own (channel tile w % 3, half w / 3 of the pixel tiles), so each
+// builds its diagonal MFMA operands once per pass; waves 6-7 sit that phase out.
 constexpr int SM_T = 512;                       // threads
 constexpr int SM_NJ = 3;                        // 16-channel MFMA tiles per pass
 constexpr int SM_MC = 16 * SM_NJ;               // 48 expanded channels per pass
 constexpr int SM_CG = SM_MC / 8;                // 6 channel groups in the depthwise phase
-constexpr int SM_PG = SM_T / SM_CG;             // 85 pixel-group threads per channel group (510 threads work)
+constexpr int SM_PG = SM_T / SM_CG;             // 85 pixel-group threads per channel group (float32 depthwise; 510 threads work)
 template <typename T> struct ERowS { static constexpr int value = SM_MC + 16 / (int)sizeof(T); };
 
 template <typename T, int KS, int S>
@@ -192,6 +194,22 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
         xs[kc] = ok ? 16 * (SM_T / 64) * arow : 0;
     }
 
+    // bf16 depthwise on the matrix cores (see mbconv_deep_kernel): lane constants of the diagonal operands
+    constexpr bool MF = sizeof(T) == 2;
+    constexpr int NTAP = KS * KS, NPAIR = (NTAP + 1) / 2;
+    constexpr int NH = 2;                                   // waves per channel tile (waves >= NH * SM_NJ idle in that phase)
+    const int dj = wave % SM_NJ, dhalf = wave / SM_NJ;
+    const int dhi = fpiece >> 1;
+    const bool dactive = (fpiece & 1) == (frow >> 3);
+    const int ddq = (frow & 7) >> 1;
+    // byte offset of tap t inside the expanded tile; per pair a lane picks the even or the odd tap's (uniform) offset
+    auto tap_off = [&](int pr) {
+        const int t0 = 2 * pr, t1 = 2 * pr + 1 < NTAP ? 2 * pr + 1 : 0;
+        const int o0 = ((t0 / KS) * p.IW + (t0 % KS)) * EROW * (int)sizeof(T);
+        const int o1 = ((t1 / KS) * p.IW + (t1 % KS)) * EROW * (int)sizeof(T);
+        return dhi ? o1 : o0;
+    };
+
     for (int c0 = 0; c0 < mid; c0 += SM_MC) {
         __syncthreads();                                    // previous pass done with Wc / E / red / cpar
         commit(c0);
@@ -248,15 +266,83 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
             }
         }
         __syncthreads();
-        // ---- depthwise out of LDS: a thread owns 8 channels of one output pixel at a time
-        F8 pool = f8_zero();
-        const int cg = tid % SM_CG, pg0 = tid / SM_CG;
-        if (pg0 < SM_PG && !(p.dbg & 2)) {
-            for (int px = pg0; px < p.TH * p.TW; px += SM_PG) {
-                const int ty = px >> p.tw_shift, tx = px & (p.TW - 1);
-                const int oy = oy0 + ty, ox = ox0 + tx;
-                if (oy >= p.Ho || ox >= p.Wo) continue;
-                F8 acc = f8_zero();
+        if constexpr (MF) {
+            // ---- depthwise on the matrix cores: wave (dj, dhalf) owns channel tile dj and every NH-th pixel tile
+            float plr[4] = {0.f, 0.f, 0.f, 0.f};
+            if (wave < NH * SM_NJ && !(p.dbg & 2)) {
+                // the lane's single non-zero dword of each diagonal operand; expanded to the 16-byte fragment at use
+                unsigned abits[NPAIR];
+#pragma unroll
+                for (int pr = 0; pr < NPAIR; ++pr) {
+                    const int t = 2 * pr + dhi;
+                    const bool on = dactive && t < NTAP;
+                    const float wv = on ? ctap[(t < NTAP ? t : 0) * SM_MC + 16 * dj + frow] : 0.f;
+                    abits[pr] = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)wv) << (16 * (frow & 1));
+                }
+                const f32x4 s2v = *reinterpret_cast<const f32x4*>(cpar + 2 * SM_MC + 16 * dj + 4 * fpiece);
+                const f32x4 t2v = *reinterpret_cast<const f32x4*>(cpar + 3 * SM_MC + 16 * dj + 4 * fpiece);
+                const char* Eb = reinterpret_cast<const char*>(E) + (16 * dj + 8 * (fpiece & 1)) * (int)sizeof(T);
+                const int npix = p.TH * p.TW;
+                float pl[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int q0 = 16 * dhalf; q0 < npix; q0 += 16 * NH) {
+                    const int q = q0 + frow;
+                    const int qq = q < npix ? q : 0;
+                    const int ty = qq >> p.tw_shift, tx = qq & (p.TW - 1);
+                    const int oy = oy0 + ty, ox = ox0 + tx;
+                    const bool ok = q < npix && oy < p.Ho && ox < p.Wo;
+                    const char* base = Eb + ((ty * S) * p.IW + tx * S) * (EROW * (int)sizeof(T));
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int pr = 0; pr < NPAIR; ++pr) {
+                        unsigned bits = abits[pr];
+                        asm volatile("" : "+v"(bits));           // keep the expansion here: hoisted, the fragments would not fit the registers
+                        const u32x4 fr = {ddq == 0 ? bits : 0u, ddq == 1 ? bits : 0u, ddq == 2 ? bits : 0u, ddq == 3 ? bits : 0u};
+                        Frag<T> af; af.v = __builtin_bit_cast(bf16x8, fr);
+                        mma_chunk(af, ld_frag<T>(base + tap_off(pr)), acc);
+                    }
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = to_f<T>(from_f<T>(silu_t<T>(acc[r] * s2v[r] + t2v[r])));   // SE averages what the next layer reads
+                    if (ok) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pl[r] += o[r];
+                        store4<T>(Y + ((long long)oy * p.Wo + ox) * mid + c0 + 16 * dj + 4 * fpiece, o[0], o[1], o[2], o[3]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = pl[r];
+                    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                    plr[r] = v;
+                }
+            }
+            if (p.pool_partial != nullptr) {
+                __syncthreads();                            // every wave is done reading E: `red` may overwrite it
+                if (dhalf > 0 && dhalf < NH && frow == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[(dhalf - 1) * SM_MC + 16 * dj + 4 * fpiece + r] = plr[r];
+                }
+                __syncthreads();
+                if (dhalf == 0 && frow == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = plr[r];
+#pragma unroll
+                        for (int h = 1; h < NH; ++h) v += red[(h - 1) * SM_MC + 16 * dj + 4 * fpiece + r];
+                        p.pool_partial[((long long)b * (p.tiles_x * p.tiles_y) + tile) * mid + c0 + 16 * dj + 4 * fpiece + r] = v;
+                    }
+                }
+            }
+        } else {
+            // ---- float32: depthwise on the vector ALU out of LDS, a thread owns 8 channels of one output pixel at a time
+            F8 pool = f8_zero();
+            const int cg = tid % SM_CG, pg0 = tid / SM_CG;
+            if (pg0 < SM_PG && !(p.dbg & 2)) {
+                for (int px = pg0; px < p.TH * p.TW; px += SM_PG) {
+                    const int ty = px >> p.tw_shift, tx = px & (p.TW - 1);
+                    const int oy = oy0 + ty, ox = ox0 + tx;
+                    if (oy >= p.Ho || ox >= p.Wo) continue;
+                    F8 acc = f8_zero();
 #pragma unroll 1
                     for (int ky = 0; ky < KS; ++ky) {      // one tap / one LDS vector at a time: small register footprint
                         const T* erow = E + ((ty * S + ky) * p.IW + tx * S) * EROW + cg * 8;
@@ -269,21 +355,21 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
                             for (int q = 0; q < 8; ++q) acc.v[q] = fmaf(e.v[q], w.v[q], acc.v[q]);
                         }
                     }
-                const F8 s2 = load8<float>(cpar + 2 * SM_MC + cg * 8), t2 = load8<float>(cpar + 3 * SM_MC + cg * 8);
-                F8 o;
+                    const F8 s2 = load8<float>(cpar + 2 * SM_MC + cg * 8), t2 = load8<float>(cpar + 3 * SM_MC + cg * 8);
+                    F8 o;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float v = silu_t<T>(acc.v[q] * s2.v[q] + t2.v[q]);
-                    o.v[q] = to_f<T>(from_f<T>(v));              // SE averages what the next layer reads
-                    pool.v[q] += o.v[q];
+                    for (int q = 0; q < 8; ++q) {
+                        o.v[q] = silu_t<T>(acc.v[q] * s2.v[q] + t2.v[q]);
+                        pool.v[q] += o.v[q];
+                    }
+                    store8<T>(Y + ((long long)oy * p.Wo + ox) * mid + c0 + cg * 8, o);
                 }
-                store8<T>(Y + ((long long)oy * p.Wo + ox) * mid + c0 + cg * 8, o);
             }
-        }
-        if (p.pool_partial != nullptr) {
-            __syncthreads();                                // every thread is done reading E
-            const float tot = pool_reduce<SM_T>(pool, red, red + SM_T * 8, tid, SM_CG, SM_CG * SM_PG);
-            if (tid < SM_MC) p.pool_partial[((long long)b * (p.tiles_x * p.tiles_y) + tile) * mid + c0 + tid] = tot;
+            if (p.pool_partial != nullptr) {
+                __syncthreads();                            // every thread is done reading E
+                const float tot = pool_reduce<SM_T>(pool, red, red + SM_T * 8, tid, SM_CG, SM_CG * SM_PG);
+                if (tid < SM_MC) p.pool_partial[((long long)b * (p.tiles_x * p.tiles_y) + tile) * mid + c0 + tid] = tot;
+            }
         }
     }
 }
