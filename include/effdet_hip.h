@@ -77,9 +77,10 @@ int effdet_mbconv_expand_dw(void* stream, int dtype, const void* X, void* Y, con
                             int B, int H, int W, int Cin, int mid, int k, int stride);
 int effdet_mbconv_tiles_per_image(int dtype, int H, int W, int Cin, int mid, int k, int stride);
 
-/* SqueezeExcite gate: mean -> fc(C->R)+SiLU -> fc(R->C) -> sigmoid.  W1: [R][C], W2: [C][R]. */
+/* SqueezeExcite gate: mean -> fc(C->R)+SiLU -> fc(R->C) -> sigmoid.  W1: [R][C] (conv_reduce weight),
+ * W2t: [R][C] (conv_expand weight TRANSPOSED, so that consecutive threads read consecutive channels). */
 int effdet_se_gate(void* stream, const float* partial, int nblk, int hw, const float* W1, const float* b1,
-                   const float* W2, const float* b2, float* gate, int B, int C, int R);
+                   const float* W2t, const float* b2, float* gate, int B, int C, int R);
 
 /* ---- BiFPN + heads (effdet/efficientdet.py:140-469) ---------------------------------------------- */
 

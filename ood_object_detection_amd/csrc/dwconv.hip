@@ -144,44 +144,71 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs p) {
 struct SeArgs {
     const float* partial; int nblk; float inv_hw;
     const float* W1; const float* b1;       // [R][C], [R]
-    const float* W2; const float* b2;       // [C][R], [C]
+    const float* W2t; const float* b2;      // [R][C] (conv_expand weight transposed: coalesced over channels), [C]
     float* gate;                            // [B, C]
-    int C, R, nw;                           // nw: waves that split the partial-sum rows
+    int C, R, S;                            // S: slices that split the partial-sum rows
 };
 
+// One workgroup per image.  Every step is a short dependent chain, so the kernel is all latency: loads are
+// issued in batches of 8 before they are consumed and each thread sums only ~nblk / S partial rows.
 __global__ __launch_bounds__(1024) void se_gate_kernel(SeArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];    // pooled[C] + r[R] + wave partials [16][C]
+    extern __shared__ __attribute__((aligned(16))) float sm[];    // pooled[C] + r[R] + slice sums [S][C]
     float* pooled = sm;
     float* red = sm + p.C;
     float* wsum = red + p.R;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // partial sums: wave w (< nw) takes blocks w, w+nw, ... (fixed order -> bitwise reproducible)
-    for (int c = lane; c < p.C; c += 64) {
+    const int C = p.C, S = p.S;
+    // partial sums: slice sl takes rows sl, sl+S, ... (fixed order -> bitwise reproducible)
+    for (int idx = tid; idx < C * S; idx += 1024) {
+        const int sl = idx / C, c = idx - sl * C;
+        const float* src = p.partial + (long long)b * p.nblk * C + c;
         float s = 0.f;
-        const float* src = p.partial + (long long)b * p.nblk * p.C + c;
-        if (wave < p.nw) {
-            for (int q = wave; q < p.nblk; q += p.nw) s += src[(long long)q * p.C];
-            wsum[wave * p.C + c] = s;
+        int q = sl;
+        for (; q + 7 * S < p.nblk; q += 8 * S) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(long long)(q + u * S) * C];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
         }
+        for (; q < p.nblk; q += S) s += src[(long long)q * C];
+        wsum[idx] = s;
     }
     __syncthreads();
-    for (int c = tid; c < p.C; c += 1024) {
+    for (int c = tid; c < C; c += 1024) {
         float s = 0.f;
-        for (int w = 0; w < p.nw; ++w) s += wsum[w * p.C + c];
+        for (int w = 0; w < S; ++w) s += wsum[w * C + c];
         pooled[c] = s * p.inv_hw;
     }
     __syncthreads();
     for (int j = wave; j < p.R; j += 16) {
+        const float* w1 = p.W1 + (long long)j * C;
         float s = 0.f;
-        for (int c = lane; c < p.C; c += 64) s = fmaf(p.W1[(long long)j * p.C + c], pooled[c], s);
+        int c = lane;
+        for (; c + 3 * 64 < C; c += 4 * 64) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = w1[c + 64 * u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s = fmaf(v[u], pooled[c + 64 * u], s);
+        }
+        for (; c < C; c += 64) s = fmaf(w1[c], pooled[c], s);
         s = wave_reduce_sum(s);
         if (lane == 0) red[j] = silu_f(s + p.b1[j]);
     }
     __syncthreads();
-    for (int c = tid; c < p.C; c += 1024) {
+    for (int c = tid; c < C; c += 1024) {
         float s = p.b2[c];
-        for (int j = 0; j < p.R; ++j) s = fmaf(p.W2[(long long)c * p.R + j], red[j], s);
-        p.gate[(long long)b * p.C + c] = sigmoid_f(s);
+        int j = 0;
+        for (; j + 7 < p.R; j += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p.W2t[(long long)(j + u) * C + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s = fmaf(v[u], red[j + u], s);
+        }
+        for (; j < p.R; ++j) s = fmaf(p.W2t[(long long)j * C + c], red[j], s);
+        p.gate[(long long)b * C + c] = sigmoid_f(s);
     }
 }
 
@@ -294,13 +321,14 @@ extern "C" int effdet_dwconv_bn_act(void* stream, int dtype, const void* X, void
 }
 
 extern "C" int effdet_se_gate(void* stream, const float* partial, int nblk, int hw,
-                              const float* W1, const float* b1, const float* W2, const float* b2,
+                              const float* W1, const float* b1, const float* W2t, const float* b2,
                               float* gate, int B, int C, int R) {
     EFFDET_ENTER();
-    if (!partial || !W1 || !b1 || !W2 || !b2 || !gate || nblk <= 0 || hw <= 0 || B <= 0 || C <= 0 || R <= 0) return EFFDET_EINVAL;
-    const int nw = C <= 768 ? 16 : 4;
-    SeArgs a{partial, nblk, 1.0f / (float)hw, W1, b1, W2, b2, gate, C, R, nw};
-    const size_t sh = (size_t)((nw + 1) * C + R) * sizeof(float);
+    if (!partial || !W1 || !b1 || !W2t || !b2 || !gate || nblk <= 0 || hw <= 0 || B <= 0 || C <= 0 || R <= 0) return EFFDET_EINVAL;
+    int S = 1024 / C; if (S < 1) S = 1; if (S > 16) S = 16; if (S > nblk) S = nblk;
+    while (S > 1 && (size_t)((S + 1) * C + R) * sizeof(float) > 64 * 1024) --S;
+    SeArgs a{partial, nblk, 1.0f / (float)hw, W1, b1, W2t, b2, gate, C, R, S};
+    const size_t sh = (size_t)((S + 1) * C + R) * sizeof(float);
     if (sh > 64 * 1024) return EFFDET_EINVAL;
     hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(1024), sh, reinterpret_cast<hipStream_t>(stream), a);
     return effdet_check_launch();

@@ -1,5 +1,5 @@
 // Pointwise (1x1) convolution as an MFMA GEMM with fused per-channel affine (folded BN / bias),
-// optional SiLU, optional SE gate on the A operand and optional residual add.
+// optional SiLU, optional SE gate on the input channels and optional residual add.
 //
 //   C[m, n] = act( (sum_k A[m,k] * gate[img(m),k] * W[n,k]) * scale[n] + shift[n] ) + R[m,n]
 //
@@ -8,10 +8,16 @@
 //   ConvBnAct2d (effdet/efficientdet.py:155-158).
 //
 // A is the NHWC activation viewed as [M = B*H*W, K]; W is the conv weight [N = Cout, K = Cin].
-// The workgroup tile is 128 rows x BN columns; K is walked in 64-byte chunks (32 bf16 / 16 f32)
-// through a double-buffered LDS image whose rows are padded to 80 bytes.  Each of the 4 waves owns
-// 32 rows x BN columns of 16x16 MFMA tiles.  The accumulator tile is staged through LDS so that
-// HBM stores are whole 16-byte pieces of a row.
+// These GEMMs have a tiny N (16..320) and stream a large A exactly once, so the design is built around
+// keeping many A bytes in flight:
+//   * a workgroup owns 128 pixels of ONE image x BN output channels; each of its 4 waves owns 32 pixels;
+//   * the activations never touch LDS: every lane loads its 16-byte MFMA operand pieces straight from
+//     HBM, PF pipeline stages (128 bytes of K each) ahead of their use;
+//   * the (small, L2-resident) weight chunk goes through a double-buffered LDS image; the SE gate is folded
+//     into it on the way in (W[n,k] * gate[img,k]), so no vector instruction ever touches A;
+//   * accumulator rows are output channels, columns pixels, and the W rows are permuted in LDS so that a lane
+//     ends up with 8 consecutive channels of one pixel per pair of tiles: affine / SiLU / residual happen in
+//     registers and every lane stores 16 bytes straight to HBM.
 #include "common.h"
 
 namespace {
@@ -23,137 +29,115 @@ struct PwArgs {
     const void* res;
     const float* gate; int rows_per_image;
     void* C; long long c_image_stride; long long ldc;
+    int tiles_per_image, n_tiles, vec_ok;
 };
 
-constexpr int BM = 128;
-
-template <typename T> struct Chunk { u32x4 raw; };
-
-template <typename T>
-DEV u32x4 apply_gate(u32x4 raw, const float* g) {
-    if constexpr (sizeof(T) == 4) {
-        f32x4 v = __builtin_bit_cast(f32x4, raw);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] *= g[i];
-        return __builtin_bit_cast(u32x4, v);
-    } else {
-        bf16x8 v = __builtin_bit_cast(bf16x8, raw);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (bf16_t)((float)v[i] * g[i]);
-        return __builtin_bit_cast(u32x4, v);
-    }
-}
+constexpr int PW_PIX = 128;                      // pixels per workgroup (4 waves x 2 MFMA tiles)
+constexpr int KCH = 2;                           // 64-byte K-chunks per pipeline stage
 
 template <typename T, int BN>
-__global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs p) {
+__global__ __launch_bounds__(256, 2) void pw_gemm_kernel(PwArgs p) {
     constexpr int EPC = VecTraits<T>::EPC;          // elements per 16-byte piece
     constexpr int KPC = 64 / (int)sizeof(T);        // elements per 64-byte K-chunk
-    constexpr int NT = BN / 16;                     // 16-wide column tiles per wave
-    // 64-byte K-chunks per pipeline stage: two for the wide tile (more bytes in flight at 2 workgroups/CU),
-    // one for the narrow tiles, whose small LDS footprint already gives 4-6 workgroups per CU
-    constexpr int KCH = BN >= 128 ? 2 : 1;
-    constexpr int ROWB = KCH * 64 + 16;             // bytes per LDS row: stage of K + 16 pad
-    constexpr int A_BYTES = BM * ROWB;
+    constexpr int NT = BN / 16, NP = NT / 2;
+    static_assert(NT % 2 == 0, "tile pairs");
+    // A stages (128 bytes of K per pixel) in flight ahead of the one being multiplied: as many as the registers
+    // left over by the accumulators allow - the late layers are latency bound, not bandwidth bound
+    constexpr int PF = 2;                           // (5 stages for the narrow tiles measured slower: fewer waves fit)
+    constexpr int ROWB = KCH * 64 + 16;             // bytes per LDS row: one stage of K + 16 pad
     constexpr int W_BYTES = BN * ROWB;
-    constexpr int TILE_BYTES = 2 * (A_BYTES + W_BYTES);
-    constexpr int SROW = BN + 4;                    // staging row stride in floats
-    constexpr int STAGE_BYTES = BM * SROW * 4;
-    constexpr int LDS_BYTES = TILE_BYTES > STAGE_BYTES ? TILE_BYTES : STAGE_BYTES;
-    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) char lds[2 * W_BYTES];
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int n_tiles = (p.N + BN - 1) / BN;
-    const long long bid = blockIdx.x;
-    const int nt = (int)(bid % n_tiles);
-    const long long mt = bid / n_tiles;
-    const long long m0 = mt * BM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 15, fpiece = lane >> 4;
+    const int K = p.K, N = p.N;
+    const int nt = blockIdx.x % p.n_tiles;
+    const int mt = blockIdx.x / p.n_tiles;
+    const int img = mt / p.tiles_per_image;
+    const int pix0 = (mt - img * p.tiles_per_image) * PW_PIX;
     const int n0 = nt * BN;
-    const int K = p.K;
+    const int n_count = (N - n0) < BN ? (N - n0) : BN;
     const long long pitch = (long long)K * (long long)sizeof(T);
     const int nkc = (K + KPC - 1) / KPC;            // 64-byte chunks
     const int nst = (nkc + KCH - 1) / KCH;          // pipeline stages
+    const int kbytes = K * (int)sizeof(T);
 
-    const char* Ab = reinterpret_cast<const char*>(p.A);
-    const char* Wb = reinterpret_cast<const char*>(p.W);
-
-    // staging assignment: per stage A has 128 rows x PPR pieces, W has BN x PPR pieces (16 bytes each)
-    constexpr int PPR = KCH * 4;
-    constexpr int A_PER_THREAD = BM * PPR / 256;
-    constexpr int W_PIECES = BN * PPR;
-    constexpr int W_PER_THREAD = (W_PIECES + 255) / 256;
-
-    u32x4 a_reg[A_PER_THREAD];
-    u32x4 w_reg[W_PER_THREAD];
-    f32x4 g_reg[A_PER_THREAD][2];                     // SE gate of the A pieces (8 floats each), applied at store time
-
-    // per-thread constants of its A rows, hoisted out of the K loop (the image index needs an integer division)
-    const char* a_src[A_PER_THREAD];
-    const float* a_gate[A_PER_THREAD];
-    bool a_ok[A_PER_THREAD];
+    // ---- this lane's two pixels (B operand columns): pointers into A, clamped inside the image
+    const char* arow[2];
+    int pix[2];
+    bool pix_ok[2];
 #pragma unroll
-    for (int q = 0; q < A_PER_THREAD; ++q) {
-        const int idx = tid + 256 * q;
-        const long long m = m0 + idx / PPR;
-        a_ok[q] = m < p.M;
-        a_src[q] = Ab + (a_ok[q] ? m : 0) * pitch;
-        a_gate[q] = p.gate != nullptr ? p.gate + (long long)((unsigned int)(a_ok[q] ? m : 0) / (unsigned int)p.rows_per_image) * K : nullptr;
+    for (int i = 0; i < 2; ++i) {
+        pix[i] = pix0 + 32 * wave + 16 * i + frow;
+        pix_ok[i] = pix[i] < p.rows_per_image;
+        const long long m = (long long)img * p.rows_per_image + (pix_ok[i] ? pix[i] : 0);
+        arow[i] = reinterpret_cast<const char*>(p.A) + m * pitch + fpiece * 16;
     }
-
-    // load_stage only ISSUES loads (A piece, its gate vector, W piece): nothing here may consume them, or the
-    // prefetch would stall on its own data instead of overlapping the MFMA work of the current stage
-    auto load_stage = [&](int stg) {
+    // A ring: PF + 1 stages x KCH chunks x 2 pixel tiles, straight from memory into MFMA operand registers
+    Frag<T> areg[PF + 1][KCH][2];
+    auto a_load = [&](int stg, int slot) {
 #pragma unroll
-        for (int q = 0; q < A_PER_THREAD; ++q) {
-            const int idx = tid + 256 * q;
-            const int piece = idx % PPR;
-            const int ke = stg * KCH * KPC + piece * EPC;    // element offset along K
-            u32x4 v = {0u, 0u, 0u, 0u};
-            f32x4 g0 = {1.f, 1.f, 1.f, 1.f}, g1 = g0;
-            if (a_ok[q] && ke < K) {
-                v = *reinterpret_cast<const u32x4*>(a_src[q] + (long long)ke * sizeof(T));
-                if (p.gate != nullptr) {
-                    g0 = *reinterpret_cast<const f32x4*>(a_gate[q] + ke);
-                    if constexpr (sizeof(T) == 2) g1 = *reinterpret_cast<const f32x4*>(a_gate[q] + ke + 4);
-                }
-            }
-            a_reg[q] = v; g_reg[q][0] = g0; g_reg[q][1] = g1;
-        }
+        for (int sub = 0; sub < KCH; ++sub) {
+            const int off = (stg * KCH + sub) * 64 + fpiece * 16;
+            const bool ok = off < kbytes;
+            const int offc = ok ? off - fpiece * 16 : 0;     // a lane past the end of K re-reads byte 0 and is zeroed below
 #pragma unroll
-        for (int q = 0; q < W_PER_THREAD; ++q) {
-            const int idx = tid + 256 * q;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (idx < W_PIECES) {
-                const int piece = idx % PPR, row = idx / PPR;
-                const int n = n0 + row;
-                const int ke = stg * KCH * KPC + piece * EPC;
-                if (n < p.N && ke < K)
-                    v = *reinterpret_cast<const u32x4*>(Wb + (long long)n * pitch + (long long)ke * sizeof(T));
+            for (int i = 0; i < 2; ++i) {
+                Frag<T> f = ld_frag<T>(arow[i] + offc);
+                if (!ok) f.v = decltype(f.v){};
+                areg[slot][sub][i] = f;
             }
-            w_reg[q] = v;
         }
     };
-    auto store_stage = [&](int buf) {
-        char* Ad = lds + buf * (A_BYTES + W_BYTES);
-        char* Wd = Ad + A_BYTES;
-#pragma unroll
-        for (int q = 0; q < A_PER_THREAD; ++q) {
-            const int idx = tid + 256 * q;
-            u32x4 v = a_reg[q];
-            if (p.gate != nullptr) {
-                float g[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { g[e] = g_reg[q][0][e]; g[4 + e] = g_reg[q][1][e]; }
-                v = apply_gate<T>(v, g);
-            }
-            *reinterpret_cast<u32x4*>(Ad + (idx / PPR) * ROWB + (idx % PPR) * 16) = v;
-        }
+
+    // ---- W staging: BN rows x 8 pieces per stage; gate folded in
+    const char* Wb = reinterpret_cast<const char*>(p.W);
+    const float* gate = p.gate != nullptr ? p.gate + (long long)img * K : nullptr;
+    constexpr int PPR = KCH * 4;
+    constexpr int W_PER_THREAD = (BN * PPR + 255) / 256;
+    auto lds_row = [](int co) { return 16 * (2 * (co >> 5) + ((co >> 2) & 1)) + 4 * ((co >> 3) & 3) + (co & 3); };
+    u32x4 w_reg[W_PER_THREAD];
+    f32x4 g_reg[W_PER_THREAD][2];
+    auto w_load = [&](int stg) {                     // issues loads only
 #pragma unroll
         for (int q = 0; q < W_PER_THREAD; ++q) {
             const int idx = tid + 256 * q;
-            if (idx < W_PIECES)
-                *reinterpret_cast<u32x4*>(Wd + (idx / PPR) * ROWB + (idx % PPR) * 16) = w_reg[q];
+            const int co = idx / PPR, piece = idx % PPR;
+            const int ke = stg * KCH * KPC + piece * EPC;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            f32x4 g0 = {1.f, 1.f, 1.f, 1.f}, g1 = g0;
+            if (idx < BN * PPR && co < n_count && ke < K) {
+                v = *reinterpret_cast<const u32x4*>(Wb + (long long)(n0 + co) * pitch + (long long)ke * sizeof(T));
+                if (gate != nullptr) {
+                    g0 = *reinterpret_cast<const f32x4*>(gate + ke);
+                    if constexpr (sizeof(T) == 2) g1 = *reinterpret_cast<const f32x4*>(gate + ke + 4);
+                }
+            }
+            w_reg[q] = v; g_reg[q][0] = g0; g_reg[q][1] = g1;
+        }
+    };
+    auto w_store = [&](int buf) {
+        char* Wd = lds + buf * W_BYTES;
+#pragma unroll
+        for (int q = 0; q < W_PER_THREAD; ++q) {
+            const int idx = tid + 256 * q;
+            if (idx < BN * PPR) {
+                u32x4 v = w_reg[q];
+                if (gate != nullptr) {
+                    if constexpr (sizeof(T) == 4) {
+                        f32x4 x = __builtin_bit_cast(f32x4, v);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[e] *= g_reg[q][0][e];
+                        v = __builtin_bit_cast(u32x4, x);
+                    } else {
+                        bf16x8 x = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] = (bf16_t)((float)x[e] * (e < 4 ? g_reg[q][0][e] : g_reg[q][1][e - 4]));
+                        v = __builtin_bit_cast(u32x4, x);
+                    }
+                }
+                *reinterpret_cast<u32x4*>(Wd + lds_row(idx / PPR) * ROWB + (idx % PPR) * 16) = v;
+            }
         }
     };
 
@@ -163,94 +147,119 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    load_stage(0);
-    store_stage(0);
+    // prologue: PF stages of A in flight, W stage 0 in LDS
+#pragma unroll
+    for (int s = 0; s < PF; ++s) if (s < nst) a_load(s, s);
+    w_load(0);
+    w_store(0);
     __syncthreads();
 
-    const int frow = lane & 15, fpiece = lane >> 4;
-    for (int stg = 0; stg < nst; ++stg) {
-        const int buf = stg & 1;
-        if (stg + 1 < nst) load_stage(stg + 1);
-        const char* As = lds + buf * (A_BYTES + W_BYTES);
-        const char* Ws = As + A_BYTES;
+    const int njp = (n_count + 31) / 32;               // 32-channel groups that hold real channels
+    for (int stg0 = 0; stg0 < nst; stg0 += PF + 1) {
 #pragma unroll
-        for (int sub = 0; sub < KCH; ++sub) {
-            if (stg * KCH + sub < nkc) {
-                Frag<T> a0 = ld_frag<T>(As + (32 * wave + frow) * ROWB + sub * 64 + fpiece * 16);
-                Frag<T> a1 = ld_frag<T>(As + (32 * wave + 16 + frow) * ROWB + sub * 64 + fpiece * 16);
+        for (int u = 0; u < PF + 1; ++u) {              // slot index = stage % (PF + 1), compile-time per unrolled step
+            const int stg = stg0 + u;
+            if (stg < nst) {
+                if (stg + PF < nst) a_load(stg + PF, (u + PF) % (PF + 1));
+                if (stg + 1 < nst) w_load(stg + 1);
+                const char* Ws = lds + (stg & 1) * W_BYTES;
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    Frag<T> b = ld_frag<T>(Ws + (16 * j + frow) * ROWB + sub * 64 + fpiece * 16);
-                    mma_chunk(a0, b, acc[0][j]);
-                    mma_chunk(a1, b, acc[1][j]);
+                for (int sub = 0; sub < KCH; ++sub) {
+                    if (stg * KCH + sub < nkc) {
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            if (j < 2 * njp) {
+                                const Frag<T> wf = ld_frag<T>(Ws + (16 * j + frow) * ROWB + sub * 64 + fpiece * 16);
+                                mma_chunk(wf, areg[u][sub][0], acc[0][j]);
+                                mma_chunk(wf, areg[u][sub][1], acc[1][j]);
+                            }
+                        }
+                    }
                 }
+                if (stg + 1 < nst) w_store((stg + 1) & 1);
+                __syncthreads();
             }
         }
-        if (stg + 1 < nst) store_stage(buf ^ 1);
-        __syncthreads();
     }
 
-    // ---- epilogue: accumulators -> LDS staging (fp32) -> affine/act/residual -> HBM
-    float* S = reinterpret_cast<float*>(lds);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                S[(32 * wave + 16 * i + 4 * fpiece + r) * SROW + 16 * j + frow] = acc[i][j][r];
-    __syncthreads();
-
-    constexpr int GPR = BN / 8;                      // 8-column groups per row
-    T* Cb = reinterpret_cast<T*>(p.C);
+    // ---- epilogue in registers: per 32-channel group J this lane holds channels [32J + 8*fpiece, +8) of its pixels
+    T* Cb = reinterpret_cast<T*>(p.C) + (long long)img * p.c_image_stride;
     const T* Rb = reinterpret_cast<const T*>(p.res);
-    for (int g = tid; g < BM * GPR; g += 256) {
-        const int row = g / GPR, cg = g % GPR;
-        const long long m = m0 + row;
-        const int n = n0 + cg * 8;
-        if (m >= p.M || n >= p.N) continue;
-        const unsigned int bimg = (unsigned int)m / (unsigned int)p.rows_per_image;      // M < 2^31: 32-bit division
-        const unsigned int pix = (unsigned int)m - bimg * (unsigned int)p.rows_per_image;
-        T* dst = Cb + (long long)bimg * p.c_image_stride + (long long)pix * p.ldc + n;
-        const int nvalid = (p.N - n) < 8 ? (p.N - n) : 8;
-        float v[8];
-        const f32x4 va = *reinterpret_cast<const f32x4*>(S + row * SROW + cg * 8);        // aligned: SROW % 4 == 0
-        const f32x4 vb = *reinterpret_cast<const f32x4*>(S + row * SROW + cg * 8 + 4);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float x = e < 4 ? va[e] : vb[e - 4];
-            if (e < nvalid) {
-                const float sc = p.scale ? p.scale[n + e] : 1.0f;
-                x = x * sc + p.shift[n + e];
-                if (p.act == 1) x = silu_t<T>(x);
-                if (Rb) x += to_f<T>(Rb[m * p.N + n + e]);
+    for (int J = 0; J < NP; ++J) {
+        if (J < njp) {
+            const int cb = 32 * J + 8 * fpiece;
+            const int nvalid = n_count - cb;
+            if (nvalid > 0) {
+                float sc[8], sh[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int n = n0 + cb + (e < nvalid ? e : 0);
+                    sc[e] = p.scale ? p.scale[n] : 1.0f;
+                    sh[e] = p.shift[n];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (!pix_ok[i]) continue;
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = fmaf(acc[i][2 * J][r], sc[r], sh[r]);
+                        v[4 + r] = fmaf(acc[i][2 * J + 1][r], sc[4 + r], sh[4 + r]);
+                    }
+                    if (p.act == 1) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = silu_t<T>(v[e]);
+                    }
+                    T* dst = Cb + (long long)pix[i] * p.ldc + n0 + cb;
+                    if (Rb != nullptr) {
+                        const T* rsrc = Rb + ((long long)img * p.rows_per_image + pix[i]) * N + n0 + cb;
+                        if (p.vec_ok && nvalid >= 8) {
+                            const F8 rv = load8<T>(rsrc);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += rv.v[e];
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += to_f<T>(rsrc[e]);
+                        }
+                    }
+                    if (p.vec_ok && nvalid >= 8) {
+                        F8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o.v[e] = v[e];
+                        store8<T>(dst, o);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) if (e < nvalid) dst[e] = from_f<T>(v[e]);
+                    }
+                }
             }
-            v[e] = x;
-        }
-        if (nvalid == 8 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
-            F8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o.v[e] = v[e];
-            store8<T>(dst, o);
-        } else {
-            for (int e = 0; e < nvalid; ++e) dst[e] = from_f<T>(v[e]);
         }
     }
 }
 
 template <typename T>
-int launch_pw(hipStream_t st, const PwArgs& a) {
-    const long long mt = (a.M + BM - 1) / BM;
-    int bn = a.N <= 16 ? 16 : a.N <= 32 ? 32 : a.N <= 64 ? 64 : 128;
-    const long long ntile = (a.N + bn - 1) / bn;
-    const long long blocks = mt * ntile;
+int launch_pw(hipStream_t st, PwArgs& a) {
+    // output-channel tile: the smallest of {32, 64, 96, 128, 160, 192} that covers N, else equal tiles <= 192
+    int ntl = (a.N + 191) / 192;
+    int bn = ((a.N + ntl - 1) / ntl + 31) / 32 * 32;
+    a.tiles_per_image = (a.rows_per_image + PW_PIX - 1) / PW_PIX;
+    const long long images = a.M / a.rows_per_image;
+    a.n_tiles = (a.N + bn - 1) / bn;
+    const long long blocks = images * a.tiles_per_image * a.n_tiles;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return EFFDET_EINVAL;
+    const size_t esz = sizeof(T);
+    a.vec_ok = ((size_t)a.N * esz) % 16 == 0 && ((size_t)a.ldc * esz) % 16 == 0 && ((size_t)a.c_image_stride * esz) % 16 == 0 &&
+               reinterpret_cast<uintptr_t>(a.C) % 16 == 0 && (a.res == nullptr || reinterpret_cast<uintptr_t>(a.res) % 16 == 0);
     dim3 grid((unsigned)blocks), block(256);
     switch (bn) {
-        case 16: hipLaunchKernelGGL((pw_gemm_kernel<T, 16>), grid, block, 0, st, a); break;
-        case 32: hipLaunchKernelGGL((pw_gemm_kernel<T, 32>), grid, block, 0, st, a); break;
-        case 64: hipLaunchKernelGGL((pw_gemm_kernel<T, 64>), grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL((pw_gemm_kernel<T, 128>), grid, block, 0, st, a); break;
+        case 32:  hipLaunchKernelGGL((pw_gemm_kernel<T, 32>), grid, block, 0, st, a); break;
+        case 64:  hipLaunchKernelGGL((pw_gemm_kernel<T, 64>), grid, block, 0, st, a); break;
+        case 96:  hipLaunchKernelGGL((pw_gemm_kernel<T, 96>), grid, block, 0, st, a); break;
+        case 128: hipLaunchKernelGGL((pw_gemm_kernel<T, 128>), grid, block, 0, st, a); break;
+        case 160: hipLaunchKernelGGL((pw_gemm_kernel<T, 160>), grid, block, 0, st, a); break;
+        case 192: hipLaunchKernelGGL((pw_gemm_kernel<T, 192>), grid, block, 0, st, a); break;
+        default: return EFFDET_EINVAL;
     }
     return effdet_check_launch();
 }
@@ -269,10 +278,10 @@ extern "C" int effdet_pw_gemm_bn_act(void* stream, int dtype,
     if (K % 8 != 0 || M > 0x7fffffffLL) return EFFDET_EINVAL;   // 16-byte pieces along K; 32-bit row arithmetic
     if (act != 0 && act != 1) return EFFDET_EINVAL;
     if (rows_per_image <= 0) { rows_per_image = (int)(M > 0x7fffffffLL ? 0x7fffffff : M); }
-    if (gate && (M % rows_per_image) != 0) return EFFDET_EINVAL;
+    if ((M % rows_per_image) != 0) return EFFDET_EINVAL;         // workgroups never straddle images
     if (ldc <= 0) ldc = N;
     if (c_image_stride <= 0) c_image_stride = (long long)rows_per_image * ldc;
-    PwArgs a{A, M, K, W, N, scale, shift, act, residual, gate, rows_per_image, C, c_image_stride, ldc};
+    PwArgs a{A, M, K, W, N, scale, shift, act, residual, gate, rows_per_image, C, c_image_stride, ldc, 0, 0, 0};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == 0) return launch_pw<float>(st, a);
     if (dtype == 1) return launch_pw<bf16_t>(st, a);

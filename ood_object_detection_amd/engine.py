@@ -235,7 +235,7 @@ class Engine(object):
                     pw_out, bn_out = m.conv_pw, m.bn2
                 W1 = self._f32(m.se.conv_reduce.weight.reshape(b['se'], b['mid']))
                 b1 = self._f32(m.se.conv_reduce.bias)
-                W2 = self._f32(m.se.conv_expand.weight.reshape(b['mid'], b['se']))
+                W2 = self._f32(m.se.conv_expand.weight.reshape(b['mid'], b['se']).t())      # [R][C]: coalesced over channels
                 b2 = self._f32(m.se.conv_expand.bias)
                 plan.append((lib.effdet_se_gate,
                              (partial.data_ptr(), nblk, ho * wo, W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(),

@@ -95,7 +95,7 @@ def test_dwconv_se(dtype, C, H, W, k, s):
     pooled = _hip.nchw(y).cpu().mean((2, 3))
     gref = torch.sigmoid(om.silu(pooled @ W1.t() + b1) @ W2.t() + b2)
     gate = torch.empty(B, C, dtype=torch.float32, device=DEV)
-    args = [t.to(DEV).contiguous() for t in (W1, b1, W2, b2)]
+    args = [t.to(DEV).contiguous() for t in (W1, b1, W2.t(), b2)]       # conv_expand weight goes in transposed ([R][C])
     rc = lib.effdet_se_gate(_hip.stream(DEV), part.data_ptr(), nblk, Ho * Wo, *[a.data_ptr() for a in args], gate.data_ptr(), B, C, R)
     assert rc == 0
     assert _rel(gate, gref) < 2e-5
