@@ -246,6 +246,17 @@ def main():
                 'algorithmic_bytes_per_launch': int(d['bytes'] / d['launches']),
                 'network_frac': round(net_bytes / (net_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 'step_frac': round(net_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    # HBM traffic of the dominant family: PMC counters cannot be read from inside this process, so the number
+    # comes from the committed rocprofv3 --pmc passes of the same workload (tools/profile_gpu.sh ->
+    # tools/pmc_traffic.py); null when the workload is not the profiled one.
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'latest_pmc_traffic.json')
+    if os.path.exists(tpath) and (args.model, args.image, B, args.dtype, args.classes) == ('tf_efficientdet_d0', 640, 64, 'bf16', 90):
+        try:
+            tj = json.load(open(tpath))
+            roofline['traffic'] = int(tj['families'][dom]['bytes'] / d['launches'])
+            roofline['traffic_source'] = 'profiles/latest_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)'
+        except (KeyError, ValueError):
+            pass
     if args.profile_out:
         with open(args.profile_out, 'w') as fh:
             fh.write('# per-launch HIP-event times, %s %dx%d batch %d %s\n' % (args.model, args.image, args.image, B, args.dtype))
@@ -261,7 +272,7 @@ def main():
     if not args.no_cpu_baseline:
         cpu = cpu_baseline(sd_cpu, cfg, args.image, args.classes)
     out = {
-        'metric': 'images/sec, tf_efficientdet_d0 640px bf16 inference + OOD score (DetBenchPredict end-to-end)',
+        'metric': 'images/sec, %s %dpx %s inference + OOD score (DetBenchPredict end-to-end)' % (args.model, args.image, args.dtype),
         'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.dtype, 'data': 'synthetic',
