@@ -376,14 +376,16 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void sepconv_kernel(SepArg
                         if (p.post_act) { a0 = silu_t<T>(a0); a1 = silu_t<T>(a1); }
                         vals[J][r] = a0; vals[J][4 + r] = a1;
                     }
-                    const int nvalid = n_count - cb;
+                    const bool group_full = 32 * J + 32 <= n_count;     // uniform: only the last group of a chunk has a tail
+                    const int nvalid = group_full ? 8 : n_count - cb;
                     if (pix_in[i] && nvalid > 0) store_piece<T>(out + pix_off[i] + n_begin + cb, vals[J], nvalid, p.vec_ok != 0);
                     if constexpr (OOD) {
+                        if (!group_full) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            if (e >= nvalid) vals[J][e] = -INFINITY;
-                            m = fmaxf(m, vals[J][e]);
+                            for (int e = 0; e < 8; ++e) if (e >= nvalid) vals[J][e] = -INFINITY;
                         }
+                        m = fmaxf(m, fmaxf(fmaxf(fmaxf(vals[J][0], vals[J][1]), fmaxf(vals[J][2], vals[J][3])),
+                                           fmaxf(fmaxf(vals[J][4], vals[J][5]), fmaxf(vals[J][6], vals[J][7]))));
                     }
                 }
             }
@@ -461,11 +463,22 @@ int launch_sep(hipStream_t st, SepArgs& a, int B) {
     return effdet_check_launch();
 }
 
+template <typename T, int TH, int TW, int NTH, int FT>
+int dispatch_sep_f(hipStream_t st, SepArgs& a, int B) {
+    return a.ood_classes > 0 ? launch_sep<T, TH, TW, 96, true, NTH, FT>(st, a, B) : launch_sep<T, TH, TW, 64, false, NTH, FT>(st, a, B);
+}
+
+// the BiFPN widths of tf_efficientdet_d0..d4 get compile-time channel counts; anything else the generic kernel
 template <typename T, int TH, int TW, int NTH>
 int dispatch_sep(hipStream_t st, SepArgs& a, int B) {
-    const bool ood = a.ood_classes > 0;
-    if (a.F == 64) return ood ? launch_sep<T, TH, TW, 96, true, NTH, 64>(st, a, B) : launch_sep<T, TH, TW, 64, false, NTH, 64>(st, a, B);
-    return ood ? launch_sep<T, TH, TW, 96, true, NTH, 0>(st, a, B) : launch_sep<T, TH, TW, 64, false, NTH, 0>(st, a, B);
+    switch (a.F) {
+        case 64:  return dispatch_sep_f<T, TH, TW, NTH, 64>(st, a, B);
+        case 88:  return dispatch_sep_f<T, TH, TW, NTH, 88>(st, a, B);
+        case 112: return dispatch_sep_f<T, TH, TW, NTH, 112>(st, a, B);
+        case 160: return dispatch_sep_f<T, TH, TW, NTH, 160>(st, a, B);
+        case 224: return dispatch_sep_f<T, TH, TW, NTH, 224>(st, a, B);
+        default:  return dispatch_sep_f<T, TH, TW, NTH, 0>(st, a, B);
+    }
 }
 
 }  // namespace
