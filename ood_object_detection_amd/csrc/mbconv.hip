@@ -679,14 +679,13 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void mbconv_deep_kernel(Mb
 struct DeepGeometry { bool use; int band_rows, nbands, nchunks, arow, e_rows_max, we; size_t lds; };
 
 template <typename T>
-DeepGeometry pick_deep(int H, int W, int Cin, int mid, int k, int stride) {
+DeepGeometry pick_deep_budget(int H, int W, int Cin, int mid, int k, int stride, size_t budget) {
     DeepGeometry g{};
     const int Ho = same_out(H, stride);
     const int nkc = (Cin * (int)sizeof(T) + 63) / 64;
     g.arow = nkc * 64 + 16;
     g.nchunks = (mid + MC - 1) / MC;
     const size_t wc = (size_t)MC * g.arow > 9216 ? (size_t)MC * g.arow : 9216;
-    const size_t budget = 78 * 1024;      // two workgroups per CU (160 KiB LDS)
     g.use = false;
     // bf16 stores the band with its zero padding: (Wo-1)*stride + k columns and unclipped rows
     const bool mf = sizeof(T) == 2;
@@ -712,6 +711,15 @@ DeepGeometry pick_deep(int H, int W, int Cin, int mid, int k, int stride) {
     if (g.band_rows < 3 && g.band_rows < Ho) return g;          // too much halo recompute: use spatial tiles
     g.nbands = (Ho + g.band_rows - 1) / g.band_rows;
     g.use = true;
+    return g;
+}
+
+// Two workgroups per CU (78 KiB each) where a useful band fits; very wide inputs (the W1 slice of a 448-channel
+// block alone is 58 KiB) take the whole CU rather than falling back to tiny spatial tiles.
+template <typename T>
+DeepGeometry pick_deep(int H, int W, int Cin, int mid, int k, int stride) {
+    DeepGeometry g = pick_deep_budget<T>(H, W, Cin, mid, k, stride, 78 * 1024);
+    if (!g.use && Cin * (int)sizeof(T) >= 512) g = pick_deep_budget<T>(H, W, Cin, mid, k, stride, 156 * 1024);
     return g;
 }
 
