@@ -47,6 +47,19 @@ int effdet_stem_dw_fused(void* stream, int in_dtype, int dtype, const void* X, c
                          void* Y, float* pool_partial, int B, int H, int W, int C);
 int effdet_stem_dw_tiles_per_image(int H, int W);
 
+/* Input normalisation of the reference's PrefetchLoader (effdet/data/loader.py:114-128):
+ * y = (float(x) - mean[c]) / std[c], x uint8 NCHW [B,C,hw], mean/std = 255 * the dataset constants
+ * (host arrays of C <= 4 floats), y in out_dtype.  The *_u8 stem entry points apply the same arithmetic
+ * (result rounded to the model dtype, exactly what feeding the normalised tensor would give) while loading
+ * the input patch, so a uint8 batch needs no separate pass. */
+int effdet_normalize_u8(void* stream, int out_dtype, const unsigned char* X, const float* mean, const float* stdv,
+                        void* Y, int B, int C, long long hw);
+int effdet_stem_conv_u8(void* stream, int out_dtype, const unsigned char* X, const float* mean, const float* stdv,
+                        const float* Wt, const float* scale, const float* shift, void* Y, int B, int H, int W, int Cout);
+int effdet_stem_dw_fused_u8(void* stream, int dtype, const unsigned char* X, const float* mean, const float* stdv,
+                            const void* Wk, const float* s1, const float* t1, const float* taps, const float* s2, const float* t2,
+                            void* Y, float* pool_partial, int B, int H, int W, int C);
+
 /* 1x1 conv as GEMM with folded BN / bias, optional SiLU (act=1), optional SE gate on A
  * (gate [B,K] fp32, rows_per_image = H*W), optional residual [M,N].  A: [M,K], W: [N,K].
  * Output row m goes to C + (m / rows_per_image) * c_image_stride + (m % rows_per_image) * ldc

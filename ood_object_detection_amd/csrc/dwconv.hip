@@ -19,7 +19,8 @@ namespace {
 
 // ------------------------------------------------------------------------------------------ stem
 struct StemArgs {
-    const void* X; int in_dtype;            // NCHW, 0 = f32, 1 = bf16
+    const void* X; int in_dtype;            // NCHW, 0 = f32, 1 = bf16, 2 = uint8 (normalised on the fly)
+    float nmean[3], nstd[3];                // uint8 input: y = (x - mean) / std, then rounded to the model dtype
     const float* Wt;                        // [27][Cout] tap-major (ky, kx, ci)
     const float* scale; const float* shift;
     void* Y;                                // NHWC [B, Ho, Wo, Cout]
@@ -57,8 +58,10 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs p) {
 #pragma unroll
             for (int ci = 0; ci < 3; ++ci) {
                 const long long off = ((long long)b * 3 + ci) * plane + (long long)iy * p.W + ix;
-                const float x = p.in_dtype == 0 ? reinterpret_cast<const float*>(p.X)[off]
-                                                : (float)reinterpret_cast<const bf16_t*>(p.X)[off];
+                float x;
+                if (p.in_dtype == 0) x = reinterpret_cast<const float*>(p.X)[off];
+                else if (p.in_dtype == 1) x = (float)reinterpret_cast<const bf16_t*>(p.X)[off];
+                else x = to_f<T>(from_f<T>(((float)reinterpret_cast<const unsigned char*>(p.X)[off] - p.nmean[ci]) / p.nstd[ci]));
                 const float* w = wl + ((ky * 3 + kx) * 3 + ci) * C + cg * 8;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] = fmaf(x, w[e], acc[e]);
@@ -251,14 +254,13 @@ __global__ __launch_bounds__(256) void maxpool_kernel(PoolArgs p) {
 
 }  // namespace
 
-extern "C" int effdet_stem_conv(void* stream, int in_dtype, int out_dtype,
-                                const void* X, const float* Wt, const float* scale, const float* shift,
-                                void* Y, int B, int H, int W, int Cout) {
-    EFFDET_ENTER();
+static int stem_conv_common(void* stream, int in_dtype, int out_dtype, const void* X, const float* mean, const float* stdv,
+                            const float* Wt, const float* scale, const float* shift, void* Y, int B, int H, int W, int Cout) {
     if (!X || !Wt || !scale || !shift || !Y || B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout % 8) return EFFDET_EINVAL;
-    if ((in_dtype | out_dtype) & ~1) return EFFDET_EINVAL;
-    StemArgs a{X, in_dtype, Wt, scale, shift, Y, B, H, W, Cout, same_out(H, 2), same_out(W, 2),
+    if (in_dtype < 0 || in_dtype > 2 || (out_dtype & ~1) || (in_dtype == 2 && (!mean || !stdv))) return EFFDET_EINVAL;
+    StemArgs a{X, in_dtype, {0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}, Wt, scale, shift, Y, B, H, W, Cout, same_out(H, 2), same_out(W, 2),
                same_pad_before(H, 3, 2), same_pad_before(W, 3, 2)};
+    if (in_dtype == 2) for (int i = 0; i < 3; ++i) { a.nmean[i] = mean[i]; a.nstd[i] = stdv[i]; }
     const long long total = (long long)B * a.Ho * a.Wo * (Cout / 8);
     const long long blocks = (total + 255) / 256;
     if (blocks > 0x7fffffffLL) return EFFDET_EINVAL;
@@ -266,6 +268,73 @@ extern "C" int effdet_stem_conv(void* stream, int in_dtype, int out_dtype,
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (out_dtype == 0) hipLaunchKernelGGL(stem_kernel<float>, dim3((unsigned)blocks), dim3(256), sh, st, a);
     else hipLaunchKernelGGL(stem_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), sh, st, a);
+    return effdet_check_launch();
+}
+
+extern "C" int effdet_stem_conv(void* stream, int in_dtype, int out_dtype,
+                                const void* X, const float* Wt, const float* scale, const float* shift,
+                                void* Y, int B, int H, int W, int Cout) {
+    EFFDET_ENTER();
+    if (in_dtype & ~1) return EFFDET_EINVAL;
+    return stem_conv_common(stream, in_dtype, out_dtype, X, nullptr, nullptr, Wt, scale, shift, Y, B, H, W, Cout);
+}
+
+extern "C" int effdet_stem_conv_u8(void* stream, int out_dtype, const unsigned char* X, const float* mean, const float* stdv,
+                                   const float* Wt, const float* scale, const float* shift,
+                                   void* Y, int B, int H, int W, int Cout) {
+    EFFDET_ENTER();
+    return stem_conv_common(stream, 2, out_dtype, X, mean, stdv, Wt, scale, shift, Y, B, H, W, Cout);
+}
+
+namespace {
+struct NormArgs { const unsigned char* X; void* Y; float mean[4], stdv[4]; int C; long long hw, total; };
+
+// PrefetchLoader normalisation: 16 pixels of one plane per thread (one 16-byte load)
+template <typename T>
+__global__ __launch_bounds__(256) void normalize_u8_kernel(NormArgs p) {
+    const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (i0 >= p.total) return;
+    const int c = (int)((i0 / p.hw) % p.C);                   // hw % 16 == 0 on this path: a piece never straddles planes
+    const float m = p.mean[c], s = p.stdv[c];
+    const u32x4 raw = *reinterpret_cast<const u32x4*>(p.X + i0);
+    T* dst = reinterpret_cast<T*>(p.Y) + i0;
+    F8 o[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const float x = (float)((raw[e >> 2] >> (8 * (e & 3))) & 0xFFu);
+        o[e >> 3].v[e & 7] = (x - m) / s;
+    }
+    store8<T>(dst, o[0]);
+    store8<T>(dst + 8, o[1]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void normalize_u8_scalar_kernel(NormArgs p) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.total) return;
+    const int c = (int)((i / p.hw) % p.C);
+    reinterpret_cast<T*>(p.Y)[i] = from_f<T>(((float)p.X[i] - p.mean[c]) / p.stdv[c]);
+}
+}  // namespace
+
+extern "C" int effdet_normalize_u8(void* stream, int out_dtype, const unsigned char* X, const float* mean, const float* stdv,
+                                   void* Y, int B, int C, long long hw) {
+    EFFDET_ENTER();
+    if (!X || !Y || !mean || !stdv || B <= 0 || C <= 0 || C > 4 || hw <= 0 || (out_dtype & ~1)) return EFFDET_EINVAL;
+    NormArgs a; a.X = X; a.Y = Y; a.C = C; a.hw = hw; a.total = (long long)B * C * hw;
+    for (int i = 0; i < C; ++i) { if (stdv[i] == 0.f) return EFFDET_EINVAL; a.mean[i] = mean[i]; a.stdv[i] = stdv[i]; }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool vec = hw % 16 == 0 && reinterpret_cast<uintptr_t>(X) % 16 == 0 && reinterpret_cast<uintptr_t>(Y) % 16 == 0;
+    const long long items = vec ? a.total / 16 : a.total;
+    const long long blocks = (items + 255) / 256;
+    if (blocks > 0x7fffffffLL) return EFFDET_EINVAL;
+    if (vec) {
+        if (out_dtype == 0) hipLaunchKernelGGL(normalize_u8_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(normalize_u8_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    } else {
+        if (out_dtype == 0) hipLaunchKernelGGL(normalize_u8_scalar_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(normalize_u8_scalar_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    }
     return effdet_check_launch();
 }
 

@@ -19,7 +19,8 @@
 namespace {
 
 struct SdArgs {
-    const void* X; int in_dtype;
+    const void* X; int in_dtype;                 // NCHW; 0 = f32, 1 = bf16, 2 = uint8 normalised on the fly
+    float nmean[3], nstd[3];
     const void* Wk;                              // [Cpad][32] im2col weights (T), k = (ky*3+kx)*3+ci, zero padded
     const float* s1; const float* t1;            // stem BN fold [C]
     const float* taps;                           // depthwise [9][C]
@@ -76,7 +77,9 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(SdArgs p) {
                 const int y = iy0 + rem / SD_IW, x = ix0 + rem % SD_IW;
                 if (y >= 0 && y < p.H && x >= 0 && x < p.W) {
                     const long long off = ((long long)b * 3 + ci) * plane + (long long)y * p.W + x;
-                    v = p.in_dtype == 0 ? reinterpret_cast<const float*>(p.X)[off] : (float)reinterpret_cast<const bf16_t*>(p.X)[off];
+                    if (p.in_dtype == 0) v = reinterpret_cast<const float*>(p.X)[off];
+                    else if (p.in_dtype == 1) v = (float)reinterpret_cast<const bf16_t*>(p.X)[off];
+                    else v = ((float)reinterpret_cast<const unsigned char*>(p.X)[off] - p.nmean[ci]) / p.nstd[ci];
                 }
             }
             vin[q] = v;
@@ -245,14 +248,14 @@ extern "C" int effdet_stem_dw_tiles_per_image(int H, int W) {
     return ((Ho + SD_TH - 1) / SD_TH) * ((Wo + SD_TW - 1) / SD_TW);
 }
 
-extern "C" int effdet_stem_dw_fused(void* stream, int in_dtype, int dtype, const void* X, const void* Wk,
-                                    const float* s1, const float* t1, const float* taps,
-                                    const float* s2, const float* t2, void* Y, float* pool_partial,
-                                    int B, int H, int W, int C) {
-    EFFDET_ENTER();
+static int stem_dw_common(void* stream, int in_dtype, int dtype, const void* X, const float* mean, const float* stdv, const void* Wk,
+                          const float* s1, const float* t1, const float* taps,
+                          const float* s2, const float* t2, void* Y, float* pool_partial,
+                          int B, int H, int W, int C) {
     if (!X || !Wk || !s1 || !t1 || !taps || !s2 || !t2 || !Y || B <= 0 || H <= 0 || W <= 0) return EFFDET_EINVAL;
-    if (C <= 0 || C % 8 || C > 64 || ((in_dtype | dtype) & ~1)) return EFFDET_EINVAL;
+    if (C <= 0 || C % 8 || C > 64 || in_dtype < 0 || in_dtype > 2 || (dtype & ~1) || (in_dtype == 2 && (!mean || !stdv))) return EFFDET_EINVAL;
     SdArgs a;
+    for (int i = 0; i < 3; ++i) { a.nmean[i] = in_dtype == 2 ? mean[i] : 0.f; a.nstd[i] = in_dtype == 2 ? stdv[i] : 1.f; }
     a.X = X; a.in_dtype = in_dtype; a.Wk = Wk; a.s1 = s1; a.t1 = t1; a.taps = taps; a.s2 = s2; a.t2 = t2;
     a.Y = Y; a.pool_partial = pool_partial; a.B = B; a.H = H; a.W = W; a.C = C;
     a.Ho = same_out(H, 2); a.Wo = same_out(W, 2);
@@ -276,4 +279,21 @@ extern "C" int effdet_stem_dw_fused(void* stream, int in_dtype, int dtype, const
         hipLaunchKernelGGL(stem_dw_kernel<bf16_t>, grid, block, lds, st, a);
     }
     return effdet_check_launch();
+}
+
+extern "C" int effdet_stem_dw_fused(void* stream, int in_dtype, int dtype, const void* X, const void* Wk,
+                                    const float* s1, const float* t1, const float* taps,
+                                    const float* s2, const float* t2, void* Y, float* pool_partial,
+                                    int B, int H, int W, int C) {
+    EFFDET_ENTER();
+    if (in_dtype & ~1) return EFFDET_EINVAL;
+    return stem_dw_common(stream, in_dtype, dtype, X, nullptr, nullptr, Wk, s1, t1, taps, s2, t2, Y, pool_partial, B, H, W, C);
+}
+
+extern "C" int effdet_stem_dw_fused_u8(void* stream, int dtype, const unsigned char* X, const float* mean, const float* stdv,
+                                       const void* Wk, const float* s1, const float* t1, const float* taps,
+                                       const float* s2, const float* t2, void* Y, float* pool_partial,
+                                       int B, int H, int W, int C) {
+    EFFDET_ENTER();
+    return stem_dw_common(stream, 2, dtype, X, mean, stdv, Wk, s1, t1, taps, s2, t2, Y, pool_partial, B, H, W, C);
 }

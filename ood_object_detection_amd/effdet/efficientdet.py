@@ -279,6 +279,9 @@ class EfficientDet(nn.Module):
         self._engine = None
         self.ood_energy = None
         self.ood_max_logit = None
+        # normalisation applied when a raw uint8 batch is passed to forward (effdet/data/loader.py:114-128)
+        self.input_mean = (0.485, 0.456, 0.406)
+        self.input_std = (0.229, 0.224, 0.225)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
 
     # ---- engine management -----------------------------------------------------------------

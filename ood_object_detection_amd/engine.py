@@ -48,6 +48,8 @@ class Engine(object):
         self.A = model.num_anchors
         self.L = cfg.num_levels
         self._keep = []          # tensors / ctypes arrays referenced by the launch lists
+        self.input_mean = tuple(getattr(model, 'input_mean', (0.485, 0.456, 0.406)))     # used for uint8 inputs only
+        self.input_std = tuple(getattr(model, 'input_std', (0.229, 0.224, 0.225)))
         self.pyr_es = torch.empty(0, dtype=self.dtype).element_size()
         H, W = self.image_size
         if H % (2 ** cfg.max_level) or W % (2 ** cfg.max_level):
@@ -257,8 +259,8 @@ class Engine(object):
     def run_backbone(self, x):
         if tuple(x.shape) != self.x_shape:
             raise ValueError('engine was prepared for input %s, got %s' % (self.x_shape, tuple(x.shape)))
-        if x.device != self.device or x.dtype not in _DT:
-            raise RuntimeError('input must be a float32/bfloat16 tensor on %s' % (self.device,))
+        if x.device != self.device or (x.dtype not in _DT and x.dtype != torch.uint8):
+            raise RuntimeError('input must be a float32/bfloat16 (normalised) or uint8 (raw) tensor on %s' % (self.device,))
         x = x.contiguous()
         self._stem_call(x)
         self._run(self._bb_plan)
@@ -266,6 +268,23 @@ class Engine(object):
 
     def _stem_call(self, x):
         st = torch.cuda.current_stream(self.device).cuda_stream
+        if x.dtype == torch.uint8:
+            # raw images: the loader's (x - 255*mean) / (255*std) (effdet/data/loader.py:114-128) happens inside the
+            # stem kernel's input load
+            import ctypes
+            mean = (ctypes.c_float * 3)(*[255.0 * v for v in self.input_mean])
+            std = (ctypes.c_float * 3)(*[255.0 * v for v in self.input_std])
+            if self._fuse_stem:
+                wk, s, t, taps0, s2, t2, dbuf, partial, H, W, c = self._stem
+                _lib.check(self.lib.effdet_stem_dw_fused_u8(st, self.dt, x.data_ptr(), mean, std, wk.data_ptr(), s.data_ptr(),
+                                                            t.data_ptr(), taps0.data_ptr(), s2.data_ptr(), t2.data_ptr(),
+                                                            dbuf.data_ptr(), partial.data_ptr(), self.B, H, W, c),
+                           'backbone.conv_stem+blocks.0.0.conv_dw (uint8)')
+            else:
+                wt, s, t, out, H, W, c = self._stem
+                _lib.check(self.lib.effdet_stem_conv_u8(st, self.dt, x.data_ptr(), mean, std, wt.data_ptr(), s.data_ptr(),
+                                                        t.data_ptr(), out.data_ptr(), self.B, H, W, c), 'backbone.conv_stem (uint8)')
+            return
         if self._fuse_stem:
             wk, s, t, taps0, s2, t2, dbuf, partial, H, W, c = self._stem
             _lib.check(self.lib.effdet_stem_dw_fused(st, _DT[x.dtype], self.dt, x.data_ptr(), wk.data_ptr(), s.data_ptr(),

@@ -167,3 +167,21 @@ def test_d2_d4_small(name, size, ncls):
     mb = model.to(torch.bfloat16)
     cls_b, box_b = mb(x.to(DEV).to(torch.bfloat16))
     assert all(bool(torch.isfinite(t.float()).all()) for t in list(cls_b) + list(box_b))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_uint8_input_equals_normalised_input(dtype):
+    """A raw uint8 batch (normalisation fused into the stem kernel) gives bit-identical outputs to feeding the
+    loader-normalised tensor cast to the model dtype."""
+    import copy
+    from ood_object_detection_amd.effdet.preprocess import normalize_batch
+    model, cfg, nodes, sd = seeded_model('tf_efficientdet_d0', 128, 20, seed=2)
+    model = copy.deepcopy(model).to(DEV).to(dtype)
+    g = torch.Generator().manual_seed(9)
+    xu = torch.randint(0, 256, (2, 3, 128, 128), generator=g, dtype=torch.uint8).to(DEV)
+    with torch.no_grad():
+        ca, ba = model(xu)
+        ca = [t.clone() for t in ca]; ba = [t.clone() for t in ba]
+        cb, bb = model(normalize_batch(xu, dtype=torch.float32).to(dtype))
+    for a, b in zip(ca + ba, list(cb) + list(bb)):
+        assert torch.equal(a, b)

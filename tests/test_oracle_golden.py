@@ -120,3 +120,16 @@ def test_bifpn_head_wiring(golden, tag):
         assert np.array_equal(activs[i].numpy(), g['%s_act%d' % (tag, i)])
         assert np.array_equal(cls_o[i].numpy(), g['%s_cls%d' % (tag, i)])
         assert np.array_equal(box_o[i].numpy(), g['%s_box%d' % (tag, i)])
+
+
+def test_normalize_matches_loader_expression():
+    """oracle/preprocess.py vs the literal PrefetchLoader expression (effdet/data/loader.py:114-115,127-128)."""
+    import torch
+    from oracle import preprocess as opre
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(0, 256, (2, 3, 16, 24), generator=g, dtype=torch.uint8)
+    mean = torch.tensor([v * 255 for v in opre.IMAGENET_DEFAULT_MEAN]).view(1, 3, 1, 1)
+    std = torch.tensor([v * 255 for v in opre.IMAGENET_DEFAULT_STD]).view(1, 3, 1, 1)
+    ref = x.float().sub_(mean).div_(std)
+    got = opre.normalize_u8(x.numpy())
+    assert np.array_equal(got, ref.numpy())
