@@ -178,6 +178,14 @@ int effdet_label_anchors(void* stream, const float* anchors, const float* gt_box
                          int B, int Mmax, long long N, float match_threshold, long long* cls_t, float* box_t,
                          float* num_positives, long long* match, void* workspace, long long workspace_bytes);
 
+/* ---- OOD evaluation helpers -------------------------------------------- */
+
+/* Image-level OOD score out[b] = max_a(-energy[b, a]) over the per-anchor energies [B, N]. */
+int effdet_ood_image_score(void* stream, const float* energy, int B, long long N, float* out);
+/* AUROC of in-distribution scores `pos` against OOD scores `neg` by exact pair counting:
+ * counts[0] = #{(i,j): pos_i > neg_j}, counts[1] = #{pos_i == neg_j};  AUROC = (counts[0] + counts[1]/2) / (n_pos*n_neg). */
+int effdet_auroc_counts(void* stream, const float* pos, const float* neg, int n_pos, int n_neg, unsigned long long* counts);
+
 #ifdef __cplusplus
 }
 #endif

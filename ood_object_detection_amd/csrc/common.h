@@ -167,6 +167,14 @@ DEV float pool_reduce(const F8& pool, float* red, float* red2, int tid, int cgn,
     return tot;
 }
 
+DEV unsigned long long wave_reduce_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)(v & 0xFFFFFFFFull), o, 64), hi = __shfl_xor((unsigned)(v >> 32), o, 64);
+        v += ((unsigned long long)hi << 32) | lo;
+    }
+    return v;
+}
 DEV float wave_reduce_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -728,6 +728,52 @@ inline int topk_segments(int B, long long L) {
 
 }  // namespace
 
+namespace {
+
+// Image-level OOD score from the per-anchor energies: max_a(-energy_a); one workgroup per image
+__global__ __launch_bounds__(256) void ood_image_score_kernel(const float* energy, long long N, float* out) {
+    const float* row = energy + (long long)blockIdx.x * N;
+    float m = -INFINITY;
+    for (long long i = threadIdx.x; i < N; i += 256) m = fmaxf(m, -row[i]);
+    m = wave_reduce_max(m);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+}
+
+// AUROC by exhaustive pair counting (exact, ties = 1/2): counts[0] += #{pos > neg}, counts[1] += #{pos == neg}
+__global__ __launch_bounds__(256) void auroc_count_kernel(const float* pos, const float* neg, int np, int nn,
+                                                          unsigned long long* counts) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long gt = 0, eq = 0;
+    if (i < np) {
+        const float p = pos[i];
+        for (int j = 0; j < nn; ++j) { const float q = neg[j]; gt += p > q; eq += p == q; }
+    }
+    gt = wave_reduce_sum_u64(gt); eq = wave_reduce_sum_u64(eq);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&counts[0], gt); atomicAdd(&counts[1], eq); }     // integer adds: order independent
+}
+
+}  // namespace
+
+extern "C" int effdet_ood_image_score(void* stream, const float* energy, int B, long long N, float* out) {
+    EFFDET_ENTER();
+    if (!energy || !out || B <= 0 || N <= 0) return EFFDET_EINVAL;
+    hipLaunchKernelGGL(ood_image_score_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), energy, N, out);
+    return effdet_check_launch();
+}
+
+extern "C" int effdet_auroc_counts(void* stream, const float* pos, const float* neg, int n_pos, int n_neg,
+                                   unsigned long long* counts) {
+    EFFDET_ENTER();
+    if (!pos || !neg || !counts || n_pos <= 0 || n_neg <= 0) return EFFDET_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(counts, 0, 16, st) != hipSuccess) return EFFDET_ELAUNCH;
+    hipLaunchKernelGGL(auroc_count_kernel, dim3((n_pos + 255) / 256), dim3(256), 0, st, pos, neg, n_pos, n_neg, counts);
+    return effdet_check_launch();
+}
+
 extern "C" long long effdet_topk_workspace_bytes(int B, long long n_anchors) {
     if (B <= 0 || n_anchors <= 0) return EFFDET_EINVAL;
     // 2 states | histogram | candidate keys | selected anchors | row maxima (when the caller has none)

@@ -210,3 +210,18 @@ def generate_detections(cls_outputs, box_outputs, anchors, indices, classes, img
     if return_aux:
         return det, src[top]
     return det
+
+
+def auroc(pos, neg):
+    """AUROC with `pos` as the positive class: P(pos > neg) + P(pos == neg)/2 (Mann-Whitney U / (n_p n_n)).
+    Build-defined metric; pinned in tests against sklearn.metrics.roc_auc_score."""
+    import numpy as np
+    p = np.asarray(pos, dtype=np.float64).reshape(-1, 1)
+    n = np.asarray(neg, dtype=np.float64).reshape(1, -1)
+    return float(((p > n).sum() + 0.5 * (p == n).sum()) / (p.size * n.size))
+
+
+def image_ood_score(energy):
+    """[B, N] per-anchor energies -> [B] max_a(-energy_a)."""
+    import numpy as np
+    return (-np.asarray(energy, dtype=np.float32)).max(axis=1)

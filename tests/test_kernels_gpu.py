@@ -521,3 +521,19 @@ def test_normalize_u8(dtype, shape):
     ref = torch.from_numpy(opre.normalize_u8(x.numpy()))
     got = normalize_batch(x.to(DEV), dtype=dtype)
     assert torch.equal(got.float().cpu(), ref.to(dtype).float())
+
+
+def test_ood_image_score_and_auroc():
+    """Device-side image score max_a(-energy) and pair-counting AUROC vs the oracle (exact)."""
+    from ood_object_detection_amd import ood
+    g = torch.Generator().manual_seed(11)
+    e_in = torch.randn(37, 3069, generator=g) - 0.4
+    e_out = torch.randn(29, 3069, generator=g)
+    s_in, s_out = ood.image_scores(e_in.to(DEV)), ood.image_scores(e_out.to(DEV))
+    assert np.array_equal(s_in.cpu().numpy(), op.image_ood_score(e_in.numpy()))
+    assert np.array_equal(s_out.cpu().numpy(), op.image_ood_score(e_out.numpy()))
+    assert abs(ood.auroc(s_in, s_out) - op.auroc(s_in.cpu().numpy(), s_out.cpu().numpy())) < 1e-12
+    # heavy ties
+    a = torch.round(torch.randn(500, generator=g) * 2) / 2
+    b = torch.round(torch.randn(300, generator=g) * 2) / 2 - 0.5
+    assert abs(ood.auroc(a.to(DEV), b.to(DEV)) - op.auroc(a.numpy(), b.numpy())) < 1e-12

@@ -133,3 +133,13 @@ def test_normalize_matches_loader_expression():
     ref = x.float().sub_(mean).div_(std)
     got = opre.normalize_u8(x.numpy())
     assert np.array_equal(got, ref.numpy())
+
+
+def test_auroc_oracle_matches_sklearn():
+    sk = pytest.importorskip('sklearn.metrics')
+    from oracle import postprocess as opp
+    rng = np.random.RandomState(0)
+    pos = np.round(rng.randn(200) + 0.7, 1)          # rounding plants ties
+    neg = np.round(rng.randn(150), 1)
+    ref = sk.roc_auc_score(np.r_[np.ones_like(pos), np.zeros_like(neg)], np.r_[pos, neg])
+    assert abs(opp.auroc(pos, neg) - ref) < 1e-12
