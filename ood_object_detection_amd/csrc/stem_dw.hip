@@ -35,7 +35,9 @@ constexpr int SD_HP = SD_HH * SD_HW;                         // 324
 constexpr int SD_HPPAD = (SD_HP + 15) / 16 * 16;             // 336
 constexpr int SD_IH = 2 * SD_TH + 5, SD_IW = 2 * SD_TW + 5;  // input patch 37 x 37
 
-template <typename T>
+// IN: input dtype at compile time (0 = f32, 1 = bf16, 2 = uint8 normalised on the fly): keeps the patch gather a
+// straight batch of loads
+template <typename T, int IN>
 __global__ __launch_bounds__(256) void stem_dw_kernel(SdArgs p) {
     constexpr int EPC = VecTraits<T>::EPC;                   // im2col elements per lane per MFMA chunk
     constexpr int KPC = 64 / (int)sizeof(T);                 // k values per chunk (32 bf16 / 16 f32)
@@ -77,9 +79,13 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(SdArgs p) {
                 const int y = iy0 + rem / SD_IW, x = ix0 + rem % SD_IW;
                 if (y >= 0 && y < p.H && x >= 0 && x < p.W) {
                     const long long off = ((long long)b * 3 + ci) * plane + (long long)y * p.W + x;
-                    if (p.in_dtype == 0) v = reinterpret_cast<const float*>(p.X)[off];
-                    else if (p.in_dtype == 1) v = (float)reinterpret_cast<const bf16_t*>(p.X)[off];
-                    else v = ((float)reinterpret_cast<const unsigned char*>(p.X)[off] - p.nmean[ci]) / p.nstd[ci];
+                    if constexpr (IN == 0) v = reinterpret_cast<const float*>(p.X)[off];
+                    else if constexpr (IN == 1) v = (float)reinterpret_cast<const bf16_t*>(p.X)[off];
+                    else {
+                        const float m = ci == 0 ? p.nmean[0] : ci == 1 ? p.nmean[1] : p.nmean[2];
+                        const float sd = ci == 0 ? p.nstd[0] : ci == 1 ? p.nstd[1] : p.nstd[2];
+                        v = ((float)reinterpret_cast<const unsigned char*>(p.X)[off] - m) / sd;
+                    }
                 }
             }
             vin[q] = v;
@@ -146,6 +152,7 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(SdArgs p) {
                 xf[kc].v[j] = In[koff[kc][j] >= 0 ? base + koff[kc][j] : 3 * SD_IH * SD_IW];
         const int sy = sy0 + hy, sx = sx0 + hx;
         const bool inside = hp < SD_HP && sy >= 0 && sy < p.Ho && sx >= 0 && sx < p.Wo;
+        const float inside_m = inside ? 1.f : 0.f;
         for (int j = 0; j < n_ct; ++j) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(SdArgs p) {
                 const f32x4 sh = *reinterpret_cast<const f32x4*>(par + 10 * C + ch);
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = inside ? silu_t<T>(acc[r] * sc[r] + sh[r]) : 0.f;
+                for (int r = 0; r < 4; ++r) v[r] = silu_t<T>(acc[r] * sc[r] + sh[r]) * inside_m;   // a mask, not a branch per element
                 if constexpr (sizeof(T) == 2) {
                     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                     *reinterpret_cast<bf16x4*>(E + hp * erow + ch) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
@@ -263,21 +270,15 @@ static int stem_dw_common(void* stream, int in_dtype, int dtype, const void* X, 
     a.tiles_x = (a.Wo + SD_TW - 1) / SD_TW; a.tiles_y = (a.Ho + SD_TH - 1) / SD_TH;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(a.tiles_x * a.tiles_y, B), block(256);
-    if (dtype == 0) {
-        const size_t lds = sd_lds_bytes<float>(C);
-        if (lds > 64 * 1024) {
-            static bool done = false;
-            if (!done) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_dw_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return EFFDET_ELAUNCH; done = true; }
-        }
-        hipLaunchKernelGGL(stem_dw_kernel<float>, grid, block, lds, st, a);
-    } else {
-        const size_t lds = sd_lds_bytes<bf16_t>(C);
-        if (lds > 64 * 1024) {
-            static bool done = false;
-            if (!done) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_dw_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return EFFDET_ELAUNCH; done = true; }
-        }
-        hipLaunchKernelGGL(stem_dw_kernel<bf16_t>, grid, block, lds, st, a);
+    const size_t lds = dtype == 0 ? sd_lds_bytes<float>(C) : sd_lds_bytes<bf16_t>(C);
+    void (*kern)(SdArgs) = nullptr;
+    if (dtype == 0) kern = in_dtype == 0 ? stem_dw_kernel<float, 0> : in_dtype == 1 ? stem_dw_kernel<float, 1> : stem_dw_kernel<float, 2>;
+    else kern = in_dtype == 0 ? stem_dw_kernel<bf16_t, 0> : in_dtype == 1 ? stem_dw_kernel<bf16_t, 1> : stem_dw_kernel<bf16_t, 2>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return EFFDET_ELAUNCH;
     }
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     return effdet_check_launch();
 }
 
