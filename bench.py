@@ -123,20 +123,27 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
-    dev = torch.device('cuda', local_rank)
+    # EFFDET_DIST_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks
+    # (ranks then share devices round-robin); the real runs use RCCL, one rank per GPU.
+    backend = os.environ.get('EFFDET_DIST_BACKEND', 'nccl')
+    dev = torch.device('cuda', local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from ood_object_detection_amd.effdet.bench import DetBenchPredict
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     model = build_model(args.model, args.image, args.classes)
     cfg = model.config
     cfg.soft_nms = bool(args.soft_nms)
-    sd_cpu = {k: v.clone().float() for k, v in model.state_dict().items()} if (rank == 0 and not args.no_cpu_baseline) else None
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline       # the CPU baseline is an N=1 item
+    sd_cpu = {k: v.clone().float() for k, v in model.state_dict().items()} if want_cpu else None
     model = model.to(dev).to(dtype)
     bench = DetBenchPredict(model).to(dev)
     B = args.batch
@@ -182,7 +189,7 @@ def main():
         elapsed = time.perf_counter() - t0
 
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank != 0:
@@ -269,7 +276,7 @@ def main():
                     k, f['launches'], f['ms'], f['bytes'] / 1e9, f['bytes'] / f['ms'] / 1e6, f['flops'] / f['ms'] / 1e9))
             fh.write('# network (sum of launches) ms %.3f ; timed step ms %.3f (adds top-k/decode/NMS/OOD gather)\n' % (net_ms, ms_per_step))
     cpu = None
-    if not args.no_cpu_baseline:
+    if want_cpu:
         cpu = cpu_baseline(sd_cpu, cfg, args.image, args.classes)
     out = {
         'metric': 'images/sec, %s %dpx %s inference + OOD score (DetBenchPredict end-to-end)' % (args.model, args.image, args.dtype),
