@@ -81,6 +81,18 @@ template <> DEV void store8<bf16_t>(bf16_t* p, const F8& r) {
     for (int i = 0; i < 8; ++i) a[i] = (bf16_t)r.v[i];
     *reinterpret_cast<bf16x8*>(p) = a;
 }
+// 4 consecutive elements (8 bytes of bf16 / 16 bytes of f32): the accumulator piece of one lane after an MFMA
+template <typename T>
+DEV void store4(T* p, float a, float b, float c, float d) {
+    if constexpr (sizeof(T) == 2) {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        bf16x4 v = {(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+        *reinterpret_cast<bf16x4*>(p) = v;
+    } else {
+        *reinterpret_cast<f32x4*>(p) = f32x4{a, b, c, d};
+    }
+}
+
 DEV F8 f8_zero() { F8 r;
 #pragma unroll
     for (int i = 0; i < 8; ++i) r.v[i] = 0.f;

@@ -42,16 +42,6 @@ template <typename T> struct Pack4;
 template <> struct Pack4<bf16_t> { typedef unsigned long long type; };
 template <> struct Pack4<float> { typedef f32x4 type; };
 
-template <typename T>
-DEV void store4(T* p, float a, float b, float c, float d) {
-    if constexpr (sizeof(T) == 2) {
-        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-        bf16x4 v = {(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
-        *reinterpret_cast<bf16x4*>(p) = v;
-    } else {
-        *reinterpret_cast<f32x4*>(p) = f32x4{a, b, c, d};
-    }
-}
 
 // Spatial-tile form.  512 threads (8 waves) per workgroup: with the LDS footprint allowing two workgroups per
 // CU this keeps 4 waves per SIMD in flight, which the VALU-heavy epilogues (SiLU on every expanded element)

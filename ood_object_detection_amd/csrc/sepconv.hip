@@ -53,11 +53,47 @@ constexpr int FC = 64;    // channels per halo pass
 
 
 
+// 8 channels as loaded (16 bytes of bf16 / 32 bytes of f32): halo inputs wait in this form, so that a thread can keep
+// every load of a pass in flight without holding 8 converted floats per piece
+template <typename T> struct Raw8 { u32x4 v[sizeof(T) == 2 ? 1 : 2]; };
+template <typename T> DEV Raw8<T> load_raw8(const T* p) {
+    Raw8<T> r;
+    r.v[0] = *reinterpret_cast<const u32x4*>(p);
+    if constexpr (sizeof(T) == 4) r.v[1] = *(reinterpret_cast<const u32x4*>(p) + 1);
+    return r;
+}
+template <typename T> DEV F8 unpack8(const Raw8<T>& r) {
+    F8 o;
+    if constexpr (sizeof(T) == 2) {
+        const bf16x8 a = __builtin_bit_cast(bf16x8, r.v[0]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.v[e] = (float)a[e];
+    } else {
+        const f32x4 a = __builtin_bit_cast(f32x4, r.v[0]), b = __builtin_bit_cast(f32x4, r.v[1]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o.v[e] = a[e]; o.v[4 + e] = b[e]; }
+    }
+    return o;
+}
+template <typename T> DEV Raw8<T> pack8(const F8& f) {
+    Raw8<T> r;
+    if constexpr (sizeof(T) == 2) {
+        bf16x8 a;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = (bf16_t)f.v[e];
+        r.v[0] = __builtin_bit_cast(u32x4, a);
+    } else {
+        r.v[0] = __builtin_bit_cast(u32x4, f32x4{f.v[0], f.v[1], f.v[2], f.v[3]});
+        r.v[1] = __builtin_bit_cast(u32x4, f32x4{f.v[4], f.v[5], f.v[6], f.v[7]});
+    }
+    return r;
+}
+
 // 8 channels of input `in` (already offset to the image) at output-grid position (y, x)
 template <typename T>
-DEV F8 fetch_input(const T* base, const SepInput& in, int y, int x, int F, int c) {
-    if (in.mode == 0) return load8<T>(base + (y * in.W + x) * F + c);
-    if (in.mode == 1) return load8<T>(base + ((y >> 1) * in.W + (x >> 1)) * F + c);
+DEV Raw8<T> fetch_input(const T* base, const SepInput& in, int y, int x, int F, int c) {
+    if (in.mode == 0) return load_raw8<T>(base + (y * in.W + x) * F + c);
+    if (in.mode == 1) return load_raw8<T>(base + ((y >> 1) * in.W + (x >> 1)) * F + c);
     F8 m = f8_fill(-INFINITY);
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
@@ -72,7 +108,7 @@ DEV F8 fetch_input(const T* base, const SepInput& in, int y, int x, int F, int c
             for (int e = 0; e < 8; ++e) m.v[e] = fmaxf(m.v[e], v.v[e]);
         }
     }
-    return m;
+    return pack8<T>(m);                          // a maximum of stored values: exactly representable
 }
 
 // 8 consecutive output channels -> memory.  Rows are only guaranteed dword aligned (e.g. 1620-byte class
@@ -115,7 +151,11 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void sepconv_kernel(SepArg
     const int nkc = (fbytes + 63) / 64;
     const int arow = nkc * 64 + 16;              // A / W row pitch in bytes
     // LDS carve (all multiples of 16): the halo tile (phases 1-2) and the W chunk (phase 3) share a region
-    constexpr int HALO_BYTES = HW_ * FC * (int)sizeof(T);
+    // bf16 runs the depthwise taps on the matrix cores (see mbconv.hip): 16 pixels x 16 bytes per operand read, so the
+    // halo rows get 16 bytes of padding to spread the pixels over the LDS banks
+    constexpr bool MF = sizeof(T) == 2 && TW == 16 && NTH == 512;
+    constexpr int HROW = FC + (MF ? 8 : 0);          // halo row pitch in elements
+    constexpr int HALO_BYTES = HW_ * HROW * (int)sizeof(T);
     const int r0 = HALO_BYTES > BN * arow ? HALO_BYTES : BN * arow;
     char* halo = lds;
     char* Wt = lds;
@@ -166,9 +206,9 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void sepconv_kernel(SepArg
         __syncthreads();
         // HU halo items per step: their input loads are all issued before the first use (the loop has a runtime
         // trip count, so the compiler would otherwise expose one memory round trip per item)
-        constexpr int HU = NTH == 512 ? 1 : 2;
+        constexpr int HU = NTH == 512 ? 3 : 2;              // bf16 tile: all 1440 items of a 64-channel pass in one batch
         for (int it0 = tid; it0 < HW_ * fcg; it0 += HU * NTH) {
-            F8 xin[HU][3];
+            Raw8<T> xin[HU][3];
             bool ok[HU];
 #pragma unroll
             for (int u = 0; u < HU; ++u) {
@@ -191,17 +231,18 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void sepconv_kernel(SepArg
                 F8 v = f8_zero();
                 if (ok[u]) {
                     if (p.fuse_mode == 0) {
-                        v = xin[u][0];
+                        v = unpack8<T>(xin[u][0]);
                     } else {
 #pragma unroll
                         for (int i = 0; i < 3; ++i) {
                             if (i < p.n_in) {
+                                const F8 xi = unpack8<T>(xin[u][i]);
                                 if (divide) {
 #pragma unroll
-                                    for (int e = 0; e < 8; ++e) v.v[e] += (xin[u][i].v[e] * fwm[i]) / p.fden;
+                                    for (int e = 0; e < 8; ++e) v.v[e] += (xi.v[e] * fwm[i]) / p.fden;
                                 } else {
 #pragma unroll
-                                    for (int e = 0; e < 8; ++e) v.v[e] = fmaf(xin[u][i].v[e], fwm[i], v.v[e]);
+                                    for (int e = 0; e < 8; ++e) v.v[e] = fmaf(xi.v[e], fwm[i], v.v[e]);
                                 }
                             }
                         }
@@ -211,7 +252,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void sepconv_kernel(SepArg
                         for (int e = 0; e < 8; ++e) v.v[e] = silu_t<T>(v.v[e]);
                     }
                 }
-                store8<T>(reinterpret_cast<T*>(halo) + hp * FC + cgh * 8, v);
+                store8<T>(reinterpret_cast<T*>(halo) + hp * HROW + cgh * 8, v);
             }
         }
         if (fc0 == 0) {
@@ -226,6 +267,44 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void sepconv_kernel(SepArg
             }
         }
         __syncthreads();
+        if constexpr (MF) {
+            // depthwise 3x3 on the matrix cores: wave (j, part) owns channel tile j of this pass and half of the
+            // 16-pixel rows of the tile; A = diag(w[t0]) | diag(w[t1]) per pair of taps, B = the halo pixels shifted
+            // by those taps; the accumulator (4 channels x 1 pixel per lane) goes straight into the A tile.
+            const int frow_ = lane & 15, fp_ = lane >> 4;
+            const int j = wave & 3, part = wave >> 2;
+            if (16 * j < fcn) {
+                const int hi = fp_ >> 1;
+                const bool active = (fp_ & 1) == (frow_ >> 3);
+                const int dq = (frow_ & 7) >> 1;
+                Frag<T> afr[5];
+#pragma unroll
+                for (int pr = 0; pr < 5; ++pr) {
+                    const int t = 2 * pr + hi;
+                    const bool on = active && t < 9 && 16 * j + frow_ < fcn;
+                    const float wv = on ? dww[(t < 9 ? t : 0) * F + fc0 + 16 * j + frow_] : 0.f;
+                    const unsigned bits = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)wv) << (16 * (frow_ & 1));
+                    const u32x4 fr = {dq == 0 ? bits : 0u, dq == 1 ? bits : 0u, dq == 2 ? bits : 0u, dq == 3 ? bits : 0u};
+                    afr[pr].v = __builtin_bit_cast(bf16x8, fr);
+                }
+                const char* hb = halo + (frow_ * HROW + 16 * j + 8 * (fp_ & 1)) * (int)sizeof(T);
+#pragma unroll
+                for (int pt = 0; pt < TH / 2; ++pt) {
+                    const int ty = part * (TH / 2) + pt;             // TW == 16: a pixel tile is one row of the output tile
+                    const char* base = hb + ty * (TW + 2) * HROW * (int)sizeof(T);
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int pr = 0; pr < 5; ++pr) {
+                        constexpr int RB = (TW + 2) * HROW * (int)sizeof(T), CB = HROW * (int)sizeof(T);
+                        const int t0 = 2 * pr, t1 = 2 * pr + 1 < 9 ? 2 * pr + 1 : 0;
+                        const int off = hi ? (t1 / 3) * RB + (t1 % 3) * CB : (t0 / 3) * RB + (t0 % 3) * CB;
+                        mma_chunk(afr[pr], ld_frag<T>(base + off), acc);
+                    }
+                    if (16 * j + 4 * fp_ < fcn)
+                        store4<T>(reinterpret_cast<T*>(At + (16 * ty + frow_) * arow) + fc0 + 16 * j + 4 * fp_, acc[0], acc[1], acc[2], acc[3]);
+                }
+            }
+        } else {
         for (int it = tid; it < BM * fcg; it += NTH) {
             const int cg = it % fcg, px = it / fcg;
             const int ty = px / TW, tx = px % TW;
@@ -234,12 +313,13 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void sepconv_kernel(SepArg
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const F8 xv = load8<T>(reinterpret_cast<const T*>(halo) + ((ty + ky) * (TW + 2) + tx + kx) * FC + cg * 8);
+                    const F8 xv = load8<T>(reinterpret_cast<const T*>(halo) + ((ty + ky) * (TW + 2) + tx + kx) * HROW + cg * 8);
                     const F8 w = load8<float>(dww + (ky * 3 + kx) * F + fc0 + cg * 8);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) acc.v[e] = fmaf(xv.v[e], w.v[e], acc.v[e]);
                 }
             store8<T>(reinterpret_cast<T*>(At + px * arow) + fc0 + cg * 8, acc);
+        }
         }
     }
 
@@ -434,7 +514,7 @@ size_t sep_lds_bytes(int F) {
     constexpr int HW_ = (TH + 2) * (TW + 2);
     const int nkc = (F * (int)sizeof(T) + 63) / 64;
     const int arow = nkc * 64 + 16;
-    const size_t halo = (size_t)HW_ * FC * sizeof(T);
+    const size_t halo = (size_t)HW_ * (FC + (sizeof(T) == 2 && TW == 16 ? 8 : 0)) * sizeof(T);
     const size_t wt = (size_t)BN * arow;
     return (halo > wt ? halo : wt) + (size_t)BM * arow + (size_t)9 * F * 4 + (size_t)2 * BN * 4;
 }
