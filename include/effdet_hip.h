@@ -89,6 +89,15 @@ int effdet_mbconv_expand_dw(void* stream, int dtype, const void* X, void* Y, con
                             const float* s2, const float* t2, float* pool_partial,
                             int B, int H, int W, int Cin, int mid, int k, int stride);
 int effdet_mbconv_tiles_per_image(int dtype, int H, int W, int Cin, int mid, int k, int stride);
+/* The same with X multiplied by a per-image channel gate [B][Cin] (rounded to dtype) while it is loaded.  Lets a
+ * squeeze-excited, residual-free block hand its depthwise output straight to the next block: its project conv +
+ * BN (both linear) are folded into W1 / t1 by the caller, so the narrow tensor in between is never written.
+ * Always the spatial-tile geometry: size pool_partial with effdet_mbconv_gated_tiles_per_image. */
+int effdet_mbconv_expand_dw_gated(void* stream, int dtype, const void* X, const float* in_gate, void* Y, const void* W1,
+                                  const float* s1, const float* t1, const float* taps,
+                                  const float* s2, const float* t2, float* pool_partial,
+                                  int B, int H, int W, int Cin, int mid, int k, int stride);
+int effdet_mbconv_gated_tiles_per_image(int dtype, int H, int W, int Cin, int mid, int k, int stride);
 
 /* SqueezeExcite gate: mean -> fc(C->R)+SiLU -> fc(R->C) -> sigmoid.  W1: [R][C] (conv_reduce weight),
  * W2t: [R][C] (conv_expand weight TRANSPOSED, so that consecutive threads read consecutive channels). */

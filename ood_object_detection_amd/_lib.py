@@ -34,6 +34,9 @@ SIGNATURES = {
     'effdet_dwconv_bn_act': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                      c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
     'effdet_dwconv_blocks_per_image': (c_int, [c_int, c_int, c_int]),
+    'effdet_mbconv_gated_tiles_per_image': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    'effdet_mbconv_expand_dw_gated': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'effdet_mbconv_expand_dw': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'effdet_mbconv_tiles_per_image': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),

@@ -19,6 +19,7 @@ namespace {
 
 struct MbArgs {
     const void* X; void* Y;
+    const float* in_gate;                       // optional [B][Cin]: X is multiplied by it (rounded to T) while the tile is loaded
     const void* W1;                             // [mid][Cin]  (T)
     const float* s1; const float* t1;           // [mid]
     const float* taps;                          // [k*k][mid]
@@ -99,8 +100,23 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
                     const int hy = fdiv(hp, p.fd_iw);
                     const int y = iy0 + hy, x = ix0 + hp - hy * p.IW;
                     inside = y >= 0 && y < p.H && x >= 0 && x < p.W;
-                    if (inside)
+                    if (inside) {
                         v[u] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(X + ((long long)y * p.W + x) * Cin) + piece * 16);
+                        if (p.in_gate != nullptr) {            // SE gate of the producing block (its project conv was folded into W1)
+                            const float* g = p.in_gate + (long long)b * Cin + piece * (16 / (int)sizeof(T));
+                            if constexpr (sizeof(T) == 2) {
+                                bf16x8 xv = __builtin_bit_cast(bf16x8, v[u]);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) xv[e] = (bf16_t)((float)xv[e] * g[e]);
+                                v[u] = __builtin_bit_cast(u32x4, xv);
+                            } else {
+                                f32x4 xv = __builtin_bit_cast(f32x4, v[u]);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) xv[e] *= g[e];
+                                v[u] = __builtin_bit_cast(u32x4, xv);
+                            }
+                        }
+                    }
                 }
                 if (piece == 0) msk[hp] = inside ? 1.f : 0.f;
             }
@@ -758,7 +774,7 @@ int launch_deep(hipStream_t st, const MbArgs& a, const DeepGeometry& g) {
 template <typename T>
 int launch_mb(hipStream_t st, MbArgs& a) {
     const DeepGeometry dg = pick_deep<T>(a.H, a.W, a.Cin, a.mid, a.k, a.stride);
-    if (dg.use) return launch_deep<T>(st, a, dg);
+    if (dg.use && !a.in_gate) return launch_deep<T>(st, a, dg);                    // gated inputs always take the spatial form
     const Geometry g = pick_tile<T>(a.Ho, a.Wo, a.Cin, a.k, a.stride);
     if (g.lds > 160 * 1024) return EFFDET_EINVAL;
     a.TH = g.TH; a.TW = g.TW; a.IH = g.IH; a.IW = g.IW; a.HP = g.HP; a.HPpad = g.HPpad; a.arow = g.arow; a.e_bytes = g.e_bytes;
@@ -792,15 +808,22 @@ extern "C" int effdet_mbconv_tiles_per_image(int dtype, int H, int W, int Cin, i
     return ((Wo + g.TW - 1) / g.TW) * ((Ho + g.TH - 1) / g.TH);
 }
 
-extern "C" int effdet_mbconv_expand_dw(void* stream, int dtype, const void* X, void* Y, const void* W1,
-                                       const float* s1, const float* t1, const float* taps,
-                                       const float* s2, const float* t2, float* pool_partial,
-                                       int B, int H, int W, int Cin, int mid, int k, int stride) {
-    EFFDET_ENTER();
+extern "C" int effdet_mbconv_gated_tiles_per_image(int dtype, int H, int W, int Cin, int mid, int k, int stride) {
+    if (H <= 0 || W <= 0 || Cin <= 0 || mid <= 0 || (k != 3 && k != 5) || (stride != 1 && stride != 2) || (dtype & ~1)) return EFFDET_EINVAL;
+    const int Ho = same_out(H, stride), Wo = same_out(W, stride);
+    const Geometry g = dtype == 0 ? pick_tile<float>(Ho, Wo, Cin, k, stride) : pick_tile<bf16_t>(Ho, Wo, Cin, k, stride);
+    if (g.lds > 160 * 1024 || mid % SM_MC) return EFFDET_EINVAL;
+    return ((Wo + g.TW - 1) / g.TW) * ((Ho + g.TH - 1) / g.TH);
+}
+
+static int mbconv_common(void* stream, int dtype, const void* X, const float* in_gate, void* Y, const void* W1,
+                         const float* s1, const float* t1, const float* taps,
+                         const float* s2, const float* t2, float* pool_partial,
+                         int B, int H, int W, int Cin, int mid, int k, int stride) {
     if (!X || !Y || !W1 || !s1 || !t1 || !taps || !s2 || !t2 || B <= 0 || H <= 0 || W <= 0) return EFFDET_EINVAL;
     if (Cin <= 0 || Cin % 8 || mid <= 0 || mid % 8 || (k != 3 && k != 5) || (stride != 1 && stride != 2) || (dtype & ~1)) return EFFDET_EINVAL;
     MbArgs a;
-    a.X = X; a.Y = Y; a.W1 = W1; a.s1 = s1; a.t1 = t1; a.taps = taps; a.s2 = s2; a.t2 = t2; a.pool_partial = pool_partial;
+    a.X = X; a.in_gate = in_gate; a.Y = Y; a.W1 = W1; a.s1 = s1; a.t1 = t1; a.taps = taps; a.s2 = s2; a.t2 = t2; a.pool_partial = pool_partial;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.mid = mid; a.k = k; a.stride = stride;
     a.Ho = same_out(H, stride); a.Wo = same_out(W, stride);
     a.pad_t = same_pad_before(H, k, stride); a.pad_l = same_pad_before(W, k, stride);
@@ -808,4 +831,21 @@ extern "C" int effdet_mbconv_expand_dw(void* stream, int dtype, const void* X, v
     a.dbg = dbg;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return dtype == 0 ? launch_mb<float>(st, a) : launch_mb<bf16_t>(st, a);
+}
+
+extern "C" int effdet_mbconv_expand_dw(void* stream, int dtype, const void* X, void* Y, const void* W1,
+                                       const float* s1, const float* t1, const float* taps,
+                                       const float* s2, const float* t2, float* pool_partial,
+                                       int B, int H, int W, int Cin, int mid, int k, int stride) {
+    EFFDET_ENTER();
+    return mbconv_common(stream, dtype, X, nullptr, Y, W1, s1, t1, taps, s2, t2, pool_partial, B, H, W, Cin, mid, k, stride);
+}
+
+extern "C" int effdet_mbconv_expand_dw_gated(void* stream, int dtype, const void* X, const float* in_gate, void* Y, const void* W1,
+                                             const float* s1, const float* t1, const float* taps,
+                                             const float* s2, const float* t2, float* pool_partial,
+                                             int B, int H, int W, int Cin, int mid, int k, int stride) {
+    EFFDET_ENTER();
+    if (!in_gate) return EFFDET_EINVAL;
+    return mbconv_common(stream, dtype, X, in_gate, Y, W1, s1, t1, taps, s2, t2, pool_partial, B, H, W, Cin, mid, k, stride);
 }

@@ -150,8 +150,21 @@ class Engine(object):
                 h, w = ho, wo
         ping = [self._new(io_max), self._new(io_max)]
         dbuf = self._new(max(mid_max, 1))
+        # Stage 0 = one residual-free depthwise-separable block followed by a residual-free MBConv block: the first
+        # block's project conv + BN (linear) are folded into the second block's expand weights and its SE gate is
+        # applied while that kernel loads its input tile, so the narrow tensor in between never exists.
+        b00, b10 = stages[0][0], (stages[1][0] if len(stages) > 1 else None)
+        self._compose01 = bool(len(stages[0]) == 1 and b10 is not None and b00['type'] == 'ds' and not b00['residual']
+                               and b10['type'] == 'ir' and not b10['residual'] and b00['mid'] % 8 == 0 and
+                               lib.effdet_mbconv_gated_tiles_per_image(dt, Hs, Ws, b00['mid'], b10['mid'], b10['k'], b10['s']) > 0)
+        dbuf2 = None
+        if self._compose01:
+            h1, w1_ = _same_out(Hs, b10['s']), _same_out(Ws, b10['s'])
+            dbuf2 = self._new(B * h1 * w1_ * b10['mid'])
+            part_max = max(part_max, B * lib.effdet_mbconv_gated_tiles_per_image(dt, Hs, Ws, b00['mid'], b10['mid'], b10['k'], b10['s']) * b10['mid'])
         ebuf = self._new(exp_max) if exp_max else None
         partial = self._new(part_max, dtype=torch.float32)
+        composed = None          # (W_proj folded, t3) of block 0.0 while block 1.0 is being planned
         gate_max = B * max(b['mid'] for blocks in stages for b in blocks)
         gate = self._new(gate_max, dtype=torch.float32)
 
@@ -189,20 +202,43 @@ class Engine(object):
                     out = self._new(B, ho, wo, b['cout'])
                     self.feats.append(out)
                 else:
-                    out = ping[1] if cur.data_ptr() == ping[0].data_ptr() else ping[0]
+                    out = ping[1] if (cur is not None and cur.data_ptr() == ping[0].data_ptr()) else ping[0]
                 what = 'backbone.blocks.%d.%d' % (si, bi)
                 es = self.pyr_es
                 if b['type'] == 'ir':
                     # fused expand 1x1 + BN + SiLU -> depthwise + BN + SiLU (+ SE pool partials); the expanded
                     # activation stays in LDS
                     s1, t1 = self._fold(m.bn1)
-                    w1 = self._w(m.conv_pw.weight.reshape(b['mid'], b['cin']))
-                    s1, t1 = self._f32(s1), self._f32(t1)
                     s2, t2 = self._fold(m.bn2)
                     taps = self._f32(self._dw_taps(m.conv_dw.weight))
                     s2, t2 = self._f32(s2), self._f32(t2)
-                    nblk = lib.effdet_mbconv_tiles_per_image(dt, h, w, b['cin'], b['mid'], b['k'], b['s'])
-                    if nblk > 0:
+                    if composed is not None:
+                        # expand(project(x)) = W_e (S3 W_p (g*x) + t3) = (W_e S3 W_p)(g*x) + W_e t3: one conv over the
+                        # previous block's gated depthwise output; the constant goes into the BN shift
+                        wp, s3c, t3c, cmid = composed
+                        we = m.conv_pw.weight.detach().reshape(b['mid'], b['cin']).to(device=self.device, dtype=torch.float32)
+                        wcomb = we @ (s3c.view(-1, 1) * wp)                           # [mid][cmid]
+                        t1 = t1.to(self.device) + s1.to(self.device) * (we @ t3c)
+                        w1 = self._w(wcomb)
+                        s1, t1 = self._f32(s1), self._f32(t1)
+                        nblk = lib.effdet_mbconv_gated_tiles_per_image(dt, h, w, cmid, b['mid'], b['k'], b['s'])
+                        plan.append((lib.effdet_mbconv_expand_dw_gated,
+                                     (dt, dbuf.data_ptr(), gate.data_ptr(), dbuf2.data_ptr(), w1.data_ptr(), s1.data_ptr(), t1.data_ptr(),
+                                      taps.data_ptr(), s2.data_ptr(), t2.data_ptr(), partial.data_ptr(),
+                                      B, h, w, cmid, b['mid'], b['k'], b['s']), what + '.conv_pw(+blocks.0.0.conv_pw)+conv_dw',
+                                     dict(kind='mbconv', bytes=B * (h * w * cmid + ho * wo * b['mid']) * es + b['mid'] * cmid * es,
+                                          flops=2 * B * (h * w * cmid * b['mid'] + b['k'] * b['k'] * ho * wo * b['mid']))))
+                        composed = None
+                        mid_buf = dbuf2
+                        pw_out, bn_out = m.conv_pwl, m.bn3
+                    else:
+                      w1 = self._w(m.conv_pw.weight.reshape(b['mid'], b['cin']))
+                      s1, t1 = self._f32(s1), self._f32(t1)
+                      nblk = lib.effdet_mbconv_tiles_per_image(dt, h, w, b['cin'], b['mid'], b['k'], b['s'])
+                      mid_buf = dbuf
+                    if mid_buf is dbuf2:
+                        pass
+                    elif nblk > 0:
                         plan.append((lib.effdet_mbconv_expand_dw,
                                      (dt, cur.data_ptr(), dbuf.data_ptr(), w1.data_ptr(), s1.data_ptr(), t1.data_ptr(),
                                       taps.data_ptr(), s2.data_ptr(), t2.data_ptr(), partial.data_ptr(),
@@ -224,6 +260,7 @@ class Engine(object):
                 elif si == 0 and bi == 0 and self._fuse_stem:
                     nblk = lib.effdet_stem_dw_tiles_per_image(H, W)       # launched by run_backbone (takes x)
                     pw_out, bn_out = m.conv_pw, m.bn2
+                    mid_buf = dbuf
                 else:
                     s2, t2 = self._fold(m.bn1)
                     taps = self._f32(self._dw_taps(m.conv_dw.weight))
@@ -235,6 +272,7 @@ class Engine(object):
                                  dict(kind='dwconv', bytes=B * (h * w + ho * wo) * b['mid'] * es,
                                       flops=2 * b['k'] * b['k'] * B * ho * wo * b['mid'])))
                     pw_out, bn_out = m.conv_pw, m.bn2
+                    mid_buf = dbuf
                 W1 = self._f32(m.se.conv_reduce.weight.reshape(b['se'], b['mid']))
                 b1 = self._f32(m.se.conv_reduce.bias)
                 W2 = self._f32(m.se.conv_expand.weight.reshape(b['mid'], b['se']).t())      # [R][C]: coalesced over channels
@@ -245,10 +283,16 @@ class Engine(object):
                              dict(kind='se_gate', bytes=B * (nblk + 1) * b['mid'] * 4 + 8 * b['mid'] * b['se'],
                                   flops=4 * B * b['mid'] * b['se'])))
                 s3, t3 = self._fold(bn_out)
+                if si == 0 and bi == 0 and self._compose01 and self._fuse_stem:
+                    # no project launch: hand (W_p, s3, t3) to the next block (see above)
+                    composed = (pw_out.weight.detach().reshape(b['cout'], b['mid']).to(device=self.device, dtype=torch.float32),
+                                s3.to(device=self.device, dtype=torch.float32), t3.to(device=self.device, dtype=torch.float32), b['mid'])
+                    cur, h, w = None, ho, wo
+                    continue
                 w3 = self._w(pw_out.weight.reshape(b['cout'], b['mid']))
                 s3, t3 = self._f32(s3), self._f32(t3)
                 plan.append((lib.effdet_pw_gemm_bn_act,
-                             (dt, dbuf.data_ptr(), B * ho * wo, b['mid'], w3.data_ptr(), b['cout'], s3.data_ptr(),
+                             (dt, mid_buf.data_ptr(), B * ho * wo, b['mid'], w3.data_ptr(), b['cout'], s3.data_ptr(),
                               t3.data_ptr(), 0, cur.data_ptr() if b['residual'] else None, gate.data_ptr(), ho * wo,
                               out.data_ptr(), 0, 0), what + '.conv_pwl',
                              self._gemm_meta(B * ho * wo, b['mid'], b['cout'], residual=b['residual'], gate=True)))
