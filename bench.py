@@ -202,13 +202,19 @@ def main():
     value = world * B * args.steps / elapsed
     counts = bench.last_count.float()
     # ---- roofline of the dominant kernel family (HIP events on the launch stream) -------------------
+    # The timed step may run as concurrent half-batches (DetBenchPredict streams); the per-launch table is taken
+    # on a full-batch launch plan of the same weights, one launch at a time, so that bytes and times per launch
+    # refer to the same thing as the rocprofv3 / PMC summaries under profiles/.
+    import copy
+    pmodel = copy.copy(model)
+    pbench = DetBenchPredict(pmodel, streams=1).to(dev)
     with torch.no_grad():
-        bench(x)
-        prof = model._engine.profile(reps=5)
+        pbench(x)
+        prof = pmodel._engine.profile(reps=5)
     # the launches outside the engine plans: stem conv, top-k, decode + NMS + OOD gather
     from ood_object_detection_amd.effdet.bench import _post_process
     from ood_object_detection_amd.effdet.anchors import batched_detections
-    eng = model._engine
+    eng = pmodel._engine
     es = 2 if args.dtype == 'bf16' else 4
 
     def timed(fn, reps=5):
@@ -287,6 +293,7 @@ def main():
                                % (args.model, args.image, args.image, B, args.classes, 'soft' if args.soft_nms else 'hard'),
                    'global_batch': world * B, 'parallelism': 'image-sharded dp%d, no collective' % world,
                    'weights': 'seeded reference init, randomised BN stats, class bias 0', 'launch': launch,
+                   'execution': '%d concurrent sub-batches on separate streams' % (bench.streams or (2 if B >= 16 and B % 2 == 0 else 1)),
                    'detections_per_image_mean': round(float(counts.mean()), 1)},
         'roofline': roofline, 'cpu_baseline': cpu,
     }

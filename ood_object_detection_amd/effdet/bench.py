@@ -68,7 +68,12 @@ def _packed(outs, num_levels, width):
 
 
 class DetBenchPredict(nn.Module):
-    def __init__(self, model):
+    """`streams` (extension, default: automatic): with two streams the batch is processed as two concurrent
+    half-batches - images are independent, so results are identical - and the narrow, latency-bound launches of
+    one half (SE gates, top-k sort, NMS: 64 workgroups on a 256-CU chip) overlap with the wide kernels of the
+    other.  The halves run on shallow copies of the model (same parameters, own launch plans and buffers)."""
+
+    def __init__(self, model, streams=None):
         super().__init__()
         self.model = model
         self.config = model.config
@@ -78,36 +83,84 @@ class DetBenchPredict(nn.Module):
         self.max_detection_points = model.config.max_detection_points
         self.max_det_per_image = model.config.max_det_per_image
         self.soft_nms = model.config.soft_nms
+        self.streams = streams
         self.last_count = None
         self.last_ood = None
+        self._replicas = None       # [(model copy, stream)], built on first use
+        self._ood_buf = None
 
-    def forward(self, x, img_info: Optional[Dict[str, torch.Tensor]] = None):
+    def _one(self, model, x, img_scale, img_size):
+        """One (sub-)batch: model -> top-k -> decode -> NMS -> OOD gather."""
         lib = _lib.load()
-        if tuple(x.shape[2:]) != tuple(self.anchors.image_size):
-            # the anchors follow the actual input size (the reference needs config.image_size == input size)
-            self.anchors = Anchors(self.config.min_level, self.config.max_level, self.config.num_scales,
-                                   self.config.aspect_ratios, self.config.anchor_scale, tuple(x.shape[2:])).to(x.device)
-        class_out, box_out = self.model(x)
+        class_out, box_out = model(x)
         cls_topk, box_topk, indices, classes = _post_process(
             class_out, box_out, num_levels=self.num_levels, num_classes=self.num_classes,
-            max_detection_points=self.max_detection_points, anchor_max=self.model.ood_max_logit)
-        if img_info is None:
-            img_scale, img_size = None, None
-        else:
-            img_scale, img_size = img_info['img_scale'], img_info['img_size']
+            max_detection_points=self.max_detection_points, anchor_max=model.ood_max_logit)
         B, k = indices.shape
         det, count, keep_src = batched_detections(
             cls_topk.reshape(B, k), box_topk, self.anchors.boxes, indices, classes, img_scale, img_size,
             max_det_per_image=self.max_det_per_image, soft_nms=self.soft_nms)
-        self.last_count = count
         energy = torch.empty(B, self.max_det_per_image, dtype=torch.float32, device=x.device)
         maxlogit = torch.empty_like(energy)
         st = torch.cuda.current_stream(x.device).cuda_stream
-        _lib.check(lib.effdet_gather_ood(st, keep_src.data_ptr(), indices.data_ptr(), self.model.ood_energy.data_ptr(),
-                                         self.model.ood_max_logit.data_ptr(), self.model.ood_energy.shape[1], B, k,
+        _lib.check(lib.effdet_gather_ood(st, keep_src.data_ptr(), indices.data_ptr(), model.ood_energy.data_ptr(),
+                                         model.ood_max_logit.data_ptr(), model.ood_energy.shape[1], B, k,
                                          self.max_det_per_image, energy.data_ptr(), maxlogit.data_ptr()), 'effdet_gather_ood')
-        self.last_ood = {'energy': energy, 'max_logit': maxlogit, 'anchor_energy': self.model.ood_energy,
-                         'anchor_max_logit': self.model.ood_max_logit}
+        return det, count, energy, maxlogit
+
+    def _split_setup(self, x, n):
+        """Shallow model copies (shared parameters) with engines that write their OOD rows into one [B, N] buffer."""
+        import copy
+        B, size = x.shape[0], (x.shape[2], x.shape[3])
+        N = self.anchors.boxes.shape[0]
+        key = (B, size, n, x.device, self.model._wver[0], self.num_classes)
+        if self._replicas is not None and self._replicas[0] == key and all(rep._engine is eng for rep, _, eng in self._replicas[1]):
+            return self._replicas[1]
+        e = torch.empty(B, N, dtype=torch.float32, device=x.device)
+        m = torch.empty(B, N, dtype=torch.float32, device=x.device)
+        self._ood_buf = (e, m)
+        Bh = B // n
+        reps = []
+        for i in range(n):
+            rep = self.model if i == 0 else copy.copy(self.model)
+            eng = rep.prepare(Bh, size, ood_out=(e[i * Bh:(i + 1) * Bh], m[i * Bh:(i + 1) * Bh]))
+            reps.append((rep, torch.cuda.Stream(x.device), eng))
+        self._replicas = (key, reps)
+        return reps
+
+    def forward(self, x, img_info: Optional[Dict[str, torch.Tensor]] = None):
+        if tuple(x.shape[2:]) != tuple(self.anchors.image_size):
+            # the anchors follow the actual input size (the reference needs config.image_size == input size)
+            self.anchors = Anchors(self.config.min_level, self.config.max_level, self.config.num_scales,
+                                   self.config.aspect_ratios, self.config.anchor_scale, tuple(x.shape[2:])).to(x.device)
+        if img_info is None:
+            img_scale, img_size = None, None
+        else:
+            img_scale, img_size = img_info['img_scale'], img_info['img_size']
+        B = x.shape[0]
+        n = self.streams if self.streams is not None else (2 if B >= 16 and B % 2 == 0 else 1)
+        if n <= 1 or B % n or x.device.type != 'cuda':
+            det, count, energy, maxlogit = self._one(self.model, x, img_scale, img_size)
+            self.last_count = count
+            self.last_ood = {'energy': energy, 'max_logit': maxlogit, 'anchor_energy': self.model.ood_energy,
+                             'anchor_max_logit': self.model.ood_max_logit}
+            return det
+        reps = self._split_setup(x, n)
+        Bh = B // n
+        cur = torch.cuda.current_stream(x.device)
+        outs = []
+        for i, (rep, stream, _) in enumerate(reps):
+            sl = slice(i * Bh, (i + 1) * Bh)
+            stream.wait_stream(cur)
+            with torch.cuda.stream(stream):
+                outs.append(self._one(rep, x[sl], None if img_scale is None else img_scale[sl],
+                                      None if img_size is None else img_size[sl]))
+        for _, stream, _ in reps:
+            cur.wait_stream(stream)
+        det = torch.cat([o[0] for o in outs], 0)
+        self.last_count = torch.cat([o[1] for o in outs], 0)
+        self.last_ood = {'energy': torch.cat([o[2] for o in outs], 0), 'max_logit': torch.cat([o[3] for o in outs], 0),
+                         'anchor_energy': self._ood_buf[0], 'anchor_max_logit': self._ood_buf[1]}
         return det
 
     def ragged(self, det):

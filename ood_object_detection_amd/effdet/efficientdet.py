@@ -277,6 +277,7 @@ class EfficientDet(nn.Module):
             if 'backbone' not in n:
                 (_init_weight_alt if alternate_init else _init_weight)(m, n)
         self._engine = None
+        self._wver = [0]            # bumped whenever parameters may have changed; shared by shallow copies of the model
         self.ood_energy = None
         self.ood_max_logit = None
         # normalisation applied when a raw uint8 batch is passed to forward (effdet/data/loader.py:114-128)
@@ -288,9 +289,11 @@ class EfficientDet(nn.Module):
     def invalidate(self):
         """Drop packed weights; call after changing parameters in place (load_state_dict does it)."""
         self._engine = None
+        self._wver[0] += 1
 
     def _apply(self, fn, *a, **k):
         self._engine = None
+        self._wver[0] += 1
         return super()._apply(fn, *a, **k)
 
     def __getstate__(self):
@@ -299,16 +302,16 @@ class EfficientDet(nn.Module):
         d['_engine'] = None
         return d
 
-    def prepare(self, batch_size, image_size=None):
+    def prepare(self, batch_size, image_size=None, ood_out=None):
         """Fold BN, repack weights to the kernel layouts and build the launch plan."""
         from ..engine import Engine
         image_size = tuple(image_size or self.config.image_size)
-        self._engine = Engine(self, int(batch_size), image_size)
+        self._engine = Engine(self, int(batch_size), image_size, ood_out=ood_out)
         return self._engine
 
     def engine_for(self, batch_size, image_size):
         e = self._engine
-        if e is None or e.B != batch_size or e.image_size != tuple(image_size) or not e.matches(self):
+        if e is None or e.B != batch_size or e.image_size != tuple(image_size) or not e.matches(self) or e.wver != self._wver[0]:
             e = self.prepare(batch_size, image_size)
         return e
 

@@ -32,8 +32,10 @@ def _arr(ctype, values):
 
 
 class Engine(object):
-    def __init__(self, model, B, image_size):
+    def __init__(self, model, B, image_size, ood_out=None):
         cfg = model.config
+        self._ood_out = ood_out
+        self.wver = getattr(model, '_wver', [0])[0]          # weights version the packed copies were made from
         p0 = model.backbone.conv_stem.weight
         if p0.device.type != 'cuda':
             raise RuntimeError('the EfficientDet HIP path needs the model on a GPU (cuda:N); there is no CPU fallback')
@@ -529,8 +531,14 @@ class Engine(object):
         self.N = N
         self.cls_all = self._new(B, N, C)
         self.box_all = self._new(B, N, 4)
-        self.ood_energy = self._new(B, N, dtype=torch.float32)
-        self.ood_max_logit = self._new(B, N, dtype=torch.float32)
+        if self._ood_out is not None:                      # caller-provided [B, N] float32 views (DetBenchPredict's split batches)
+            self.ood_energy, self.ood_max_logit = self._ood_out
+            if tuple(self.ood_energy.shape) != (B, N) or tuple(self.ood_max_logit.shape) != (B, N) or not self.ood_energy.is_contiguous() \
+                    or not self.ood_max_logit.is_contiguous() or self.ood_energy.dtype != torch.float32:
+                raise ValueError('ood_out must be two contiguous float32 [B, N] tensors')
+        else:
+            self.ood_energy = self._new(B, N, dtype=torch.float32)
+            self.ood_max_logit = self._new(B, N, dtype=torch.float32)
         t1, t2 = self._new(B, P, F), self._new(B, P, F)
         es = self.pyr.element_size()
 
