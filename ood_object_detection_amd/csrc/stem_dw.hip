@@ -27,6 +27,7 @@ struct SdArgs {
     const float* s2; const float* t2;            // depthwise BN fold [C]
     void* Y; float* pool_partial;                // [B,Ho,Wo,C], [B][tiles][C]
     int B, H, W, C, Ho, Wo, pad_t, pad_l, tiles_x, tiles_y;
+    int vec_in;                                  // bf16 input, even W and pad_l, 4-byte aligned: the patch is loaded two pixels at a time
 };
 
 constexpr int SD_TH = 16, SD_TW = 16;
@@ -34,6 +35,7 @@ constexpr int SD_HH = SD_TH + 2, SD_HW = SD_TW + 2;          // stem-output halo
 constexpr int SD_HP = SD_HH * SD_HW;                         // 324
 constexpr int SD_HPPAD = (SD_HP + 15) / 16 * 16;             // 336
 constexpr int SD_IH = 2 * SD_TH + 5, SD_IW = 2 * SD_TW + 5;  // input patch 37 x 37
+constexpr int SD_IWP = SD_IW + 1;                            // LDS row pitch (even: rows can be filled two elements at a time)
 
 // IN: input dtype at compile time (0 = f32, 1 = bf16, 2 = uint8 normalised on the fly): keeps the patch gather a
 // straight batch of loads
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(SdArgs p) {
     const int cpad = (C + 15) / 16 * 16;
     const int erow = C + 16 / (int)sizeof(T);                // E row pitch in elements (+16 B: bank spread)
     T* In = reinterpret_cast<T*>(lds);                                       // [3][IH][IW] (+ zero slot)
-    constexpr int IN_ELEMS = 3 * SD_IH * SD_IW + 8;
+    constexpr int IN_ELEMS = 3 * SD_IH * SD_IWP + 8;
     char* Wl = lds + ((IN_ELEMS * (int)sizeof(T) + 15) / 16) * 16;           // [cpad][WROW]
     T* E = reinterpret_cast<T*>(Wl + cpad * WROW);                           // [HP][erow]
     float* red = reinterpret_cast<float*>(reinterpret_cast<char*>(E) + ((SD_HP * erow * (int)sizeof(T) + 15) / 16) * 16);
@@ -66,18 +68,42 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(SdArgs p) {
     // loop with a runtime trip count is not pipelined by the compiler: every iteration would expose a full
     // memory round trip).
     const long long plane = (long long)p.H * p.W;
-    constexpr int IN_REAL = 3 * SD_IH * SD_IW;
+    constexpr int IN_REAL = 3 * SD_IH * SD_IWP;
     constexpr int IN_PER_THREAD = (IN_ELEMS + 255) / 256;
-    {
+    if (IN == 1 && sizeof(T) == 2 && p.vec_in) {
+        // bf16 -> bf16: whole dwords (two pixels of a row); ix0 is even, so a pair never straddles the image border
+        constexpr int DPR = SD_IWP / 2;                      // dwords per patch row
+        constexpr int NDW = 3 * SD_IH * DPR;
+        constexpr int DW_PER_THREAD = (NDW + 255) / 256;
+        unsigned dv[DW_PER_THREAD];
+#pragma unroll
+        for (int q = 0; q < DW_PER_THREAD; ++q) {
+            const int i = tid + 256 * q;
+            unsigned v = 0u;
+            if (i < NDW) {
+                const int row = i / DPR, d = i % DPR;
+                const int ci = row / SD_IH, y = iy0 + row % SD_IH, x = ix0 + 2 * d;
+                if (y >= 0 && y < p.H && x >= 0 && x < p.W)
+                    v = *reinterpret_cast<const unsigned*>(reinterpret_cast<const bf16_t*>(p.X) + ((long long)b * 3 + ci) * plane + (long long)y * p.W + x);
+            }
+            dv[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < DW_PER_THREAD; ++q) {
+            const int i = tid + 256 * q;
+            if (i < NDW) reinterpret_cast<unsigned*>(In)[i] = dv[q];
+        }
+        if (tid < 4) reinterpret_cast<unsigned*>(In)[NDW + tid] = 0u;       // the zero slot of the k >= 27 im2col lanes
+    } else {
         float vin[IN_PER_THREAD];
 #pragma unroll
         for (int q = 0; q < IN_PER_THREAD; ++q) {
             const int i = tid + 256 * q;
             float v = 0.f;
             if (i < IN_REAL) {
-                const int ci = i / (SD_IH * SD_IW), rem = i % (SD_IH * SD_IW);
-                const int y = iy0 + rem / SD_IW, x = ix0 + rem % SD_IW;
-                if (y >= 0 && y < p.H && x >= 0 && x < p.W) {
+                const int ci = i / (SD_IH * SD_IWP), rem = i % (SD_IH * SD_IWP);
+                const int y = iy0 + rem / SD_IWP, x = ix0 + rem % SD_IWP;
+                if (y >= 0 && y < p.H && x >= 0 && x < p.W && rem % SD_IWP < SD_IW) {
                     const long long off = ((long long)b * 3 + ci) * plane + (long long)y * p.W + x;
                     if constexpr (IN == 0) v = reinterpret_cast<const float*>(p.X)[off];
                     else if constexpr (IN == 1) v = (float)reinterpret_cast<const bf16_t*>(p.X)[off];
@@ -134,7 +160,7 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(SdArgs p) {
         for (int j = 0; j < EPC; ++j) {
             const int k = kc * KPC + fpiece * EPC + j;
             const int tap = k / 3, ci = k % 3;
-            koff[kc][j] = k < 27 ? ci * SD_IH * SD_IW + (tap / 3) * SD_IW + (tap % 3) : -1;
+            koff[kc][j] = k < 27 ? ci * SD_IH * SD_IWP + (tap / 3) * SD_IWP + (tap % 3) : -1;
         }
     __syncthreads();
 
@@ -143,13 +169,13 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(SdArgs p) {
     for (int ms = wave; ms < SD_HPPAD / 16; ms += 4) {
         const int hp = 16 * ms + frow;
         const int hy = hp / SD_HW, hx = hp % SD_HW;
-        const int base = (hp < SD_HP) ? (2 * hy) * SD_IW + 2 * hx : 0;
+        const int base = (hp < SD_HP) ? (2 * hy) * SD_IWP + 2 * hx : 0;
         Frag<T> xf[NKC];
 #pragma unroll
         for (int kc = 0; kc < NKC; ++kc)
 #pragma unroll
             for (int j = 0; j < EPC; ++j)
-                xf[kc].v[j] = In[koff[kc][j] >= 0 ? base + koff[kc][j] : 3 * SD_IH * SD_IW];
+                xf[kc].v[j] = In[koff[kc][j] >= 0 ? base + koff[kc][j] : 3 * SD_IH * SD_IWP];
         const int sy = sy0 + hy, sx = sx0 + hx;
         const bool inside = hp < SD_HP && sy >= 0 && sy < p.Ho && sx >= 0 && sx < p.Wo;
         const float inside_m = inside ? 1.f : 0.f;
@@ -239,7 +265,7 @@ size_t sd_lds_bytes(int C) {
     const int cpad = (C + 15) / 16 * 16;
     const int erow = C + 16 / (int)sizeof(T);
     const int WROW = 32 * (int)sizeof(T) + 16;
-    size_t n = ((3 * SD_IH * SD_IW + 8) * sizeof(T) + 15) / 16 * 16;
+    size_t n = ((3 * SD_IH * SD_IWP + 8) * sizeof(T) + 15) / 16 * 16;
     n += (size_t)cpad * WROW;
     n += ((size_t)SD_HP * erow * sizeof(T) + 15) / 16 * 16;
     n += 256 * 9 * 4;
@@ -268,6 +294,7 @@ static int stem_dw_common(void* stream, int in_dtype, int dtype, const void* X, 
     a.Ho = same_out(H, 2); a.Wo = same_out(W, 2);
     a.pad_t = same_pad_before(H, 3, 2); a.pad_l = same_pad_before(W, 3, 2);
     a.tiles_x = (a.Wo + SD_TW - 1) / SD_TW; a.tiles_y = (a.Ho + SD_TH - 1) / SD_TH;
+    a.vec_in = in_dtype == 1 && dtype == 1 && W % 2 == 0 && a.pad_l % 2 == 0 && reinterpret_cast<uintptr_t>(X) % 4 == 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(a.tiles_x * a.tiles_y, B), block(256);
     const size_t lds = dtype == 0 ? sd_lds_bytes<float>(C) : sd_lds_bytes<bf16_t>(C);
