@@ -32,11 +32,14 @@ struct PwArgs {
     int tiles_per_image, n_tiles, vec_ok;
 };
 
-constexpr int PW_PIX = 128;                      // pixels per workgroup (4 waves x 2 MFMA tiles)
+constexpr int PW_PIX = 128;                      // pixels per workgroup: 4 waves x 2 MFMA tiles, or 8 waves x 1 (small maps)
 constexpr int KCH = 2;                           // 64-byte K-chunks per pipeline stage
 
-template <typename T, int BN>
-__global__ __launch_bounds__(256, 2) void pw_gemm_kernel(PwArgs p) {
+// PT 16-pixel tiles per wave, NTH threads: (2, 256) normally; (1, 512) when the launch has fewer than two workgroups per
+// CU (20x20 maps) - twice the waves per SIMD to hide the per-stage latencies, at the price of reading each W
+// fragment from LDS once per 16 instead of once per 32 pixels
+template <typename T, int BN, int PT, int NTH>
+__global__ __launch_bounds__(NTH, 2) void pw_gemm_kernel(PwArgs p) {
     constexpr int EPC = VecTraits<T>::EPC;          // elements per 16-byte piece
     constexpr int KPC = 64 / (int)sizeof(T);        // elements per 64-byte K-chunk
     constexpr int NT = BN / 16, NP = NT / 2;
@@ -63,18 +66,18 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(PwArgs p) {
     const int kbytes = K * (int)sizeof(T);
 
     // ---- this lane's two pixels (B operand columns): pointers into A, clamped inside the image
-    const char* arow[2];
-    int pix[2];
-    bool pix_ok[2];
+    const char* arow[PT];
+    int pix[PT];
+    bool pix_ok[PT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        pix[i] = pix0 + 32 * wave + 16 * i + frow;
+    for (int i = 0; i < PT; ++i) {
+        pix[i] = pix0 + 16 * PT * wave + 16 * i + frow;
         pix_ok[i] = pix[i] < p.rows_per_image;
         const long long m = (long long)img * p.rows_per_image + (pix_ok[i] ? pix[i] : 0);
         arow[i] = reinterpret_cast<const char*>(p.A) + m * pitch + fpiece * 16;
     }
     // A ring: PF + 1 stages x KCH chunks x 2 pixel tiles, straight from memory into MFMA operand registers
-    Frag<T> areg[PF + 1][KCH][2];
+    Frag<T> areg[PF + 1][KCH][PT];
     auto a_load = [&](int stg, int slot) {
 #pragma unroll
         for (int sub = 0; sub < KCH; ++sub) {
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(PwArgs p) {
             const bool ok = off < kbytes;
             const int offc = ok ? off - fpiece * 16 : 0;     // a lane past the end of K re-reads byte 0 and is zeroed below
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < PT; ++i) {
                 Frag<T> f = ld_frag<T>(arow[i] + offc);
                 if (!ok) f.v = decltype(f.v){};
                 areg[slot][sub][i] = f;
@@ -94,14 +97,14 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(PwArgs p) {
     const char* Wb = reinterpret_cast<const char*>(p.W);
     const float* gate = p.gate != nullptr ? p.gate + (long long)img * K : nullptr;
     constexpr int PPR = KCH * 4;
-    constexpr int W_PER_THREAD = (BN * PPR + 255) / 256;
+    constexpr int W_PER_THREAD = (BN * PPR + NTH - 1) / NTH;
     auto lds_row = [](int co) { return 16 * (2 * (co >> 5) + ((co >> 2) & 1)) + 4 * ((co >> 3) & 3) + (co & 3); };
     u32x4 w_reg[W_PER_THREAD];
     f32x4 g_reg[W_PER_THREAD][2];
     auto w_load = [&](int stg) {                     // issues loads only
 #pragma unroll
         for (int q = 0; q < W_PER_THREAD; ++q) {
-            const int idx = tid + 256 * q;
+            const int idx = tid + NTH * q;
             const int co = idx / PPR, piece = idx % PPR;
             const int ke = stg * KCH * KPC + piece * EPC;
             u32x4 v = {0u, 0u, 0u, 0u};
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(PwArgs p) {
         char* Wd = lds + buf * W_BYTES;
 #pragma unroll
         for (int q = 0; q < W_PER_THREAD; ++q) {
-            const int idx = tid + 256 * q;
+            const int idx = tid + NTH * q;
             if (idx < BN * PPR) {
                 u32x4 v = w_reg[q];
                 if (gate != nullptr) {
@@ -141,9 +144,9 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(PwArgs p) {
         }
     };
 
-    f32x4 acc[2][NT];
+    f32x4 acc[PT][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < PT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -170,8 +173,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(PwArgs p) {
                         for (int j = 0; j < NT; ++j) {
                             if (j < 2 * njp) {
                                 const Frag<T> wf = ld_frag<T>(Ws + (16 * j + frow) * ROWB + sub * 64 + fpiece * 16);
-                                mma_chunk(wf, areg[u][sub][0], acc[0][j]);
-                                mma_chunk(wf, areg[u][sub][1], acc[1][j]);
+#pragma unroll
+                                for (int i = 0; i < PT; ++i) mma_chunk(wf, areg[u][sub][i], acc[i][j]);
                             }
                         }
                     }
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(PwArgs p) {
                     sh[e] = p.shift[n];
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < PT; ++i) {
                     if (!pix_ok[i]) continue;
                     float v[8];
 #pragma unroll
@@ -251,16 +254,20 @@ int launch_pw(hipStream_t st, PwArgs& a) {
     const size_t esz = sizeof(T);
     a.vec_ok = ((size_t)a.N * esz) % 16 == 0 && ((size_t)a.ldc * esz) % 16 == 0 && ((size_t)a.c_image_stride * esz) % 16 == 0 &&
                reinterpret_cast<uintptr_t>(a.C) % 16 == 0 && (a.res == nullptr || reinterpret_cast<uintptr_t>(a.res) % 16 == 0);
-    dim3 grid((unsigned)blocks), block(256);
+    dim3 grid((unsigned)blocks);
+    const bool small = blocks < 512;                 // fewer than two workgroups per CU: 8 waves x 16 pixels each
+#define PW_LAUNCH(BN_) do { if (small && BN_ != 128) hipLaunchKernelGGL((pw_gemm_kernel<T, BN_ == 128 ? 96 : BN_, 1, 512>), grid, dim3(512), 0, st, a); /* the (128, 1, 512) instantiation spills */ \
+                            else hipLaunchKernelGGL((pw_gemm_kernel<T, BN_, 2, 256>), grid, dim3(256), 0, st, a); } while (0)
     switch (bn) {
-        case 32:  hipLaunchKernelGGL((pw_gemm_kernel<T, 32>), grid, block, 0, st, a); break;
-        case 64:  hipLaunchKernelGGL((pw_gemm_kernel<T, 64>), grid, block, 0, st, a); break;
-        case 96:  hipLaunchKernelGGL((pw_gemm_kernel<T, 96>), grid, block, 0, st, a); break;
-        case 128: hipLaunchKernelGGL((pw_gemm_kernel<T, 128>), grid, block, 0, st, a); break;
-        case 160: hipLaunchKernelGGL((pw_gemm_kernel<T, 160>), grid, block, 0, st, a); break;
-        case 192: hipLaunchKernelGGL((pw_gemm_kernel<T, 192>), grid, block, 0, st, a); break;
+        case 32:  PW_LAUNCH(32); break;
+        case 64:  PW_LAUNCH(64); break;
+        case 96:  PW_LAUNCH(96); break;
+        case 128: PW_LAUNCH(128); break;
+        case 160: PW_LAUNCH(160); break;
+        case 192: PW_LAUNCH(192); break;
         default: return EFFDET_EINVAL;
     }
+#undef PW_LAUNCH
     return effdet_check_launch();
 }
 

@@ -137,7 +137,7 @@ def test_mbconv_expand_dw_fused(dtype, Cin, mid, H, W, k, s):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('C,H,W', [(32, 64, 96), (48, 70, 38), (40, 34, 34)])
+@pytest.mark.parametrize('C,H,W', [(32, 64, 96), (48, 70, 38), (40, 34, 34), (32, 33, 35)])   # last: odd width -> scalar patch load
 def test_stem_dw_fused(dtype, C, H, W):
     """conv_stem + BN + SiLU -> depthwise 3x3 + BN + SiLU (+ pool partials) in one launch vs the oracle ops"""
     import _hip
