@@ -733,7 +733,7 @@ struct Geometry { int TH, TW, IH, IW, HP, HPpad, arow, e_bytes; size_t lds; };
 
 template <typename T>
 Geometry pick_tile(int Ho, int Wo, int Cin, int k, int stride) {
-    const int cand[][2] = {{8, 16}, {8, 8}, {4, 16}, {4, 8}, {4, 4}, {2, 4}};     // TW is a multiple of 4
+    const int cand[][2] = {{16, 16}, {8, 16}, {8, 8}, {4, 16}, {4, 8}, {4, 4}, {2, 4}};     // TW is a power of two >= 4
     Geometry best{};
     for (auto& c : cand) {
         Geometry g;
