@@ -187,6 +187,17 @@ int effdet_label_anchors(void* stream, const float* anchors, const float* gt_box
                          int B, int Mmax, long long N, float match_threshold, long long* cls_t, float* box_t,
                          float* num_positives, long long* match, void* workspace, long long workspace_bytes);
 
+/* ---- optimizer half of the pretrain step (pretrain.py:272-276) ------------------------------------ */
+
+/* torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.Adam.step() on flat float32 buffers.
+ * effdet_sqnorm: out[0] (+)= sum(g^2) (two-stage, fixed order; workspace of effdet_sqnorm_workspace_floats floats).
+ * effdet_adam_clip_step: g' = g * min(1, max_norm / (sqrt(*sqnorm) + 1e-6)) (sqnorm NULL: no clipping), then Adam
+ * in torch's operation order with bias corrections for `step` (1-based). */
+long long effdet_sqnorm_workspace_floats(void);
+int effdet_sqnorm(void* stream, const float* g, long long n, float* workspace, float* out, int accumulate);
+int effdet_adam_clip_step(void* stream, float* p, const float* g, float* m, float* v, long long n,
+                          float lr, float beta1, float beta2, float eps, int step, float max_norm, const float* sqnorm);
+
 /* ---- OOD evaluation helpers -------------------------------------------- */
 
 /* Image-level OOD score out[b] = max_a(-energy[b, a]) over the per-anchor energies [B, N]. */

@@ -47,6 +47,10 @@ SIGNATURES = {
                                      P(c_void_p), P(c_ll), P(c_int), P(c_int), c_int, P(c_float), c_float, c_int,
                                      c_void_p, c_void_p, c_void_p, c_void_p, P(c_int), c_int, c_int, c_int,
                                      P(c_void_p), P(c_ll), c_int, c_int, c_void_p, c_void_p, c_ll, P(c_ll)]),
+    'effdet_sqnorm_workspace_floats': (c_ll, []),
+    'effdet_sqnorm': (c_int, [c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_int]),
+    'effdet_adam_clip_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_float, c_float, c_float, c_float,
+                                      c_int, c_float, c_void_p]),
     'effdet_ood_image_score': (c_int, [c_void_p, c_void_p, c_int, c_ll, c_void_p]),
     'effdet_auroc_counts': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'effdet_topk_workspace_bytes': (c_ll, [c_int, c_ll]),

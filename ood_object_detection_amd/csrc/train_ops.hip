@@ -291,3 +291,88 @@ extern "C" int effdet_label_anchors(void* stream, const float* anchors, const fl
     hipLaunchKernelGGL(label_targets_kernel, dim3(a.nblk, B), dim3(LT), 0, st, a);
     return effdet_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Optimizer half of the pretrain step (pretrain.py:272-276): torch.nn.utils.clip_grad_norm_(params, 10.)
+// followed by torch.optim.Adam.step(), on flat float32 buffers (parameters, gradients and both moments of a
+// parameter group concatenated).  Fixed-order two-stage reductions: bitwise reproducible.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int SQN_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* g, long long n, float* partial) {
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += g[i] * g[i];
+    s = wave_reduce_sum(s);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(256) void sqnorm_final_kernel(const float* partial, int nb, float* out, int accumulate) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
+    s = wave_reduce_sum(s);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = (part[0] + part[1]) + (part[2] + part[3]);
+        out[0] = accumulate ? out[0] + t : t;
+    }
+}
+
+struct AdamArgs {
+    float* p; const float* g; float* m; float* v; long long n;
+    float lr, beta1, beta2, eps, bc1, bc2_sqrt, max_norm;
+    const float* sqnorm;                       // total squared gradient norm (all groups), or null: no clipping
+};
+
+// clip coefficient exactly as clip_grad_norm_: clamp(max_norm / (total_norm + 1e-6), max = 1), applied to the gradient;
+// then Adam in torch's order: m.lerp_(g, 1-b1); v = v*b2 + (1-b2) g^2; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adam_clip_kernel(AdamArgs a) {
+    float coef = 1.f;
+    if (a.sqnorm != nullptr) {
+        coef = a.max_norm / (sqrtf(a.sqnorm[0]) + 1e-6f);
+        coef = coef > 1.f ? 1.f : coef;
+    }
+    const float step_size = a.lr / a.bc1;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
+        const float g = a.g[i] * coef;
+        float m = a.m[i], v = a.v[i];
+        m = m + (1.f - a.beta1) * (g - m);
+        v = v * a.beta2 + (1.f - a.beta2) * g * g;
+        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+        a.p[i] = a.p[i] - step_size * (m / denom);
+        a.m[i] = m; a.v[i] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" long long effdet_sqnorm_workspace_floats(void) { return SQN_BLOCKS; }
+
+/* out[0] (+)= sum(g^2); accumulate != 0 adds to the value already there (several parameter groups). */
+extern "C" int effdet_sqnorm(void* stream, const float* g, long long n, float* workspace, float* out, int accumulate) {
+    EFFDET_ENTER();
+    if (!g || !workspace || !out || n <= 0) return EFFDET_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    long long nb = (n + 255) / 256; if (nb > SQN_BLOCKS) nb = SQN_BLOCKS;
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3((unsigned)nb), dim3(256), 0, st, g, n, workspace);
+    hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, st, workspace, (int)nb, out, accumulate);
+    return effdet_check_launch();
+}
+
+extern "C" int effdet_adam_clip_step(void* stream, float* p, const float* g, float* m, float* v, long long n,
+                                     float lr, float beta1, float beta2, float eps, int step,
+                                     float max_norm, const float* sqnorm) {
+    EFFDET_ENTER();
+    if (!p || !g || !m || !v || n <= 0 || step <= 0 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f)) return EFFDET_EINVAL;
+    AdamArgs a{p, g, m, v, n, lr, beta1, beta2, eps,
+               (float)(1.0 - pow((double)beta1, step)), (float)sqrt(1.0 - pow((double)beta2, step)), max_norm, sqnorm};
+    long long nb = (n + 255) / 256; if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(adam_clip_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return effdet_check_launch();
+}

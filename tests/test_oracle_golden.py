@@ -143,3 +143,24 @@ def test_auroc_oracle_matches_sklearn():
     neg = np.round(rng.randn(150), 1)
     ref = sk.roc_auc_score(np.r_[np.ones_like(pos), np.zeros_like(neg)], np.r_[pos, neg])
     assert abs(opp.auroc(pos, neg) - ref) < 1e-12
+
+
+def test_clip_adam_oracle_matches_torch():
+    """oracle/train.py vs torch.nn.utils.clip_grad_norm_ + torch.optim.Adam (what pretrain.py:272-276 calls)."""
+    import torch
+    from oracle import train as otr
+    g0 = torch.Generator().manual_seed(4)
+    shapes = [(7, 5), (33,), (4, 3, 3, 3)]
+    params = [torch.nn.Parameter(torch.randn(*s, generator=g0)) for s in shapes]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    p = np.concatenate([q.detach().numpy().ravel() for q in params]); m = np.zeros_like(p); v = np.zeros_like(p)
+    for step in range(1, 4):
+        grads = [torch.randn(*s, generator=g0) * (30.0 if step == 2 else 0.1) for s in shapes]    # step 2 clips
+        for q, g in zip(params, grads):
+            q.grad = g.clone()
+        tn = torch.nn.utils.clip_grad_norm_(params, 10.)
+        opt.step()
+        p, m, v, n = otr.clip_adam_step(p, np.concatenate([g.numpy().ravel() for g in grads]), m, v, step)
+        ref = np.concatenate([q.detach().numpy().ravel() for q in params])
+        assert abs(float(tn) - float(n)) < 1e-4 * max(1.0, float(tn))
+        assert np.abs(p - ref).max() < 2e-6
