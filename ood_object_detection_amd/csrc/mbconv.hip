@@ -290,29 +290,46 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
                 const char* Eb = reinterpret_cast<const char*>(E) + (16 * dj + 8 * (fpiece & 1)) * (int)sizeof(T);
                 const int npix = p.TH * p.TW;
                 float pl[4] = {0.f, 0.f, 0.f, 0.f};
-                for (int q0 = 16 * dhalf; q0 < npix; q0 += 16 * NH) {
-                    const int q = q0 + frow;
-                    const int qq = q < npix ? q : 0;
-                    const int ty = qq >> p.tw_shift, tx = qq & (p.TW - 1);
-                    const int oy = oy0 + ty, ox = ox0 + tx;
-                    const bool ok = q < npix && oy < p.Ho && ox < p.Wo;
-                    const char* base = Eb + ((ty * S) * p.IW + tx * S) * (EROW * (int)sizeof(T));
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                // two pixel tiles per step share every expanded diagonal operand (the expansion is the larger part of
+                // the per-MFMA vector work)
+                constexpr int UT = 2;
+                for (int q0 = 16 * dhalf; q0 < npix; q0 += 16 * NH * UT) {
+                    const char* base[UT];
+                    int oy[UT], ox[UT];
+                    bool ok[UT];
+                    f32x4 acc[UT];
+#pragma unroll
+                    for (int u = 0; u < UT; ++u) {
+                        const int q = q0 + 16 * NH * u + frow;
+                        const int qq = q < npix ? q : 0;
+                        const int ty = qq >> p.tw_shift, tx = qq & (p.TW - 1);
+                        oy[u] = oy0 + ty; ox[u] = ox0 + tx;
+                        ok[u] = q < npix && oy[u] < p.Ho && ox[u] < p.Wo;
+                        base[u] = Eb + ((ty * S) * p.IW + tx * S) * (EROW * (int)sizeof(T));
+                        acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    const bool second = q0 + 16 * NH < npix;       // uniform
 #pragma unroll
                     for (int pr = 0; pr < NPAIR; ++pr) {
                         unsigned bits = abits[pr];
                         asm volatile("" : "+v"(bits));           // keep the expansion here: hoisted, the fragments would not fit the registers
                         const u32x4 fr = {ddq == 0 ? bits : 0u, ddq == 1 ? bits : 0u, ddq == 2 ? bits : 0u, ddq == 3 ? bits : 0u};
                         Frag<T> af; af.v = __builtin_bit_cast(bf16x8, fr);
-                        mma_chunk(af, ld_frag<T>(base + tap_off(pr)), acc);
+                        const int to = tap_off(pr);
+                        mma_chunk(af, ld_frag<T>(base[0] + to), acc[0]);
+                        if (second) mma_chunk(af, ld_frag<T>(base[1] + to), acc[1]);
                     }
-                    float o[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = to_f<T>(from_f<T>(silu_t<T>(acc[r] * s2v[r] + t2v[r])));   // SE averages what the next layer reads
-                    if (ok) {
+                    for (int u = 0; u < UT; ++u) {
+                        if (u == 1 && !second) break;
+                        float o[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) pl[r] += o[r];
-                        store4<T>(Y + ((long long)oy * p.Wo + ox) * mid + c0 + 16 * dj + 4 * fpiece, o[0], o[1], o[2], o[3]);
+                        for (int r = 0; r < 4; ++r) o[r] = to_f<T>(from_f<T>(silu_t<T>(acc[u][r] * s2v[r] + t2v[r])));   // SE averages what the next layer reads
+                        if (ok[u]) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) pl[r] += o[r];
+                            store4<T>(Y + ((long long)oy[u] * p.Wo + ox[u]) * mid + c0 + 16 * dj + 4 * fpiece, o[0], o[1], o[2], o[3]);
+                        }
                     }
                 }
 #pragma unroll
