@@ -87,10 +87,11 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
     // ---- input halo tile -> LDS (zero rows outside the image); loads batched ahead of their LDS stores
     const T* X = reinterpret_cast<const T*>(p.X) + (long long)b * p.H * p.W * Cin;
     const int ppr = cbytes / 16;                            // 16-byte pieces per LDS row
-    for (int i0 = tid; i0 < p.HPpad * ppr; i0 += 2 * SM_T) {
-        u32x4 v[2];
+    constexpr int AB = 3;                                   // pieces in flight per thread: one round trip covers every tile of d0..d4
+    for (int i0 = tid; i0 < p.HPpad * ppr; i0 += AB * SM_T) {
+        u32x4 v[AB];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < AB; ++u) {
             const int i = i0 + SM_T * u;
             v[u] = u32x4{0u, 0u, 0u, 0u};
             if (i < p.HPpad * ppr) {
@@ -102,29 +103,34 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
                     inside = y >= 0 && y < p.H && x >= 0 && x < p.W;
                     if (inside) {
                         v[u] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(X + ((long long)y * p.W + x) * Cin) + piece * 16);
-                        if (p.in_gate != nullptr) {            // SE gate of the producing block (its project conv was folded into W1)
-                            const float* g = p.in_gate + (long long)b * Cin + piece * (16 / (int)sizeof(T));
-                            if constexpr (sizeof(T) == 2) {
-                                bf16x8 xv = __builtin_bit_cast(bf16x8, v[u]);
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) xv[e] = (bf16_t)((float)xv[e] * g[e]);
-                                v[u] = __builtin_bit_cast(u32x4, xv);
-                            } else {
-                                f32x4 xv = __builtin_bit_cast(f32x4, v[u]);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) xv[e] *= g[e];
-                                v[u] = __builtin_bit_cast(u32x4, xv);
-                            }
-                        }
                     }
                 }
                 if (piece == 0) msk[hp] = inside ? 1.f : 0.f;
             }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < AB; ++u) {
             const int i = i0 + SM_T * u;
-            if (i < p.HPpad * ppr) { const int hp = fdiv(i, p.fd_ppr); *reinterpret_cast<u32x4*>(At + hp * arow + (i - hp * ppr) * 16) = v[u]; }
+            if (i < p.HPpad * ppr) {
+                const int hp = fdiv(i, p.fd_ppr), piece = i - hp * ppr;
+                if (p.in_gate != nullptr) {
+                    // SE gate of the producing block (its project conv was folded into W1), applied here - after every
+                    // load of the batch has been issued - and rounded to T like the reference's gated tensor; zero rows stay zero
+                    const float* g = p.in_gate + (long long)b * Cin + piece * (16 / (int)sizeof(T));
+                    if constexpr (sizeof(T) == 2) {
+                        bf16x8 xv = __builtin_bit_cast(bf16x8, v[u]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) xv[e] = (bf16_t)((float)xv[e] * g[e]);
+                        v[u] = __builtin_bit_cast(u32x4, xv);
+                    } else {
+                        f32x4 xv = __builtin_bit_cast(f32x4, v[u]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) xv[e] *= g[e];
+                        v[u] = __builtin_bit_cast(u32x4, xv);
+                    }
+                }
+                *reinterpret_cast<u32x4*>(At + hp * arow + piece * 16) = v[u];
+            }
         }
     }
 
