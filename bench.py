@@ -69,8 +69,10 @@ def host_cores():
     return max(1, min(n, int(os.environ.get('EFFDET_CPU_THREADS', '16'))))
 
 
-def cpu_baseline(model_cpu_sd, cfg, image, num_classes, budget_s=20.0):
-    """The oracle's full path (forward + top-k + decode + hard NMS + OOD) on the host cores."""
+def cpu_baseline(model_cpu_sd, cfg, image, num_classes, budget_s=20.0, gpu_check=None):
+    """The oracle's full path (forward + top-k + decode + hard NMS + OOD) on the host cores.
+    gpu_check(x) -> (cls_outs, box_outs, energy) from the HIP path in float32 on the same image: the L-inf
+    against the oracle's outputs is reported next to the baseline (north star: <= 1e-3 abs)."""
     from oracle import model as om
     from oracle import postprocess as op
     from ood_object_detection_amd.effdet.config import get_fpn_config
@@ -88,6 +90,16 @@ def cpu_baseline(model_cpu_sd, cfg, image, num_classes, budget_s=20.0):
             for i in range(B):
                 op.generate_detections(c[i], b[i], anchors, idx[i], cl[i], None, torch.tensor(image), cfg.max_det_per_image, False)
 
+    parity = None
+    if gpu_check is not None:
+        with torch.no_grad():
+            cls_o, box_o = om.efficientdet_forward(model_cpu_sd, cfg, x, nodes)
+            energy, _ = om.ood_scores(cls_o, num_classes)
+            gc, gb, ge = gpu_check(x)
+        parity = {'dtype': 'f32', 'images': B,
+                  'class_logits_linf': float(max((a - b.cpu()).abs().max() for a, b in zip(cls_o, gc))),
+                  'box_outputs_linf': float(max((a - b.cpu()).abs().max() for a, b in zip(box_o, gb))),
+                  'ood_energy_linf': float((energy - ge.cpu()).abs().max())}
     t0 = time.time()
     step()                                    # first pass: warm-up, and the measurement itself if it is very slow
     first = time.time() - t0
@@ -98,8 +110,11 @@ def cpu_baseline(model_cpu_sd, cfg, image, num_classes, budget_s=20.0):
             step()
             n += 1
         dt = time.time() - t1
-    return {'value': round(B * n / dt, 3), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d x batch-%d fp32 oracle passes of the same d0/%d workload (forward+OOD+top-k+decode+hard NMS)' % (n, B, image)}
+    out = {'value': round(B * n / dt, 3), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+           'sample': '%d x batch-%d fp32 oracle passes of the same d0/%d workload (forward+OOD+top-k+decode+hard NMS)' % (n, B, image)}
+    if parity is not None:
+        out['parity_vs_hip_f32'] = parity
+    return out
 
 
 def main():
@@ -283,7 +298,13 @@ def main():
             fh.write('# network (sum of launches) ms %.3f ; timed step ms %.3f (adds top-k/decode/NMS/OOD gather)\n' % (net_ms, ms_per_step))
     cpu = None
     if want_cpu:
-        cpu = cpu_baseline(sd_cpu, cfg, args.image, args.classes)
+        def gpu_check(x1):
+            m32 = build_model(args.model, args.image, args.classes)
+            m32.load_state_dict(sd_cpu)
+            m32 = m32.to(dev)
+            co, bo = m32(x1.to(dev))
+            return [t.float() for t in co], [t.float() for t in bo], m32.ood_energy.clone()
+        cpu = cpu_baseline(sd_cpu, cfg, args.image, args.classes, gpu_check=gpu_check)
     out = {
         'metric': 'images/sec, %s %dpx %s inference + OOD score (DetBenchPredict end-to-end)' % (args.model, args.image, args.dtype),
         'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
