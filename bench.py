@@ -27,6 +27,7 @@ for p in (ROOT,):
 import torch
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_PEAK_FLOPS = 2.5e15       # MI355X_MICROARCH.md: dense bf16 MFMA peak (the fp32 parity mode would be lower; the bench runs bf16)
 
 
 def build_model(name, image, num_classes, seed=0):
@@ -268,12 +269,15 @@ def main():
     achieved = d['bytes'] / (d['ms'] * 1e-3) / 1e9
     net_bytes = sum(f['bytes'] for f in fam.values())
     net_ms = sum(f['ms'] for f in fam.values())
+    # t_roof = sum over launches of max(flops / P_mfma, bytes / BW_hbm) for the fused launch list
+    t_roof_ms = 1e3 * sum(max(flops / MFMA_PEAK_FLOPS, nbytes / (HBM_PEAK_GBS * 1e9)) for _, _, nbytes, flops, _ in prof)
     roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
                 'kernel': dom, 'launches_per_step': d['launches'], 'avg_launch_ms': round(d['ms'] / d['launches'], 4),
                 'algorithmic_bytes_per_launch': int(d['bytes'] / d['launches']),
                 'network_frac': round(net_bytes / (net_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                'step_frac': round(net_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                'step_frac': round(net_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                't_roof_ms': round(t_roof_ms, 4), 't_roof_over_step': round(t_roof_ms / ms_per_step, 4)}
     # HBM traffic of the dominant family: PMC counters cannot be read from inside this process, so the number
     # comes from the committed rocprofv3 --pmc passes of the same workload (tools/profile_gpu.sh ->
     # tools/pmc_traffic.py); null when the workload is not the profiled one.
