@@ -559,3 +559,30 @@ def test_flat_adam_matches_oracle():
         assert abs(float(norm) - float(n)) < 1e-5 * max(1.0, float(n))
         assert np.abs(got - p).max() < 2e-6
         assert np.abs(opt.exp_avg.cpu().numpy() - m).max() < 1e-6 and np.abs(opt.exp_avg_sq.cpu().numpy() - v).max() < 1e-6
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_topk_full_size_properties(dtype):
+    """BASELINE size (640 px, C = 90: 6.9 M logits per image), checked through size-independent properties:
+    values sorted descending, ties in ascending flat index, each value is the logit at its index, and the value
+    multiset equals torch.topk's (the oracle's Python loop would take minutes here)."""
+    from ood_object_detection_amd.effdet.bench import _post_process
+    B, C, A, k = 2, 90, 9, 5000
+    sizes = [80, 40, 20, 10, 5]
+    g = torch.Generator(device=DEV).manual_seed(21)
+    cls = [(torch.randn(B, A * C, s, s, device=DEV, generator=g) * 0.7 - 3.0).to(dtype) for s in sizes]
+    box = [torch.randn(B, A * 4, s, s, device=DEV, generator=g).to(dtype) for s in sizes]
+    flat = torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1, C) for c in cls], 1)
+    amax = flat.float().max(dim=2).values
+    for am in (None, amax):
+        vals, boxes, idx, cid = _post_process(cls, box, 5, C, k, anchor_max=am)
+        v = vals.reshape(B, k).float()
+        fidx = idx * C + cid
+        assert torch.all(v[:, :-1] >= v[:, 1:])
+        tie = v[:, :-1] == v[:, 1:]
+        assert torch.all(fidx[:, :-1][tie] < fidx[:, 1:][tie])
+        assert torch.equal(v, flat.reshape(B, -1).float().gather(1, fidx))
+        ref = torch.topk(flat.reshape(B, -1).float(), k, dim=1).values
+        assert torch.equal(v, ref)
+        bflat = torch.cat([b.permute(0, 2, 3, 1).reshape(B, -1, 4) for b in box], 1)
+        assert torch.equal(boxes, bflat.gather(1, idx.unsqueeze(-1).expand(-1, -1, 4)))

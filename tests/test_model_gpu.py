@@ -211,3 +211,33 @@ def test_detbench_split_streams_identical():
         d3 = b2(x).clone()
         d4 = DetBenchPredict(model, streams=1).to(DEV)(x)
     assert torch.equal(d3, d4) and not torch.equal(d3, d2)
+
+
+def test_detbench_bench_size_properties():
+    """The BASELINE workload shape (d0, 640 px, bf16, hard NMS) through size-independent properties: valid rows are
+    sorted by score, classes are 1-based and in range, kept same-class boxes respect the NMS threshold, and the OOD
+    scores obey -energy >= max_logit (logsumexp >= max)."""
+    import bench as B
+    from ood_object_detection_amd.effdet.bench import DetBenchPredict
+    model = B.build_model('tf_efficientdet_d0', 640, 90).to(DEV).to(torch.bfloat16)
+    bench = DetBenchPredict(model).to(DEV)
+    x = torch.randn(16, 3, 640, 640, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)).to(torch.bfloat16)
+    with torch.no_grad():
+        det = bench(x).float().cpu()
+    cnt = bench.last_count.cpu()
+    assert det.shape == (16, 100, 6) and int(cnt.max()) <= 100 and int(cnt.min()) > 0
+    for i in range(16):
+        d = det[i, :int(cnt[i])]
+        assert torch.all(d[:-1, 4] >= d[1:, 4]) and torch.all(d[:, 4] > 0.01)
+        assert torch.all((d[:, 5] >= 1) & (d[:, 5] <= 90)) and torch.all(d[:, 2] >= d[:, 0]) and torch.all(d[:, 3] >= d[:, 1])
+        assert torch.all(det[i, int(cnt[i]):] == 0)
+        x1 = torch.max(d[:, None, 0], d[None, :, 0]); y1 = torch.max(d[:, None, 1], d[None, :, 1])
+        x2 = torch.min(d[:, None, 2], d[None, :, 2]); y2 = torch.min(d[:, None, 3], d[None, :, 3])
+        inter = (x2 - x1).clamp(min=0) * (y2 - y1).clamp(min=0)
+        area = (d[:, 2] - d[:, 0]) * (d[:, 3] - d[:, 1])
+        iou = inter / (area[:, None] + area[None, :] - inter).clamp(min=1e-9)
+        same = (d[:, None, 5] == d[None, :, 5]) & ~torch.eye(d.shape[0], dtype=torch.bool)
+        assert (float(iou[same].max()) <= 0.3 + 1e-3) if same.any() else True      # hard NMS threshold (anchors.py:150)
+    ood = bench.last_ood
+    assert torch.isfinite(ood['anchor_energy']).all() and torch.all(-ood['anchor_energy'] >= ood['anchor_max_logit'] - 1e-4)
+    assert torch.isfinite(ood['energy'][:, :1]).all()
