@@ -129,6 +129,26 @@ int effdet_sepconv_fused(void* stream, int dtype, int B, int nlevels, const int*
                          int ood_classes, int num_anchors, float* ood_energy, float* ood_maxlogit,
                          long long ood_image_stride, const long long* ood_level_off);
 
+/* MetaHead (effdet/efficientdet.py:569-695): the fork's functional class head - SeparableConv layers shared by the
+ * levels, each followed by F.batch_norm(training=True) (statistics of the current batch, per level) and Swish.
+ * effdet_sepconv_meta runs one layer for all levels: the previous layer's batch-norm arrives folded into
+ * in_scale / in_shift [rows][F] (row in_affine_row[level]; NULL for the first layer) applied before the SiLU (pre_act),
+ * the conv output + bias is written raw and its per-channel sums / sums of squares go to stat_partial
+ * [B][effdet_sepconv_tiles][2][N] (NULL: not needed).  dw_out (optional, per level [B, H*W, F]) receives the
+ * depthwise output (`x_pred`, what ret_activs returns).  effdet_bn_batch_stats turns the partial sums into the next
+ * layer's scale / shift [nlevels][N]: scale = w / sqrt(var_biased + eps), shift = b - mean * scale with
+ * weight / bias [rows][N] (row param_row[level]). */
+int effdet_sepconv_meta(void* stream, int dtype, int B, int nlevels, const int* level_hw,
+                        const void* const* in_ptr, const long long* in_image_stride,
+                        const float* in_scale, const float* in_shift, const int* in_affine_row, int pre_act,
+                        const float* dw_w, const void* pw_w, const float* bias, int F, int N,
+                        void* const* out_ptr, const long long* out_image_stride,
+                        float* stat_partial, void* const* dw_out, const long long* dw_out_image_stride);
+int effdet_sepconv_tiles(int dtype, int nlevels, const int* level_hw, int* level_tile_begin);
+int effdet_bn_batch_stats(void* stream, int dtype, const float* partial, int B, int nlevels, const int* level_hw, int N,
+                          const float* weight, const float* bias, const int* param_row, float eps,
+                          float* out_scale, float* out_shift);
+
 /* ---- post-processing ------------------------------------------------------------------------------ */
 
 /* _post_process (effdet/bench.py:12-56).  cls_all [B, n_anchors, C], box_all [B, n_anchors, 4] (dtype);

@@ -53,6 +53,11 @@ SIGNATURES = {
                                       c_int, c_float, c_void_p]),
     'effdet_ood_image_score': (c_int, [c_void_p, c_void_p, c_int, c_ll, c_void_p]),
     'effdet_auroc_counts': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    'effdet_sepconv_meta': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                    c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'effdet_sepconv_tiles': (c_int, [c_int, c_int, c_void_p, c_void_p]),
+    'effdet_bn_batch_stats': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float,
+                                      c_void_p, c_void_p]),
     'effdet_topk_workspace_bytes': (c_ll, [c_int, c_ll]),
     'effdet_topk_select': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_ll, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_ll]),

@@ -33,6 +33,8 @@ struct SepLevel {
     SepInput in[3];
     void* out; long long out_image_stride;
     long long ood_off;
+    int in_affine_row;                         // META: row of in_scale / in_shift for this level
+    void* dw_out; long long dw_out_image_stride;   // META: optional copy of the depthwise output [B, H*W, F]
 };
 struct SepArgs {
     int nlevels; SepLevel lv[5];
@@ -47,6 +49,11 @@ struct SepArgs {
     int F, N;
     int ood_classes, num_anchors;              // > 0: column chunks are cut per anchor
     float* ood_energy; float* ood_maxlogit; long long ood_image_stride;
+    // META (MetaHead, effdet/efficientdet.py:569-695): batch-statistics BN of the previous layer arrives as a per-level
+    // affine applied to the input before the activation, and this layer's outputs are summed for the next one's statistics
+    const float* in_scale; const float* in_shift;   // [rows][F] or null
+    float* stat_partial;                            // [B][tiles][2][N] per-workgroup sums / sums of squares, or null
+    int tiles_total;
 };
 
 constexpr int FC = 64;    // channels per halo pass
@@ -135,7 +142,7 @@ DEV void store_piece(T* dst, const float (&v)[8], int nvalid, bool vec_ok) {
 }
 
 // FT: the channel count when known at compile time (all index arithmetic folds), 0 = read it from the arguments
-template <typename T, int TH, int TW, int BN, bool OOD, int NTH, int FT>
+template <typename T, int TH, int TW, int BN, bool OOD, int NTH, int FT, bool META = false>
 __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void sepconv_kernel(SepArgs p) {
     constexpr int BM = TH * TW;
     constexpr int HW_ = (TH + 2) * (TW + 2);
@@ -245,6 +252,14 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void sepconv_kernel(SepArg
                                     for (int e = 0; e < 8; ++e) v.v[e] = fmaf(xi.v[e], fwm[i], v.v[e]);
                                 }
                             }
+                        }
+                    }
+                    if constexpr (META) {
+                        if (p.in_scale != nullptr) {
+                            const F8 is = load8<float>(p.in_scale + (long long)L.in_affine_row * F + fc0 + cgh * 8);
+                            const F8 it = load8<float>(p.in_shift + (long long)L.in_affine_row * F + fc0 + cgh * 8);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v.v[e] = v.v[e] * is.v[e] + it.v[e];
                         }
                     }
                     if (p.pre_act) {
@@ -388,6 +403,19 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void sepconv_kernel(SepArg
         int n_begin, n_count;
         chunk_range(ch, n_begin, n_count);
         __syncthreads();                               // halo / previous W chunk no longer read
+        if constexpr (META) {
+            if (ch == 0 && L.dw_out != nullptr) {       // x_pred of the reference: the depthwise output before the pointwise conv
+                T* dwo = reinterpret_cast<T*>(L.dw_out) + (long long)b * L.dw_out_image_stride;
+                const int ppf = fbytes / 16;
+                for (int i = tid; i < BM * ppf; i += NTH) {
+                    const int row = i / ppf, piece = i % ppf;
+                    const int y = y0 + row / TW, x = x0 + row % TW;
+                    if (y < H && x < W)
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(dwo + ((long long)y * W + x) * F) + piece * 16) =
+                            *reinterpret_cast<const u32x4*>(At + row * arow + piece * 16);
+                }
+            }
+        }
         if (prefetch) {
 #pragma unroll
             for (int q = 0; q < WPC; ++q) {
@@ -434,6 +462,13 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void sepconv_kernel(SepArg
         }
 
         // Epilogue in registers: per 32-channel group J this lane holds channels [32J + 8fp, +8) of its pixel
+        float st1[META ? NP : 1][8], st2[META ? NP : 1][8];
+        if constexpr (META) {
+#pragma unroll
+            for (int J = 0; J < NP; ++J)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { st1[J][e] = 0.f; st2[J][e] = 0.f; }
+        }
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             float m = -INFINITY, ssum = 0.f;
@@ -459,6 +494,15 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void sepconv_kernel(SepArg
                     const bool group_full = 32 * J + 32 <= n_count;     // uniform: only the last group of a chunk has a tail
                     const int nvalid = group_full ? 8 : n_count - cb;
                     if (pix_in[i] && nvalid > 0) store_piece<T>(out + pix_off[i] + n_begin + cb, vals[J], nvalid, p.vec_ok != 0);
+                    if constexpr (META) {
+                        if (p.stat_partial != nullptr && pix_in[i]) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float q = to_f<T>(from_f<T>(vals[J][e]));   // statistics of what the next layer reads
+                                st1[J][e] += q; st2[J][e] += q * q;
+                            }
+                        }
+                    }
                     if constexpr (OOD) {
                         if (!group_full) {
 #pragma unroll
@@ -505,6 +549,30 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void sepconv_kernel(SepArg
                 }
             }
         }
+        if constexpr (META) {
+            if (p.stat_partial != nullptr) {
+                // per-channel sums over this workgroup's pixels: 16 lanes (pixels) by shuffles, the waves through LDS in a
+                // fixed order, one row of the partial table per workgroup
+                float* sst = cs + 2 * BN;                      // [NWAVE][2][BN]
+#pragma unroll
+                for (int J = 0; J < NP; ++J)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float a = st1[J][e], q = st2[J][e];
+#pragma unroll
+                        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+                        if (frow == 0) { sst[(wave * 2 + 0) * BN + 32 * J + 8 * fpiece + e] = a; sst[(wave * 2 + 1) * BN + 32 * J + 8 * fpiece + e] = q; }
+                    }
+                __syncthreads();
+                if (tid < 2 * BN) {
+                    const int which = tid / BN, n = tid % BN;
+                    float tot = 0.f;
+                    for (int w = 0; w < NWAVE; ++w) tot += sst[(w * 2 + which) * BN + n];
+                    if (n < n_count)
+                        p.stat_partial[(((long long)b * p.tiles_total + blockIdx.x) * 2 + which) * N + n_begin + n] = tot;
+                }
+            }
+        }
     }
 }
 
@@ -519,7 +587,7 @@ size_t sep_lds_bytes(int F) {
     return (halo > wt ? halo : wt) + (size_t)BM * arow + (size_t)9 * F * 4 + (size_t)2 * BN * 4;
 }
 
-template <typename T, int TH, int TW, int BN, bool OOD, int NTH, int FT>
+template <typename T, int TH, int TW, int BN, bool OOD, int NTH, int FT, bool META = false>
 int launch_sep(hipStream_t st, SepArgs& a, int B) {
     int tiles = 0;
     for (int i = 0; i < a.nlevels; ++i) {
@@ -528,9 +596,10 @@ int launch_sep(hipStream_t st, SepArgs& a, int B) {
         a.lv[i].tile_begin = tiles;
         tiles += a.lv[i].tiles_x * a.lv[i].tiles_y;
     }
-    const size_t lds = sep_lds_bytes<T, TH, TW, BN>(a.F);
+    const size_t lds = sep_lds_bytes<T, TH, TW, BN>(a.F) + (META ? (size_t)(NTH / 64) * 2 * BN * 4 : 0);   // + statistics scratch
     if (lds > 160 * 1024) return EFFDET_EINVAL;
-    auto kern = sepconv_kernel<T, TH, TW, BN, OOD, NTH, FT>;
+    a.tiles_total = tiles;
+    auto kern = sepconv_kernel<T, TH, TW, BN, OOD, NTH, FT, META>;
     if (lds > 64 * 1024) {
         static bool attr_done = false;           // one per template instantiation
         if (!attr_done) {
@@ -564,7 +633,16 @@ int dispatch_sep(hipStream_t st, SepArgs& a, int B) {
 }  // namespace
 
 // Flat C-ABI descriptor (mirrors SepArgs; arrays are per level / per input)
-extern "C" int effdet_sepconv_fused(
+namespace {
+struct MetaExtra {
+    const float* in_scale; const float* in_shift; const int* in_affine_row;
+    float* stat_partial;
+    void* const* dw_out; const long long* dw_out_image_stride;
+};
+}
+
+static int sepconv_common(
+    const MetaExtra* meta,
     void* stream, int dtype, int B, int nlevels,
     const int* level_hw,                  // [nlevels][2]  output H, W
     int n_in,
@@ -579,7 +657,6 @@ extern "C" int effdet_sepconv_fused(
     void* const* out_ptr, const long long* out_image_stride,   // [nlevels]
     int ood_classes, int num_anchors, float* ood_energy, float* ood_maxlogit,
     long long ood_image_stride, const long long* ood_level_off) {
-    EFFDET_ENTER();
     if (nlevels < 1 || nlevels > 5 || n_in < 1 || n_in > 3 || B <= 0) return EFFDET_EINVAL;
     if (!level_hw || !in_ptr || !in_image_stride || !in_hw || !in_mode || !dw_w || !pw_w || !shift || !affine_row ||
         !out_ptr || !out_image_stride) return EFFDET_EINVAL;
@@ -598,8 +675,15 @@ extern "C" int effdet_sepconv_fused(
     a.pre_act = pre_act; a.post_act = post_act; a.dw_w = dw_w; a.pw_w = pw_w; a.scale = scale; a.shift = shift;
     a.F = F; a.N = N; a.ood_classes = ood_classes > 0 ? ood_classes : 0; a.num_anchors = num_anchors;
     a.ood_energy = ood_energy; a.ood_maxlogit = ood_maxlogit; a.ood_image_stride = ood_image_stride;
+    a.in_scale = meta ? meta->in_scale : nullptr; a.in_shift = meta ? meta->in_shift : nullptr;
+    a.stat_partial = meta ? meta->stat_partial : nullptr; a.tiles_total = 0;
+    if (meta && ((meta->in_scale != nullptr) != (meta->in_shift != nullptr) || (meta->in_scale && !meta->in_affine_row))) return EFFDET_EINVAL;
     for (int l = 0; l < nlevels; ++l) {
         SepLevel& L = a.lv[l];
+        L.in_affine_row = (meta && meta->in_affine_row) ? meta->in_affine_row[l] : 0;
+        L.dw_out = (meta && meta->dw_out) ? meta->dw_out[l] : nullptr;
+        L.dw_out_image_stride = (meta && meta->dw_out_image_stride) ? meta->dw_out_image_stride[l] : 0;
+        if (L.dw_out && reinterpret_cast<uintptr_t>(L.dw_out) % 16) return EFFDET_EINVAL;
         L.H = level_hw[2 * l]; L.W = level_hw[2 * l + 1];
         if (L.H <= 0 || L.W <= 0) return EFFDET_EINVAL;
         L.affine_row = affine_row[l];
@@ -623,8 +707,107 @@ extern "C" int effdet_sepconv_fused(
         }
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (meta) {                                  // MetaHead layers: generic-width kernels with the extra inputs / outputs
+        if (ood_classes > 0 || fuse_mode != 0) return EFFDET_EINVAL;
+        return dtype == 0 ? launch_sep<float, 8, 8, 64, false, 256, 0, true>(st, a, B)
+                          : launch_sep<bf16_t, 8, 16, 64, false, 512, 0, true>(st, a, B);
+    }
     if (dtype == 0) return dispatch_sep<float, 8, 8, 256>(st, a, B);
     // bf16: 512 threads per 8x16 tile - the LDS footprint allows two workgroups per CU, so four waves per SIMD
     // share the VALU-heavy halo and epilogue phases
     return dispatch_sep<bf16_t, 8, 16, 512>(st, a, B);
+}
+
+extern "C" int effdet_sepconv_fused(
+    void* stream, int dtype, int B, int nlevels, const int* level_hw, int n_in,
+    const void* const* in_ptr, const long long* in_image_stride, const int* in_hw, const int* in_mode,
+    int fuse_mode, const float* fuse_w, float fuse_den, int pre_act,
+    const float* dw_w, const void* pw_w, const float* scale, const float* shift, const int* affine_row,
+    int post_act, int F, int N, void* const* out_ptr, const long long* out_image_stride,
+    int ood_classes, int num_anchors, float* ood_energy, float* ood_maxlogit,
+    long long ood_image_stride, const long long* ood_level_off) {
+    EFFDET_ENTER();
+    return sepconv_common(nullptr, stream, dtype, B, nlevels, level_hw, n_in, in_ptr, in_image_stride, in_hw, in_mode,
+                          fuse_mode, fuse_w, fuse_den, pre_act, dw_w, pw_w, scale, shift, affine_row, post_act, F, N,
+                          out_ptr, out_image_stride, ood_classes, num_anchors, ood_energy, ood_maxlogit, ood_image_stride, ood_level_off);
+}
+
+// One MetaHead layer for all levels (effdet/efficientdet.py:655-676): the previous layer's batch-statistics BN arrives as
+// in_scale / in_shift [rows][F] (row in_affine_row[level]; null for the first layer) applied before the SiLU, the conv
+// output (+ bias) is written raw, and its per-channel sums / sums of squares go to stat_partial
+// [B][effdet_sepconv_tiles][2][N] for effdet_bn_batch_stats.  dw_out (optional, per level [B, H*W, F]) receives the
+// depthwise output (`x_pred`, what ret_activs returns).
+extern "C" int effdet_sepconv_meta(
+    void* stream, int dtype, int B, int nlevels, const int* level_hw,
+    const void* const* in_ptr, const long long* in_image_stride,
+    const float* in_scale, const float* in_shift, const int* in_affine_row, int pre_act,
+    const float* dw_w, const void* pw_w, const float* bias, int F, int N,
+    void* const* out_ptr, const long long* out_image_stride,
+    float* stat_partial, void* const* dw_out, const long long* dw_out_image_stride) {
+    EFFDET_ENTER();
+    if (nlevels < 1 || nlevels > 5 || !level_hw) return EFFDET_EINVAL;
+    int in_hw[10], in_mode[5], arow[5];
+    for (int l = 0; l < nlevels; ++l) { in_hw[2 * l] = level_hw[2 * l]; in_hw[2 * l + 1] = level_hw[2 * l + 1]; in_mode[l] = 0; arow[l] = 0; }
+    MetaExtra m{in_scale, in_shift, in_affine_row, stat_partial, dw_out, dw_out_image_stride};
+    return sepconv_common(&m, stream, dtype, B, nlevels, level_hw, 1, in_ptr, in_image_stride, in_hw, in_mode,
+                          0, nullptr, 1.f, pre_act, dw_w, pw_w, nullptr, bias, arow, 0, F, N,
+                          out_ptr, out_image_stride, 0, 0, nullptr, nullptr, 0, nullptr);
+}
+
+// Tiles per image of a multi-level launch (rows of stat_partial per image) and the first tile of every level
+extern "C" int effdet_sepconv_tiles(int dtype, int nlevels, const int* level_hw, int* level_tile_begin) {
+    if (nlevels < 1 || nlevels > 5 || !level_hw || (dtype & ~1)) return EFFDET_EINVAL;
+    const int TH = 8, TW = dtype == 0 ? 8 : 16;
+    int tiles = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        if (level_tile_begin) level_tile_begin[l] = tiles;
+        tiles += ((level_hw[2 * l + 1] + TW - 1) / TW) * ((level_hw[2 * l] + TH - 1) / TH);
+    }
+    return tiles;
+}
+
+namespace {
+struct BnStatArgs {
+    const float* partial; int B, tiles_total, N;
+    int nlevels; int tile_begin[6]; int count[5];       // pixels per level (B*H*W)
+    const float* weight; const float* bias; int param_row[5];
+    float eps; float* out_scale; float* out_shift;       // [nlevels][N]
+};
+
+// F.batch_norm(training=True) of one (level, layer): mean / biased variance over B*H*W from the per-workgroup sums
+// (fixed order, double accumulation), folded with the affine parameters into scale / shift for the next layer's load
+__global__ __launch_bounds__(256) void bn_batch_stats_kernel(BnStatArgs p) {
+    const int l = blockIdx.x;
+    for (int n = threadIdx.x; n < p.N; n += 256) {
+        double s = 0.0, q = 0.0;
+        for (int b = 0; b < p.B; ++b)
+            for (int t = p.tile_begin[l]; t < p.tile_begin[l + 1]; ++t) {
+                const float* row = p.partial + (((long long)b * p.tiles_total + t) * 2) * p.N;
+                s += (double)row[n]; q += (double)row[p.N + n];
+            }
+        const double mean = s / p.count[l];
+        double var = q / p.count[l] - mean * mean; if (var < 0.0) var = 0.0;
+        const float w = p.weight[(long long)p.param_row[l] * p.N + n], bb = p.bias[(long long)p.param_row[l] * p.N + n];
+        const float sc = w / sqrtf((float)var + p.eps);
+        p.out_scale[(long long)l * p.N + n] = sc;
+        p.out_shift[(long long)l * p.N + n] = bb - (float)mean * sc;
+    }
+}
+}  // namespace
+
+extern "C" int effdet_bn_batch_stats(void* stream, int dtype, const float* partial, int B, int nlevels, const int* level_hw, int N,
+                                     const float* weight, const float* bias, const int* param_row, float eps,
+                                     float* out_scale, float* out_shift) {
+    EFFDET_ENTER();
+    if (!partial || !level_hw || !weight || !bias || !param_row || !out_scale || !out_shift || B <= 0 || N <= 0 || nlevels < 1 || nlevels > 5) return EFFDET_EINVAL;
+    BnStatArgs a; a.partial = partial; a.B = B; a.N = N; a.nlevels = nlevels; a.weight = weight; a.bias = bias; a.eps = eps;
+    a.out_scale = out_scale; a.out_shift = out_shift;
+    int tb[5];
+    const int tiles = effdet_sepconv_tiles(dtype, nlevels, level_hw, tb);
+    if (tiles <= 0) return EFFDET_EINVAL;
+    a.tiles_total = tiles;
+    for (int l = 0; l < nlevels; ++l) { a.tile_begin[l] = tb[l]; a.count[l] = B * level_hw[2 * l] * level_hw[2 * l + 1]; a.param_row[l] = param_row[l]; }
+    a.tile_begin[nlevels] = tiles;
+    hipLaunchKernelGGL(bn_batch_stats_kernel, dim3(nlevels), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return effdet_check_launch();
 }

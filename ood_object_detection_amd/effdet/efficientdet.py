@@ -348,7 +348,13 @@ class EfficientDet(nn.Module):
 
     def forward(self, x, fast_weights=None, ret_activs=False, mode='full_net'):
         if mode in ('supp_cls', 'qry_cls'):
-            raise NotImplementedError("mode %r needs MetaHead (effdet/efficientdet.py:569-695), listed as 'next' in DESIGN.md" % mode)
+            from .meta_head import MetaHead
+            if not isinstance(self.class_net, MetaHead):
+                raise RuntimeError("mode %r needs `model.class_net = MetaHead(...)` as in infer.py:191" % mode)
+            if mode == 'supp_cls':        # efficientdet.py:896-897 (level_offset = FLAGS.supp_level_offset, default 0)
+                return self.class_net(x, fast_weights=fast_weights, ret_activs=True,
+                                      level_offset=getattr(self.config, 'supp_level_offset', 0), heads='both')
+            return self.class_net(x, fast_weights=fast_weights, ret_activs=ret_activs, heads='None')
         if mode not in _MODES:
             raise ValueError('unknown mode %r' % (mode,))
         if fast_weights is not None or ret_activs:
@@ -392,3 +398,5 @@ def _run(model, x, mode):
     cls_o, box_o = eng.run_heads(x, True, True)
     model.ood_energy, model.ood_max_logit = eng.ood_energy, eng.ood_max_logit
     return cls_o, box_o
+
+from .meta_head import MetaHead  # noqa: E402,F401  (reference: effdet/efficientdet.py:569)

@@ -305,3 +305,30 @@ def ood_scores(cls_outs, num_classes):
     B = cls_outs[0].shape[0]
     z = torch.cat([o.permute(0, 2, 3, 1).reshape(B, -1, num_classes) for o in cls_outs], 1).float()
     return -torch.logsumexp(z, dim=2), z.amax(dim=2)
+
+
+def meta_head_forward(conv_dw_rep, conv_pw_rep, conv_pb_rep, bn_rep_w, bn_rep_b, predict, x, level_offset=0,
+                      predict_class=None, eps=1e-5):
+    """MetaHead.forward (effdet/efficientdet.py:636-695) with explicit weight lists in the reference's order
+    (bn lists are level-major: index level * num_layers + rep).  Returns (outputs, x_pred activations[, class_outputs]).
+    Parity unpinned: the reference class allocates CUDA buffers in __init__ and cannot be instantiated in the CPU
+    container; this is a line-by-line restatement of its forward."""
+    num_layers = len(conv_dw_rep)
+    outputs, activs, class_outputs = [], [], []
+    for level in range(level_offset, len(x)):
+        x_level = x[level].float()
+        bn_w_lev = bn_rep_w[level * num_layers:(level + 1) * num_layers]
+        bn_b_lev = bn_rep_b[level * num_layers:(level + 1) * num_layers]
+        for conv_dw, conv_pw, conv_pb, bn_w, bn_b in zip(conv_dw_rep, conv_pw_rep, conv_pb_rep, bn_w_lev, bn_b_lev):
+            x_level = F.pad(x_level, (1, 1, 1, 1))
+            x_level = F.conv2d(x_level, conv_dw.float(), groups=conv_dw.shape[0], padding=(0, 0))
+            x_level = F.conv2d(x_level, conv_pw.float(), bias=conv_pb.float())
+            x_level = F.batch_norm(x_level, None, None, bn_w.float(), bn_b.float(), training=True, eps=eps)
+            x_level = x_level * torch.sigmoid(x_level)
+        x_pred = F.pad(x_level, (1, 1, 1, 1))
+        x_pred = F.conv2d(x_pred, predict[0].float(), groups=predict[0].shape[0])
+        activs.append(x_pred)
+        outputs.append(F.conv2d(x_pred, predict[1].float(), bias=predict[2].float()))
+        if predict_class is not None:
+            class_outputs.append(F.conv2d(x_pred, predict_class[0].float(), bias=predict_class[1].float()))
+    return (outputs, activs, class_outputs) if predict_class is not None else (outputs, activs)

@@ -241,3 +241,82 @@ def test_detbench_bench_size_properties():
     ood = bench.last_ood
     assert torch.isfinite(ood['anchor_energy']).all() and torch.all(-ood['anchor_energy'] >= ood['anchor_max_logit'] - 1e-4)
     assert torch.isfinite(ood['energy'][:, :1]).all()
+
+
+def _meta_head(dtype, seed=5):
+    from ood_object_detection_amd.effdet.meta_head import MetaHead
+    model, cfg, nodes, sd = seeded_model('tf_efficientdet_d0', 128, 20, seed=2)
+    init = {k: v for k, v in model.state_dict().items() if k.startswith('class_net.')}
+    torch.manual_seed(seed)
+    mh = MetaHead(model.config, pretrain_init=init)
+    with torch.no_grad():                       # non-trivial BN affine parameters
+        for n, p in mh.named_parameters():
+            if n.startswith('bn_w'):
+                p.copy_(1.0 + 0.2 * torch.randn_like(p))
+            if n.startswith('bn_b'):
+                p.copy_(0.1 * torch.randn_like(p))
+    return model, mh.to(DEV).to(dtype)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_meta_head_forward(dtype):
+    """MetaHead (functional class head with batch-statistics BN) vs the oracle restatement of efficientdet.py:636-695:
+    outputs, x_pred activations, fast_weights path, level_offset and the separate class head."""
+    model, mh = _meta_head(dtype)
+    F_, B = model.config.fpn_channels, 3
+    sizes = [16, 8, 4, 2, 1]
+    x = [torch.from_numpy(seeded_array(31, 'lvl%d' % i, (B, F_, s, s))).to(DEV).to(dtype) for i, s in enumerate(sizes)]
+    xr = [t.float().cpu() for t in x]
+
+    def close(a, b):
+        a = a.float().cpu()
+        if dtype == torch.float32:
+            return float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max()))
+        # bf16 (measured, not assumed): batch statistics over a handful of pixels (the 1x1 and 2x2 levels) amplify the
+        # rounding noise, so the check is on the relative rms error of the whole tensor
+        return float((a - b).norm()) <= 0.05 * max(float(b.norm()), 1e-3)
+
+    P = lambda ps: [p.detach().float().cpu() for p in ps]
+    with torch.no_grad():
+        outs, activs = mh(x, ret_activs=True)
+        ro, ra = om.meta_head_forward(P(mh.conv_dw_rep), P(mh.conv_pw_rep), P(mh.conv_pb_rep), P(mh.bn_rep_w), P(mh.bn_rep_b), P(mh.predict), xr)
+        for a, b in zip(outs + activs, ro + ra):
+            assert tuple(a.shape) == tuple(b.shape)
+            assert close(a, b)
+        # fast weights (reference list order) = the module's own parameters -> same result; level_offset drops levels
+        fw = mh.conv_dw_rep + mh.conv_pw_rep + mh.conv_pb_rep + mh.predict + mh.bn_rep_w + mh.bn_rep_b
+        outs2 = mh(x, fast_weights=fw)
+        for a, b in zip(outs, outs2):
+            assert torch.equal(a, b)
+        outs3 = mh(x, level_offset=2)
+        assert len(outs3) == 3 and all(torch.equal(a, b) for a, b in zip(outs3, outs[2:]))
+        # separate class head on the same x_pred (heads='both')
+        mh.add_head()
+        mh.to(DEV).to(dtype)
+        co, ao, act = mh(x, ret_activs=True, heads='both')
+        rco = om.meta_head_forward(P(mh.conv_dw_rep), P(mh.conv_pw_rep), P(mh.conv_pb_rep), P(mh.bn_rep_w), P(mh.bn_rep_b), P(mh.predict), xr,
+                                   predict_class=P(mh.predict_class))[2]
+        for a, b in zip(co, rco):
+            assert close(a, b)
+        assert all(torch.equal(a, b) for a, b in zip(ao, outs))
+
+
+def test_meta_head_modes_through_model():
+    """EfficientDet.forward(mode='qry_cls' / 'supp_cls') with model.class_net = MetaHead(...) (infer.py:191,359,681) on the
+    model's own BiFPN outputs (zero-copy pyramid views)."""
+    import copy
+    model, mh = _meta_head(torch.float32)
+    model = copy.deepcopy(model).to(DEV)
+    x = torch.from_numpy(seeded_array(32, 'img', (2, 3, 128, 128))).to(DEV)
+    with torch.no_grad():
+        activs = model(x, mode='supp_bb')
+        model.class_net = mh
+        q = model(activs, mode='qry_cls')
+        P = lambda ps: [p.detach().float().cpu() for p in ps]
+        ro, ra = om.meta_head_forward(P(mh.conv_dw_rep), P(mh.conv_pw_rep), P(mh.conv_pb_rep), P(mh.bn_rep_w), P(mh.bn_rep_b), P(mh.predict),
+                                      [a.float().cpu() for a in activs])
+        for a, b in zip(q, ro):
+            assert float((a.float().cpu() - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max()))
+        mh.add_head(); mh.to(DEV)
+        co, ao, act = model(activs, mode='supp_cls')
+        assert len(co) == len(ao) == len(act) == 5
