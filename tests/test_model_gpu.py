@@ -63,7 +63,7 @@ def test_fp32_modes_consistent(d0):
     assert all(torch.equal(a, b) for a, b in zip(c3, cls_full)) and all(torch.equal(a, b) for a, b in zip(b3, box_full))
     a4, b4 = m(feats, mode='not_cls')
     assert all(torch.equal(a, b) for a, b in zip(b4, box_full))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):          # the MetaHead modes need model.class_net = MetaHead(...) first (infer.py:191)
         m(activs, mode='qry_cls')
 
 
