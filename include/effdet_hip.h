@@ -52,6 +52,15 @@ int effdet_stem_dw_tiles_per_image(int H, int W);
  * (host arrays of C <= 4 floats), y in out_dtype.  The *_u8 stem entry points apply the same arithmetic
  * (result rounded to the model dtype, exactly what feeding the normalised tensor would give) while loading
  * the input patch, so a uint8 batch needs no separate pass. */
+/* ResizePad (effdet/data/transforms.py:75-107): Pillow's 8-bit BILINEAR resize of an HWC uint8 image [h][w][3] to
+ * sw x sh, pasted top-left on an S x S canvas of fill_rgb (host array of 3 ints), written planar [3][S][S].  bounds_*
+ * [out][2] = (first source index, count) and coef_* [out][ksize] are Pillow's integer coefficient tables (22 fractional
+ * bits; device pointers, built by the caller as Pillow's precompute_coeffs / normalize_coeffs_8bpc do); workspace:
+ * h*sw*3 bytes.  Bit-identical to Image.resize(.., BILINEAR) + paste. */
+int effdet_resize_pad_u8(void* stream, const unsigned char* src, int h, int w, unsigned char* dst, int S, int sw, int sh,
+                         const int* bounds_x, const int* coef_x, int ksize_x,
+                         const int* bounds_y, const int* coef_y, int ksize_y,
+                         const int* fill_rgb, unsigned char* workspace);
 int effdet_normalize_u8(void* stream, int out_dtype, const unsigned char* X, const float* mean, const float* stdv,
                         void* Y, int B, int C, long long hw);
 int effdet_stem_conv_u8(void* stream, int out_dtype, const unsigned char* X, const float* mean, const float* stdv,

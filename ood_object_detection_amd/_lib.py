@@ -23,6 +23,8 @@ SIGNATURES = {
                                  c_int, c_int, c_int, c_int]),
     'effdet_stem_dw_fused': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
+    'effdet_resize_pad_u8': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+                                     c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'effdet_normalize_u8': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll]),
     'effdet_stem_conv_u8': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int, c_int, c_int, c_int]),

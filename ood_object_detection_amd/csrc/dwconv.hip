@@ -418,3 +418,74 @@ extern "C" int effdet_maxpool_same(void* stream, int dtype, const void* X, long 
     else hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, a);
     return effdet_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------
+// ResizePad (effdet/data/transforms.py:75-107) = Pillow's 8-bit BILINEAR resample + paste on a fill-colour canvas.
+// The integer coefficient tables (Pillow's precompute_coeffs + normalize_coeffs_8bpc, 22 fractional bits) are built on
+// the host in double precision exactly as Pillow does; the device only does the integer passes, so results are
+// bit-identical to `Image.resize(.., Image.BILINEAR)`: horizontal pass -> 8-bit temporary -> vertical pass.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct ResizeArgs {
+    const unsigned char* src; unsigned char* tmp; unsigned char* dst;
+    int h, w, sw, sh, S;
+    const int* bx; const int* kx; int ksx;       // [sw][2], [sw][ksx]
+    const int* by; const int* ky; int ksy;       // [sh][2], [sh][ksy]
+    int fill[3];
+};
+
+DEV unsigned char clip8(int v) { v >>= 22; return (unsigned char)(v < 0 ? 0 : v > 255 ? 255 : v); }
+
+// src HWC [h][w][3] -> tmp HWC [h][sw][3]
+__global__ __launch_bounds__(256) void resize_h_kernel(ResizeArgs p) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)p.h * p.sw) return;
+    const int y = (int)(i / p.sw), xx = (int)(i % p.sw);
+    const int xmin = p.bx[2 * xx], cnt = p.bx[2 * xx + 1];
+    const int* k = p.kx + (long long)xx * p.ksx;
+    int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+    const unsigned char* row = p.src + ((long long)y * p.w + xmin) * 3;
+    for (int x = 0; x < cnt; ++x) { const int c = k[x]; s0 += row[3 * x] * c; s1 += row[3 * x + 1] * c; s2 += row[3 * x + 2] * c; }
+    unsigned char* o = p.tmp + ((long long)y * p.sw + xx) * 3;
+    o[0] = clip8(s0); o[1] = clip8(s1); o[2] = clip8(s2);
+}
+
+// tmp HWC [h][sw][3] -> dst CHW [3][S][S] (top-left paste, fill elsewhere)
+__global__ __launch_bounds__(256) void resize_v_paste_kernel(ResizeArgs p) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)p.S * p.S) return;
+    const int yy = (int)(i / p.S), xx = (int)(i % p.S);
+    int v0 = p.fill[0], v1 = p.fill[1], v2 = p.fill[2];
+    if (yy < p.sh && xx < p.sw) {
+        const int ymin = p.by[2 * yy], cnt = p.by[2 * yy + 1];
+        const int* k = p.ky + (long long)yy * p.ksy;
+        int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+        for (int y = 0; y < cnt; ++y) {
+            const unsigned char* px = p.tmp + ((long long)(ymin + y) * p.sw + xx) * 3;
+            const int c = k[y];
+            s0 += px[0] * c; s1 += px[1] * c; s2 += px[2] * c;
+        }
+        v0 = clip8(s0); v1 = clip8(s1); v2 = clip8(s2);
+    }
+    const long long plane = (long long)p.S * p.S;
+    p.dst[i] = (unsigned char)v0; p.dst[plane + i] = (unsigned char)v1; p.dst[2 * plane + i] = (unsigned char)v2;
+}
+
+}  // namespace
+
+extern "C" int effdet_resize_pad_u8(void* stream, const unsigned char* src, int h, int w, unsigned char* dst, int S, int sw, int sh,
+                                    const int* bounds_x, const int* coef_x, int ksize_x,
+                                    const int* bounds_y, const int* coef_y, int ksize_y,
+                                    const int* fill_rgb, unsigned char* workspace) {
+    EFFDET_ENTER();
+    if (!src || !dst || !bounds_x || !coef_x || !bounds_y || !coef_y || !fill_rgb || !workspace) return EFFDET_EINVAL;
+    if (h <= 0 || w <= 0 || S <= 0 || sw <= 0 || sh <= 0 || sw > S || sh > S || ksize_x <= 0 || ksize_y <= 0) return EFFDET_EINVAL;
+    ResizeArgs a{src, workspace, dst, h, w, sw, sh, S, bounds_x, coef_x, ksize_x, bounds_y, coef_y, ksize_y,
+                 {fill_rgb[0], fill_rgb[1], fill_rgb[2]}};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long long n1 = (long long)h * sw, n2 = (long long)S * S;
+    hipLaunchKernelGGL(resize_h_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(resize_v_paste_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, a);
+    return effdet_check_launch();
+}

@@ -586,3 +586,17 @@ def test_topk_full_size_properties(dtype):
         assert torch.equal(v, ref)
         bflat = torch.cat([b.permute(0, 2, 3, 1).reshape(B, -1, 4) for b in box], 1)
         assert torch.equal(boxes, bflat.gather(1, idx.unsqueeze(-1).expand(-1, -1, 4)))
+
+
+@pytest.mark.parametrize('hw', [(480, 640), (333, 500), (64, 48), (100, 37), (128, 128), (720, 1280)])
+def test_resize_pad_u8(hw):
+    """Device ResizePad vs the oracle (itself pinned bit-exactly against PIL): bit exact, CHW output."""
+    from oracle import preprocess as opre
+    from ood_object_detection_amd.effdet.preprocess import resize_pad, resolve_fill_color
+    rng = np.random.RandomState(hw[0] * 7 + hw[1])
+    img = rng.randint(0, 256, (hw[0], hw[1], 3)).astype(np.uint8)
+    fill = resolve_fill_color('mean')
+    ref, rs = opre.resize_pad(img, 128, fill)
+    got, gs = resize_pad(torch.from_numpy(img).to(DEV), 128, fill)
+    assert gs == rs
+    assert np.array_equal(got.cpu().numpy(), np.transpose(ref, (2, 0, 1)))

@@ -164,3 +164,23 @@ def test_clip_adam_oracle_matches_torch():
         ref = np.concatenate([q.detach().numpy().ravel() for q in params])
         assert abs(float(tn) - float(n)) < 1e-4 * max(1.0, float(tn))
         assert np.abs(p - ref).max() < 2e-6
+
+
+@pytest.mark.parametrize('hw', [(480, 640), (333, 500), (64, 48), (100, 37), (640, 640), (720, 1280)])
+def test_resize_pad_matches_pil(hw):
+    """oracle/preprocess.py::resize_pad vs the reference's ResizePad arithmetic executed with PIL itself
+    (effdet/data/transforms.py:82-94): Image.new + resize(BILINEAR) + paste - bit exact, down- and up-scaling."""
+    Image = pytest.importorskip('PIL.Image')
+    from oracle import preprocess as opre
+    rng = np.random.RandomState(hw[0] + hw[1])
+    img = rng.randint(0, 256, (hw[0], hw[1], 3)).astype(np.uint8)
+    target = 128
+    fill = opre.resolve_fill_color('mean')
+    pim = Image.fromarray(img)
+    width, height = pim.size
+    s = min(target / height, target / width)
+    new_img = Image.new('RGB', (target, target), color=fill)
+    new_img.paste(pim.resize((int(width * s), int(height * s)), Image.BILINEAR))
+    got, inv_scale = opre.resize_pad(img, target, fill)
+    assert np.array_equal(got, np.asarray(new_img))
+    assert inv_scale == 1.0 / s
