@@ -69,7 +69,7 @@ int effdet_stem_dw_fused_u8(void* stream, int dtype, const unsigned char* X, con
                             const void* Wk, const float* s1, const float* t1, const float* taps, const float* s2, const float* t2,
                             void* Y, float* pool_partial, int B, int H, int W, int C);
 
-/* 1x1 conv as GEMM with folded BN / bias, optional SiLU (act=1), optional SE gate on A
+/* 1x1 conv as GEMM with folded BN / bias, optional SiLU (act=1) or ReLU (act=2), optional SE gate on A
  * (gate [B,K] fp32, rows_per_image = H*W), optional residual [M,N].  A: [M,K], W: [N,K].
  * Output row m goes to C + (m / rows_per_image) * c_image_stride + (m % rows_per_image) * ldc
  * (pass 0 for rows_per_image / c_image_stride / ldc to get a plain [M,N] matrix).
@@ -215,6 +215,10 @@ long long effdet_label_anchors_workspace_bytes(int B, int Mmax, long long N);
 int effdet_label_anchors(void* stream, const float* anchors, const float* gt_boxes, const long long* gt_cls,
                          int B, int Mmax, long long N, float match_threshold, long long* cls_t, float* box_t,
                          float* num_positives, long long* match, void* workspace, long long workspace_bytes);
+
+/* ProjectionNet.weighted_median (effdet/efficientdet.py:748-760): per column of embds [n][d] (n <= 1024), the value at
+ * which the cumulative confidence (in ascending value order) first reaches half of sum(confs); conf_sum[0] = that sum. */
+int effdet_weighted_median(void* stream, const float* embds, const float* confs, int n, int d, float* med, float* conf_sum);
 
 /* ---- optimizer half of the pretrain step (pretrain.py:272-276) ------------------------------------ */
 

@@ -49,6 +49,7 @@ SIGNATURES = {
                                      P(c_void_p), P(c_ll), P(c_int), P(c_int), c_int, P(c_float), c_float, c_int,
                                      c_void_p, c_void_p, c_void_p, c_void_p, P(c_int), c_int, c_int, c_int,
                                      P(c_void_p), P(c_ll), c_int, c_int, c_void_p, c_void_p, c_ll, P(c_ll)]),
+    'effdet_weighted_median': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'effdet_sqnorm_workspace_floats': (c_ll, []),
     'effdet_sqnorm': (c_int, [c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_int]),
     'effdet_adam_clip_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_float, c_float, c_float, c_float,

@@ -909,3 +909,46 @@ extern "C" int effdet_gather_ood(void* stream, const int* keep_src, const long l
                        keep_src, indices, energy, maxlogit, n_anchors, k, max_det, B, out_energy, out_maxlogit);
     return effdet_check_launch();
 }
+
+// ProjectionNet.weighted_median (effdet/efficientdet.py:748-760): per column of embds [n][d], sort ascending carrying the
+// anchor confidences, cumulative sum, first position where it reaches half the total -> that value.  One workgroup
+// per column, n <= 1024; equal values keep their original order (stable), as the reference's sort does on the CPU.
+namespace {
+__global__ __launch_bounds__(256) void weighted_median_kernel(const float* embds, const float* confs, int n, int d,
+                                                              float* med, float* conf_sum) {
+    __shared__ unsigned long long key[1024];           // ordered float key << 32 | row
+    __shared__ float cs[1024];
+    const int col = blockIdx.x, tid = threadIdx.x;
+    int P = 1; while (P < n) P <<= 1;
+    for (int i = tid; i < P; i += 256)
+        key[i] = i < n ? (((unsigned long long)float_key(embds[(long long)i * d + col]) << 32) | (unsigned)i) : ~0ull;
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < (P >> 1); i += 256) {
+                const int pos = 2 * i - (i & (stride - 1));
+                const unsigned long long a = key[pos], c = key[pos + stride];
+                const bool asc = (pos & size) == 0;
+                if ((a > c) == asc) { key[pos] = c; key[pos + stride] = a; }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < n; i += 256) cs[i] = confs[(unsigned)(key[i] & 0xFFFFFFFFull)];
+    __syncthreads();
+    if (tid == 0) {                                     // n <= 1024: a serial scan in the reference's summation order
+        float total = 0.f;
+        for (int i = 0; i < n; ++i) total += confs[i];
+        float run = 0.f; int idx = 0; bool found = false;
+        for (int i = 0; i < n; ++i) { run += cs[i]; if (!found && run >= total / 2) { idx = i; found = true; } }
+        med[col] = key_float((unsigned)(key[idx] >> 32));
+        if (col == 0) conf_sum[0] = total;
+    }
+}
+}  // namespace
+
+extern "C" int effdet_weighted_median(void* stream, const float* embds, const float* confs, int n, int d, float* med, float* conf_sum) {
+    EFFDET_ENTER();
+    if (!embds || !confs || !med || !conf_sum || n <= 0 || n > 1024 || d <= 0) return EFFDET_EINVAL;
+    hipLaunchKernelGGL(weighted_median_kernel, dim3(d), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), embds, confs, n, d, med, conf_sum);
+    return effdet_check_launch();
+}

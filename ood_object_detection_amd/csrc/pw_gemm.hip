@@ -1,7 +1,7 @@
 // Pointwise (1x1) convolution as an MFMA GEMM with fused per-channel affine (folded BN / bias),
 // optional SiLU, optional SE gate on the input channels and optional residual add.
 //
-//   C[m, n] = act( (sum_k A[m,k] * gate[img(m),k] * W[n,k]) * scale[n] + shift[n] ) + R[m,n]
+//   C[m, n] = act( (sum_k A[m,k] * gate[img(m),k] * W[n,k]) * scale[n] + shift[n] ) + R[m,n]      act: none / SiLU / ReLU
 //
 // Replaces the 1x1 `create_conv2d` + BatchNorm2d (+ Swish) call sites of the reference:
 //   timm EfficientNet conv_pw / conv_pwl (effdet/efficientdet.py:837) and the BiFPN lateral
@@ -213,6 +213,9 @@ __global__ __launch_bounds__(NTH, 2) void pw_gemm_kernel(PwArgs p) {
                     if (p.act == 1) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = silu_t<T>(v[e]);
+                    } else if (p.act == 2) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                     }
                     T* dst = Cb + (long long)pix[i] * p.ldc + n0 + cb;
                     if (Rb != nullptr) {
@@ -283,7 +286,7 @@ extern "C" int effdet_pw_gemm_bn_act(void* stream, int dtype,
     EFFDET_ENTER();
     if (!A || !W || !C || !shift || M <= 0 || K <= 0 || N <= 0) return EFFDET_EINVAL;
     if (K % 8 != 0 || M > 0x7fffffffLL) return EFFDET_EINVAL;   // 16-byte pieces along K; 32-bit row arithmetic
-    if (act != 0 && act != 1) return EFFDET_EINVAL;
+    if (act < 0 || act > 2) return EFFDET_EINVAL;                  // 0 none, 1 SiLU, 2 ReLU
     if (rows_per_image <= 0) { rows_per_image = (int)(M > 0x7fffffffLL ? 0x7fffffff : M); }
     if ((M % rows_per_image) != 0) return EFFDET_EINVAL;         // workgroups never straddle images
     if (ldc <= 0) ldc = N;

@@ -400,3 +400,4 @@ def _run(model, x, mode):
     return cls_o, box_o
 
 from .meta_head import MetaHead  # noqa: E402,F401  (reference: effdet/efficientdet.py:569)
+from .aux_nets import AnchorNet, ProjectionNet  # noqa: E402,F401  (reference: effdet/efficientdet.py:697,765)

@@ -332,3 +332,46 @@ def meta_head_forward(conv_dw_rep, conv_pw_rep, conv_pb_rep, bn_rep_w, bn_rep_b,
         if predict_class is not None:
             class_outputs.append(F.conv2d(x_pred, predict_class[0].float(), bias=predict_class[1].float()))
     return (outputs, activs, class_outputs) if predict_class is not None else (outputs, activs)
+
+
+def anchor_net_forward(sd, x, num_levels, eps=1e-3, prefix=''):
+    """AnchorNet.forward (effdet/efficientdet.py:817-830) from a state dict: per level conv_rep[i] (SeparableConv, TF-SAME
+    3x3 = symmetric pad 1) -> bn_rep[i][level] (eval) -> Swish, then anchor_out.  Parity unpinned (FLAGS-driven
+    constructor; restated from the forward)."""
+    outs = []
+    n_rep = len({k.split('.')[1] for k in sd if k.startswith(prefix + 'conv_rep.')})
+    for level in range(len(x)):
+        t = x[level].float()
+        for i in range(n_rep):
+            p = '%sconv_rep.%d.' % (prefix, i)
+            t = F.conv2d(F.pad(t, (1, 1, 1, 1)), sd[p + 'conv_dw.weight'].float(), groups=t.shape[1])
+            t = F.conv2d(t, sd[p + 'conv_pw.weight'].float(), bias=sd[p + 'conv_pw.bias'].float() if (p + 'conv_pw.bias') in sd else None)
+            b = '%sbn_rep.%d.%d.bn.' % (prefix, i, level)
+            t = F.batch_norm(t, sd[b + 'running_mean'].float(), sd[b + 'running_var'].float(), sd[b + 'weight'].float(),
+                             sd[b + 'bias'].float(), training=False, eps=eps)
+            t = t * torch.sigmoid(t)
+        p = prefix + 'anchor_out.'
+        t = F.conv2d(F.pad(t, (1, 1, 1, 1)), sd[p + 'conv_dw.weight'].float(), groups=t.shape[1])
+        outs.append(F.conv2d(t, sd[p + 'conv_pw.weight'].float(), bias=sd[p + 'conv_pw.bias'].float()))
+    return outs
+
+
+def projection_forward(weights, x):
+    """ProjectionNet.forward (efficientdet.py:762): Linear(bias=False) + ReLU chain, last layer without ReLU."""
+    t = x.float()
+    for i, w in enumerate(weights):
+        t = F.linear(t, w.float())
+        if i + 1 < len(weights):
+            t = F.relu(t)
+    return t
+
+
+def weighted_median(embds, confs):
+    """ProjectionNet.weighted_median (efficientdet.py:748-760), the reference's torch ops verbatim in meaning."""
+    conf_sum = confs.sum()
+    sorted_elems, sorted_idxs = torch.sort(embds, dim=0, stable=True)
+    sorted_confs = confs[sorted_idxs.transpose(0, 1)].transpose(0, 1)
+    cum_sum = torch.cumsum(sorted_confs, dim=0)
+    mask = (cum_sum >= conf_sum / 2).long()
+    median_idxs = torch.argmax(mask, dim=0).view(1, -1)
+    return torch.gather(sorted_elems, 0, median_idxs), conf_sum
