@@ -1,46 +1,53 @@
-"""create_model / create_model_from_config (reference: effdet/factory.py:7-54)."""
-from .bench import DetBenchPredict, DetBenchTrain
+"""Model construction entry points with the reference's signatures (effdet/factory.py:7-54):
+`create_model(name, bench_task, num_classes, pretrained, checkpoint_path, checkpoint_ema, **kwargs)` and
+`create_model_from_config(config, ...)`.
+
+Order of operations (what the reference does, :20-54): config overrides -> EfficientDet -> pretrained weights ->
+head reset for a different class count -> checkpoint -> optional task wrapper.  Build-specific behaviour:
+* nothing can be fetched offline, so `pretrained_backbone` never triggers a download (weights come from
+  `checkpoint_path`);
+* `image_size=(H, W)` (extra keyword) runs the model at another resolution than the config default."""
+from . import bench as _bench
+from . import helpers as _helpers
 from .config import get_efficientdet_config
-from .efficientdet import EfficientDet, HeadNet
-from .helpers import load_checkpoint, load_pretrained
+from .efficientdet import EfficientDet
+
+# keyword arguments that are copied onto the config when given (factory.py:30-34 of the reference)
+_CONFIG_OVERRIDES = ('redundant_bias', 'label_smoothing', 'legacy_focal', 'jit_loss', 'soft_nms')
+_WRAPPERS = {'train': lambda m, labeler: _bench.DetBenchTrain(m, create_labeler=labeler),
+             'predict': lambda m, labeler: _bench.DetBenchPredict(m)}
 
 
-def create_model(model_name, bench_task='', num_classes=None, pretrained=False,
-                 checkpoint_path='', checkpoint_ema=False, **kwargs):
-    config = get_efficientdet_config(model_name)
-    return create_model_from_config(
-        config, bench_task=bench_task, num_classes=num_classes, pretrained=pretrained,
-        checkpoint_path=checkpoint_path, checkpoint_ema=checkpoint_ema, **kwargs)
+def _apply_overrides(config, options):
+    for name in _CONFIG_OVERRIDES:
+        if options.get(name) is not None:
+            setattr(config, name, options[name])
+        options.pop(name, None)
+    size = options.pop('image_size', None)
+    if size is not None:
+        config.image_size = tuple(size)
 
 
 def create_model_from_config(config, bench_task='', num_classes=None, pretrained=False,
                              checkpoint_path='', checkpoint_ema=False, **kwargs):
-    pretrained_backbone = kwargs.pop('pretrained_backbone', True)
-    if pretrained or checkpoint_path:
-        pretrained_backbone = False
-    # Offline build: a pretrained backbone would need a network fetch.  The reference default
-    # (pretrained_backbone=True) is therefore honoured only when the caller passes weights.
-    if pretrained_backbone:
-        pretrained_backbone = False
-    overrides = ('redundant_bias', 'label_smoothing', 'legacy_focal', 'jit_loss', 'soft_nms')
-    for ov in overrides:
-        value = kwargs.pop(ov, None)
-        if value is not None:
-            setattr(config, ov, value)
-    # extra (build-defined) override: run at another input resolution than the model default
-    image_size = kwargs.pop('image_size', None)
-    if image_size is not None:
-        config.image_size = tuple(image_size)
-    labeler = kwargs.pop('bench_labeler', False)
-    model = EfficientDet(config, pretrained_backbone=pretrained_backbone, **kwargs)
+    options = dict(kwargs)
+    options.pop('pretrained_backbone', None)          # offline: the backbone is initialised locally, weights via checkpoint
+    want_labeler = options.pop('bench_labeler', False)
+    _apply_overrides(config, options)
+
+    net = EfficientDet(config, pretrained_backbone=False, **options)
     if pretrained:
-        load_pretrained(model, config.url)
+        _helpers.load_pretrained(net, config.url)
     if num_classes is not None and num_classes != config.num_classes:
-        model.reset_head(num_classes=num_classes)
+        net.reset_head(num_classes=num_classes)
     if checkpoint_path:
-        load_checkpoint(model, checkpoint_path, use_ema=checkpoint_ema)
-    if bench_task == 'train':
-        model = DetBenchTrain(model, create_labeler=labeler)
-    elif bench_task == 'predict':
-        model = DetBenchPredict(model)
-    return model
+        _helpers.load_checkpoint(net, checkpoint_path, use_ema=checkpoint_ema)
+    wrap = _WRAPPERS.get(bench_task)
+    return wrap(net, want_labeler) if wrap is not None else net
+
+
+def create_model(model_name, bench_task='', num_classes=None, pretrained=False,
+                 checkpoint_path='', checkpoint_ema=False, **kwargs):
+    return create_model_from_config(get_efficientdet_config(model_name), bench_task=bench_task, num_classes=num_classes,
+                                    pretrained=pretrained, checkpoint_path=checkpoint_path, checkpoint_ema=checkpoint_ema,
+                                    **kwargs)
