@@ -372,3 +372,40 @@ def test_projection_net(dtype):
             med, cs = net.weighted_median(e.to(DEV), c.to(DEV))
             rm, rc = om.weighted_median(e, c)
             assert torch.equal(med.cpu(), rm) and abs(float(cs) - float(rc)) <= 1e-4 * max(1.0, float(rc))
+
+
+def test_baseline_config1_d0_512_uint8_images():
+    """BASELINE configs[0]: tf_efficientdet_d0, 512 x 512, batch 1, float32, eight synthetic uint8
+    images `randint(0, 256, (3, 512, 512), seed = i)` normalised with the ImageNet constants - DetBenchPredict on the GPU
+    (raw uint8 in, normalisation fused into the first kernel) against the CPU oracle path image by image: head outputs
+    <= 1e-3 abs (north star), detections through the same-logits stage check, OOD scores <= 1e-4."""
+    import copy
+    from oracle import preprocess as opre
+    from ood_object_detection_amd.effdet.bench import DetBenchPredict
+    model, cfg, nodes, sd = seeded_model('tf_efficientdet_d0', 512, 90, seed=11)
+    m = copy.deepcopy(model).to(DEV).float()
+    bench = DetBenchPredict(m).to(DEV)
+    anchors = op.anchor_boxes(3, 7, 3, m.config.aspect_ratios, 4.0, (512, 512))
+    assert anchors.shape[0] == 49104                                     # SURVEY 8: N at 512 px
+    for i in range(8):
+        xu = torch.randint(0, 256, (3, 512, 512), generator=torch.Generator().manual_seed(i), dtype=torch.uint8)[None]
+        xn = torch.from_numpy(opre.normalize_u8(xu.numpy()))
+        with torch.no_grad():
+            cls_r, box_r = om.efficientdet_forward(sd, cfg, xn, nodes)
+            det = bench(xu.to(DEV))
+        eng = m._engine
+        cls_g = [t.float().cpu() for t in eng.head_views(eng.cls_all, 90)]
+        box_g = [t.float().cpu() for t in eng.head_views(eng.box_all, 4)]
+        assert max(float((a - b).abs().max()) for a, b in zip(cls_g, cls_r)) <= 1e-3
+        assert max(float((a - b).abs().max()) for a, b in zip(box_g, box_r)) <= 1e-3
+        c, b, idx, cl = op.post_process(cls_g, box_g, 5, 90, 5000)
+        ref, src = op.generate_detections(c[0], b[0], anchors, idx[0], cl[0], None, torch.tensor(512), 100, False, return_aux=True)
+        n = int(bench.last_count[0])
+        assert n == ref.shape[0]
+        got = det[0, :n].cpu()
+        if n:
+            assert torch.equal(got[:, 5], ref[:, 5])
+            assert float((got[:, 4] - ref[:, 4]).abs().max()) <= 1e-5 and float((got[:, :4] - ref[:, :4]).abs().max()) <= 1e-3
+        e_ref, m_ref = om.ood_scores(cls_r, 90)
+        assert float((m.ood_energy.cpu() - e_ref).abs().max()) <= 1e-4 * max(1.0, float(e_ref.abs().max()))
+        assert float((m.ood_max_logit.cpu() - m_ref).abs().max()) <= 1e-3
