@@ -74,7 +74,7 @@ __global__ __launch_bounds__(NTH, 2) void pw_gemm_kernel(PwArgs p) {
         pix[i] = pix0 + 16 * PT * wave + 16 * i + frow;
         pix_ok[i] = pix[i] < p.rows_per_image;
         const long long m = (long long)img * p.rows_per_image + (pix_ok[i] ? pix[i] : 0);
-        arow[i] = reinterpret_cast<const char*>(p.A) + m * pitch + fpiece * 16;
+        arow[i] = reinterpret_cast<const char*>(p.A) + m * pitch;
     }
     // A ring: PF + 1 stages x KCH chunks x 2 pixel tiles, straight from memory into MFMA operand registers
     Frag<T> areg[PF + 1][KCH][PT];
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(NTH, 2) void pw_gemm_kernel(PwArgs p) {
         for (int sub = 0; sub < KCH; ++sub) {
             const int off = (stg * KCH + sub) * 64 + fpiece * 16;
             const bool ok = off < kbytes;
-            const int offc = ok ? off - fpiece * 16 : 0;     // a lane past the end of K re-reads byte 0 and is zeroed below
+            const int offc = ok ? off : 0;                   // a lane past the end of K re-reads the row start (always in bounds) and is zeroed below
 #pragma unroll
             for (int i = 0; i < PT; ++i) {
                 Frag<T> f = ld_frag<T>(arow[i] + offc);

@@ -23,7 +23,7 @@ def _rand(*shape, seed=0, scale=1.0):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('M,K,N', [(300, 16, 96), (1000, 96, 24), (257, 240, 40), (513, 1152, 320), (128, 40, 240), (77, 64, 810)])
+@pytest.mark.parametrize('M,K,N', [(300, 16, 96), (1000, 96, 24), (257, 240, 40), (513, 1152, 320), (128, 40, 240), (77, 64, 810), (300, 8, 16)])
 def test_pw_gemm(dtype, M, K, N):
     import _hip
     A, W = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5)
