@@ -8,9 +8,10 @@ from ood_object_detection_amd.effdet.bench import DetBenchPredict
 dev = torch.device('cuda:0')
 model = B.build_model('tf_efficientdet_d0', 640, 90).to(dev).to(torch.bfloat16)
 x = torch.randn(64, 3, 640, 640, device=dev).to(torch.bfloat16)
-nsplit = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-benches = [DetBenchPredict(copy.deepcopy(model) if i else model).to(dev) for i in range(nsplit)]
-xs = list(x.chunk(nsplit))
+sizes = [int(v) for v in sys.argv[1].split(',')] if len(sys.argv) > 1 else [32, 32]
+nsplit = len(sizes)
+benches = [DetBenchPredict(copy.deepcopy(model) if i else model, streams=1).to(dev) for i in range(nsplit)]
+xs = list(x.split(sizes))
 streams = [torch.cuda.Stream(dev) for _ in range(nsplit)]
 def step():
     cur = torch.cuda.current_stream(dev)
@@ -38,4 +39,4 @@ with torch.no_grad():
     for _ in range(20): g.replay()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 20
-print('splits', nsplit, 'ms/step', dt * 1e3, 'img/s', 64 / dt)
+print('splits', sizes, 'ms/step', dt * 1e3, 'img/s', 64 / dt)
