@@ -176,6 +176,12 @@ int effdet_decode_threshold(void* stream, int dtype, const void* cls_topk, const
                             const float* anchors, const long long* indices, const long long* classes,
                             const float* img_scale, const float* img_size, int B, int k,
                             float* boxes, float* scores, int* classes_out, int* src, int* count, float* maxcoord);
+/* The same with the box regressions taken from the box head's full output box_all [B, n_anchors, 4] through `indices`
+ * (effdet_topk_select may then be called with box_all = NULL and run concurrently with the box head). */
+int effdet_decode_threshold_gather(void* stream, int dtype, const void* cls_topk, const void* box_all, long long n_anchors,
+                                   const float* anchors, const long long* indices, const long long* classes,
+                                   const float* img_scale, const float* img_size, int B, int k,
+                                   float* boxes, float* scores, int* classes_out, int* src, int* count, float* maxcoord);
 
 /* generate_detections, second half (effdet/anchors.py:145-166).  det [B,max_det,6] zero padded rows
  * x1,y1,x2,y2,score,class+1; det_count [B]; keep_src [B,max_det] = position in the top-k list or -1.

@@ -64,6 +64,8 @@ SIGNATURES = {
     'effdet_topk_workspace_bytes': (c_ll, [c_int, c_ll]),
     'effdet_topk_select': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_ll, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_ll]),
+    'effdet_decode_threshold_gather': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'effdet_decode_threshold': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p]),

@@ -454,6 +454,7 @@ struct DecodeArgs {
     const float* img_scale; const float* img_size;
     int k;
     float* boxes; float* scores; int* cls_out; int* src; int* count; float* maxcoord;
+    long long gather_anchors;      // > 0: `box` is the full [B, gather_anchors, 4] head output, rows taken through `indices`
 };
 
 DEV float ld_as_float(const void* p, int dtype, long long i) {
@@ -480,8 +481,9 @@ __global__ __launch_bounds__(256) void decode_threshold_kernel(DecodeArgs p) {
             const float* a = p.anchors + p.indices[o] * 4;
             const float ya = (a[0] + a[2]) / 2, xa = (a[1] + a[3]) / 2;
             const float ha = a[2] - a[0], wa = a[3] - a[1];
-            const float ty = ld_as_float(p.box, p.dtype, o * 4 + 0), tx = ld_as_float(p.box, p.dtype, o * 4 + 1);
-            const float th = ld_as_float(p.box, p.dtype, o * 4 + 2), tw = ld_as_float(p.box, p.dtype, o * 4 + 3);
+            const long long br = p.gather_anchors > 0 ? (long long)b * p.gather_anchors + p.indices[o] : o;
+            const float ty = ld_as_float(p.box, p.dtype, br * 4 + 0), tx = ld_as_float(p.box, p.dtype, br * 4 + 1);
+            const float th = ld_as_float(p.box, p.dtype, br * 4 + 2), tw = ld_as_float(p.box, p.dtype, br * 4 + 3);
             const float w = expf(tw) * wa, h = expf(th) * ha;
             const float yc = ty * ha + ya, xc = tx * wa + xa;
             y1 = yc - h / 2.f; x1 = xc - w / 2.f; y2 = yc + h / 2.f; x2 = xc + w / 2.f;
@@ -865,7 +867,21 @@ extern "C" int effdet_decode_threshold(void* stream, int dtype, const void* cls_
     EFFDET_ENTER();
     if (!cls_topk || !box_topk || !anchors || !indices || !classes || !boxes || !scores || !classes_out || !src || !count || !maxcoord) return EFFDET_EINVAL;
     if (B <= 0 || k <= 0 || (dtype & ~1)) return EFFDET_EINVAL;
-    DecodeArgs a{cls_topk, box_topk, dtype, anchors, indices, classes, img_scale, img_size, k, boxes, scores, classes_out, src, count, maxcoord};
+    DecodeArgs a{cls_topk, box_topk, dtype, anchors, indices, classes, img_scale, img_size, k, boxes, scores, classes_out, src, count, maxcoord, 0};
+    hipLaunchKernelGGL(decode_threshold_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return effdet_check_launch();
+}
+
+// Same, with the box regressions read straight from the box head's [B, n_anchors, 4] output through `indices`: the
+// top-k then does not depend on the box head at all and can run beside it on another stream.
+extern "C" int effdet_decode_threshold_gather(void* stream, int dtype, const void* cls_topk, const void* box_all, long long n_anchors,
+                                              const float* anchors, const long long* indices, const long long* classes,
+                                              const float* img_scale, const float* img_size, int B, int k,
+                                              float* boxes, float* scores, int* classes_out, int* src, int* count, float* maxcoord) {
+    EFFDET_ENTER();
+    if (!cls_topk || !box_all || !anchors || !indices || !classes || !boxes || !scores || !classes_out || !src || !count || !maxcoord) return EFFDET_EINVAL;
+    if (B <= 0 || k <= 0 || n_anchors <= 0 || (dtype & ~1)) return EFFDET_EINVAL;
+    DecodeArgs a{cls_topk, box_all, dtype, anchors, indices, classes, img_scale, img_size, k, boxes, scores, classes_out, src, count, maxcoord, n_anchors};
     hipLaunchKernelGGL(decode_threshold_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     return effdet_check_launch();
 }

@@ -100,16 +100,19 @@ def _need_cuda(t, what):
 
 
 def batched_detections(cls_topk, box_topk, anchor_boxes, indices, classes, img_scale=None, img_size=None,
-                       max_det_per_image: int = 100, soft_nms: bool = False):
-    """All images at once: returns (det [B,max_det,6] zero padded, count [B] int32, keep_src [B,max_det] int32)."""
+                       max_det_per_image: int = 100, soft_nms: bool = False, box_all=None):
+    """All images at once: returns (det [B,max_det,6] zero padded, count [B] int32, keep_src [B,max_det] int32).
+    box_all (extension): the box head's packed [B, N, 4] output; the regressions are then read through `indices`
+    (box_topk may be None), so the top-k need not have waited for the box head."""
     lib = _lib.load()
     _need_cuda(cls_topk, 'cls_outputs')
     B, k = indices.shape
     dev = cls_topk.device
-    if cls_topk.dtype != box_topk.dtype or cls_topk.dtype not in (torch.float32, torch.bfloat16):
+    bsrc = box_all if box_all is not None else box_topk
+    if cls_topk.dtype != bsrc.dtype or cls_topk.dtype not in (torch.float32, torch.bfloat16):
         raise RuntimeError('cls/box outputs must both be float32 or bfloat16')
     dt = 0 if cls_topk.dtype == torch.float32 else 1
-    cls_topk, box_topk = cls_topk.contiguous(), box_topk.contiguous()
+    cls_topk, bsrc = cls_topk.contiguous(), bsrc.contiguous()
     indices, classes = indices.contiguous(), classes.contiguous()
     anchors = anchor_boxes.to(device=dev, dtype=torch.float32).contiguous()
     sc = sz = None
@@ -123,11 +126,16 @@ def batched_detections(cls_topk, box_topk, anchor_boxes, indices, classes, img_s
     cls_i, src, count, maxc = torch.empty(B, k, **i32), torch.empty(B, k, **i32), torch.empty(B, **i32), torch.empty(B, **f32)
     det, det_count, keep_src = torch.empty(B, max_det_per_image, 6, **f32), torch.empty(B, **i32), torch.empty(B, max_det_per_image, **i32)
     st = _stream(cls_topk)
-    _lib.check(lib.effdet_decode_threshold(
-        st, dt, cls_topk.data_ptr(), box_topk.data_ptr(), anchors.data_ptr(), indices.data_ptr(), classes.data_ptr(),
-        sc.data_ptr() if (sc is not None and sz is not None) else None, sz.data_ptr() if sz is not None else None, B, k,
-        boxes.data_ptr(), scores.data_ptr(), cls_i.data_ptr(), src.data_ptr(), count.data_ptr(), maxc.data_ptr()),
-        'effdet_decode_threshold')
+    tail = (anchors.data_ptr(), indices.data_ptr(), classes.data_ptr(),
+            sc.data_ptr() if (sc is not None and sz is not None) else None, sz.data_ptr() if sz is not None else None, B, k,
+            boxes.data_ptr(), scores.data_ptr(), cls_i.data_ptr(), src.data_ptr(), count.data_ptr(), maxc.data_ptr())
+    if box_all is not None:
+        if bsrc.dim() != 3 or bsrc.shape[0] != B or bsrc.shape[2] != 4:
+            raise ValueError('box_all must be [B, N, 4]')
+        _lib.check(lib.effdet_decode_threshold_gather(st, dt, cls_topk.data_ptr(), bsrc.data_ptr(), bsrc.shape[1], *tail),
+                   'effdet_decode_threshold_gather')
+    else:
+        _lib.check(lib.effdet_decode_threshold(st, dt, cls_topk.data_ptr(), bsrc.data_ptr(), *tail), 'effdet_decode_threshold')
     scp = sc.data_ptr() if sc is not None else None
     if soft_nms:
         _lib.check(lib.effdet_nms_soft(st, boxes.data_ptr(), scores.data_ptr(), cls_i.data_ptr(), src.data_ptr(),

@@ -15,13 +15,13 @@ from .. import _lib
 from .anchors import Anchors, batched_detections
 
 
-def _post_process(cls_outputs: List[torch.Tensor], box_outputs: List[torch.Tensor], num_levels: int,
+def _post_process(cls_outputs: List[torch.Tensor], box_outputs: Optional[List[torch.Tensor]], num_levels: int,
                   num_classes: int, max_detection_points: int = 5000, anchor_max: Optional[torch.Tensor] = None):
     """Top-k over all class logits (effdet/bench.py:12-56); ties go to the lower flat index.
 
     `anchor_max` (extension): the [B, N] float32 per-anchor maximum logit the class head already produced
     (`model.ood_max_logit`); the select then only scans the anchors that can reach the top k.  Results are
-    identical with and without it.
+    identical with and without it.  `box_outputs=None` (extension) skips the box gather (returned box tensor is None).
 
     Accepts the per-level [B, A*C, H, W] / [B, A*4, H, W] lists.  When they are the engine's own
     NHWC-backed views the concatenation is free; other tensors are packed with one copy.
@@ -32,12 +32,12 @@ def _post_process(cls_outputs: List[torch.Tensor], box_outputs: List[torch.Tenso
         raise RuntimeError('_post_process runs on the GPU only (no CPU fallback)')
     B = c0.shape[0]
     cls_all = _packed(cls_outputs, num_levels, num_classes)
-    box_all = _packed(box_outputs, num_levels, 4)
+    box_all = _packed(box_outputs, num_levels, 4) if box_outputs is not None else None
     n_anchors = cls_all.shape[1]
     k = max_detection_points
     dt = 0 if cls_all.dtype == torch.float32 else 1
     out_cls = torch.empty(B, k, 1, dtype=cls_all.dtype, device=c0.device)
-    out_box = torch.empty(B, k, 4, dtype=cls_all.dtype, device=c0.device)
+    out_box = torch.empty(B, k, 4, dtype=cls_all.dtype, device=c0.device) if box_all is not None else None
     idx = torch.empty(B, k, dtype=torch.int64, device=c0.device)
     cls_id = torch.empty(B, k, dtype=torch.int64, device=c0.device)
     if anchor_max is not None:
@@ -48,8 +48,8 @@ def _post_process(cls_outputs: List[torch.Tensor], box_outputs: List[torch.Tenso
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=c0.device)
     st = torch.cuda.current_stream(c0.device).cuda_stream
     _lib.check(lib.effdet_topk_select(st, dt, cls_all.data_ptr(), anchor_max.data_ptr() if anchor_max is not None else None,
-                                      B, n_anchors, num_classes, box_all.data_ptr(), k,
-                                      out_cls.data_ptr(), out_box.data_ptr(), idx.data_ptr(), cls_id.data_ptr(),
+                                      B, n_anchors, num_classes, box_all.data_ptr() if box_all is not None else None, k,
+                                      out_cls.data_ptr(), out_box.data_ptr() if out_box is not None else None, idx.data_ptr(), cls_id.data_ptr(),
                                       ws.data_ptr(), ws_bytes), 'effdet_topk_select')
     return out_cls, out_box, idx, cls_id
 
@@ -90,16 +90,19 @@ class DetBenchPredict(nn.Module):
         self._ood_buf = None
 
     def _one(self, model, x, img_scale, img_size):
-        """One (sub-)batch: model -> top-k -> decode -> NMS -> OOD gather."""
+        """One (sub-)batch: model -> top-k -> decode -> NMS -> OOD gather.  The top-k runs without the box gather and
+        decode reads the box regressions from the box head's packed output through the top-k indices.  (Running the box
+        head beside the top-k on a third stream works eagerly but crashes hipStreamEndCapture - nested forks - so the
+        two stay in launch order; the half-batches already overlap each other.)"""
         lib = _lib.load()
         class_out, box_out = model(x)
-        cls_topk, box_topk, indices, classes = _post_process(
-            class_out, box_out, num_levels=self.num_levels, num_classes=self.num_classes,
+        cls_topk, _, indices, classes = _post_process(
+            class_out, None, num_levels=self.num_levels, num_classes=self.num_classes,
             max_detection_points=self.max_detection_points, anchor_max=model.ood_max_logit)
         B, k = indices.shape
         det, count, keep_src = batched_detections(
-            cls_topk.reshape(B, k), box_topk, self.anchors.boxes, indices, classes, img_scale, img_size,
-            max_det_per_image=self.max_det_per_image, soft_nms=self.soft_nms)
+            cls_topk.reshape(B, k), None, self.anchors.boxes, indices, classes, img_scale, img_size,
+            max_det_per_image=self.max_det_per_image, soft_nms=self.soft_nms, box_all=_packed(box_out, self.num_levels, 4))
         energy = torch.empty(B, self.max_det_per_image, dtype=torch.float32, device=x.device)
         maxlogit = torch.empty_like(energy)
         st = torch.cuda.current_stream(x.device).cuda_stream
