@@ -79,6 +79,24 @@ SIGNATURES = {
     'effdet_label_anchors_workspace_bytes': (c_ll, [c_int, c_int, c_ll]),
     'effdet_label_anchors': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_float, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_ll]),
+    'effdet_train_gemm_nt': (c_int, [c_void_p, c_void_p, c_ll, c_ll, c_ll, c_void_p, c_void_p, c_void_p, c_ll, c_ll, c_ll,
+                                     c_ll, c_int, c_int, c_int]),
+    'effdet_train_gemm_tn_workspace_floats': (c_ll, [c_ll, c_int, c_int]),
+    'effdet_train_gemm_tn': (c_int, [c_void_p, c_void_p, c_ll, c_ll, c_ll, c_void_p, c_ll, c_ll, c_ll, c_ll, c_int, c_int,
+                                     c_void_p, c_void_p, c_ll]),
+    'effdet_train_reduce_mid': (c_int, [c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p, c_int]),
+    'effdet_train_dwconv_bwd_dx': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
+    'effdet_train_dwconv_bwd_dw_workspace_floats': (c_ll, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    'effdet_train_dwconv_bwd_dw': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                           c_void_p, c_ll]),
+    'effdet_train_ew': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_float, c_float, c_float, c_float, c_ll, c_int, c_ll]),
+    'effdet_train_col_reduce_workspace_floats': (c_ll, [c_int, c_ll, c_int]),
+    'effdet_train_col_reduce': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_ll, c_int, c_void_p, c_void_p, c_ll]),
+    'effdet_train_spatial': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
+    'effdet_train_im2col_stem': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
+    'effdet_train_se_bwd': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_int, c_int, c_int]),
     'effdet_gather_ood': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_int, c_int, c_int,
                                   c_void_p, c_void_p]),
 }

@@ -1,0 +1,729 @@
+// Training-path kernels of the pretrain step (pretrain.py:226-236: forward with saved activations,
+// `qry_loss.backward()` through heads, BiFPN and backbone).  float32 only (the reference trains in fp32), NHWC.
+//
+// The step is a sequence of these generic operators (host side: ood_object_detection_amd/train_engine.py):
+//   effdet_train_gemm_nt     C[M,N] = A[M,K] W[N,K]^T + bias      1x1 conv forward, and dX = dY W (W passed transposed)
+//   effdet_train_gemm_tn     out[N,K+1] = dY[M,N]^T [X[M,K] | 1]   weight gradient and per-channel sum of dY in one pass
+//   effdet_train_dwconv_bwd_dx / _dw                               depthwise k x k (TF-SAME, stride 1|2) backward
+//   effdet_train_ew          element-wise family (SiLU fwd/bwd, affine, SE gate fwd/bwd, BN-train bwd, fusion, add)
+//   effdet_train_col_reduce  per-channel reductions over pixels (BN statistics, SE pool, dot products)
+//   effdet_train_spatial     nearest x2 upsample fwd/bwd, 3x3/s2 max-pool backward
+//   effdet_train_im2col_stem conv_stem input patches (the stem then runs on the two GEMMs above)
+//   effdet_train_se_bwd      SqueezeExcite FC backward (per image) + its parameter-gradient partials
+//   effdet_train_reduce_mid  fixed-order second stage of every two-stage reduction (bitwise reproducible)
+// Every reduction is two-stage with a fixed order: gradients are bitwise reproducible run to run.
+// MFMA 16x16x4 f32 carries the GEMMs; operands are streamed from HBM/L2 straight into registers (the weight side is
+// small and L2 resident); D holds 4 consecutive output channels of one pixel per lane -> 16-byte stores.
+#include "common.h"
+
+namespace {
+
+struct RowMap { long long rpi, img_stride, ld; };      // row m -> (m / rpi) * img_stride + (m % rpi) * ld
+DEV long long row_off(const RowMap& r, long long m) {
+    if (r.img_stride == 0) return m * r.ld;
+    const long long q = m / r.rpi;
+    return q * r.img_stride + (m - q * r.rpi) * r.ld;
+}
+inline RowMap make_rowmap(long long rpi, long long img_stride, long long ld, long long M, long long cols) {
+    RowMap r;
+    if (rpi <= 0 || img_stride <= 0) { r.rpi = M > 0 ? M : 1; r.img_stride = 0; r.ld = ld > 0 ? ld : cols; }
+    else { r.rpi = rpi; r.img_stride = img_stride; r.ld = ld > 0 ? ld : cols; }
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// C = A W^T + bias
+// ------------------------------------------------------------------------------------------------------------
+struct GemmNtArgs {
+    const float* A; RowMap am; const float* W; const float* bias; float* C; RowMap cm;
+    long long M; int K, N, accumulate;
+};
+
+template <bool VEC>
+DEV Frag<float> ld_k4(const float* row, int k, int K) {
+    Frag<float> f;
+    if constexpr (VEC) {
+        if (k + 3 < K) f.v = *reinterpret_cast<const f32x4*>(row + k);
+        else f.v = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f.v[i] = (k + i < K) ? row[k + i] : 0.f;
+    }
+    return f;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const long long m0 = ((long long)blockIdx.x * 4 + wave) * 16;
+    const int n0 = blockIdx.y * 64;
+    if (m0 >= p.M) return;                                   // wave-uniform, no barriers in this kernel
+    long long m = m0 + r16;
+    const bool mv = m < p.M;
+    if (!mv) m = p.M - 1;
+    const float* arow = p.A + row_off(p.am, m);
+    const float* wrow[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int n = n0 + 16 * t + r16;
+        if (n >= p.N) n = p.N - 1;
+        wrow[t] = p.W + (long long)n * p.K;
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < p.K; k0 += 16) {
+        const int k = k0 + 4 * g;
+        const Frag<float> b = ld_k4<VEC>(arow, k, p.K);
+        Frag<float> a[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = ld_k4<VEC>(wrow[t], k, p.K);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) mma_chunk(a[t], b, acc[t]);
+    }
+    if (!mv) return;
+    float* crow = p.C + row_off(p.cm, m0 + r16);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int n = n0 + 16 * t + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (n + r < p.N) {
+                float v = acc[t][r];
+                if (p.bias) v += p.bias[n + r];
+                if (p.accumulate) v += crow[n + r];
+                crow[n + r] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// out[N][K+1] = dY^T [X | 1]  (two-stage over M)
+// ------------------------------------------------------------------------------------------------------------
+struct GemmTnArgs {
+    const float* dY; RowMap ym; const float* X; RowMap xm; float* partial;
+    long long M, rows_per_slice; int N, K, S;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
+    __shared__ float sm[4][32 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c16 = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 64;
+    const long long mb = (long long)blockIdx.z * p.rows_per_slice;
+    long long me = mb + p.rows_per_slice;
+    if (me > p.M) me = p.M;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int Kx = p.K + 1;
+    for (long long mm = mb + wave * 4; mm < me; mm += 16) {
+        const long long m = mm + g;
+        const bool valid = m < me;
+        const float* yrow = p.dY + (valid ? row_off(p.ym, m) : 0);
+        const float* xrow = p.X + (valid ? row_off(p.xm, m) : 0);
+        float a[2], b[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int n = n0 + 16 * i + c16;
+            a[i] = (valid && n < p.N) ? yrow[n] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kk = k0 + 16 * j + c16;
+            b[j] = !valid ? 0.f : (kk < p.K ? xrow[kk] : (kk == p.K ? 1.f : 0.f));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    // D[row = n local (4g + r)][col = k local (c16)]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sm[wave][(16 * i + 4 * g + r) * 64 + 16 * j + c16] = acc[i][j][r];
+    __syncthreads();
+    float* out = p.partial + (long long)blockIdx.z * p.N * Kx;
+    for (int e = threadIdx.x; e < 32 * 64; e += 256) {
+        const int n = n0 + e / 64, kk = k0 + e % 64;
+        if (n < p.N && kk < Kx) out[(long long)n * Kx + kk] = ((sm[0][e] + sm[1][e]) + sm[2][e]) + sm[3][e];
+    }
+}
+
+// out[g][l] (+)= sum_s in[g][s][l] in index order
+struct ReduceMidArgs { const float* in; float* out; long long L; int G, S, accumulate; };
+__global__ __launch_bounds__(256) void reduce_mid_kernel(ReduceMidArgs p) {
+    const long long l = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int gi = blockIdx.y;
+    if (l >= p.L) return;
+    const float* src = p.in + (long long)gi * p.S * p.L + l;
+    float s = 0.f;
+    for (int i = 0; i < p.S; ++i) s += src[(long long)i * p.L];
+    float* dst = p.out + (long long)gi * p.L + l;
+    *dst = p.accumulate ? *dst + s : s;
+}
+
+int launch_reduce_mid(hipStream_t st, const float* in, int G, int S, long long L, float* out, int accumulate) {
+    ReduceMidArgs a{in, out, L, G, S, accumulate};
+    const long long blocks = (L + 255) / 256;
+    if (blocks > 0x7fffffffLL || G > 65535) return EFFDET_EINVAL;
+    hipLaunchKernelGGL(reduce_mid_kernel, dim3((unsigned)blocks, (unsigned)G), dim3(256), 0, st, a);
+    return effdet_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// depthwise backward
+// ------------------------------------------------------------------------------------------------------------
+struct DwBwdArgs {
+    const float* dY; const float* X; const float* taps; float* dX; float* partial;
+    int B, H, W, C, k, stride, Ho, Wo, pad_t, pad_l; long long px_per_chunk;
+};
+
+// dX[b,iy,ix,c] = sum_taps dY[b,(iy+pad-ky)/s,(ix+pad-kx)/s,c] * w[ky,kx,c]   (4 channels per thread)
+__global__ __launch_bounds__(256) void dw_bwd_dx_kernel(DwBwdArgs p) {
+    const int C4 = p.C / 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)p.B * p.H * p.W * C4;
+    if (i >= total) return;
+    const int c = (int)(i % C4) * 4;
+    long long px = i / C4;
+    const int ix = (int)(px % p.W); px /= p.W;
+    const int iy = (int)(px % p.H);
+    const int b = (int)(px / p.H);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ky = 0; ky < p.k; ++ky) {
+        const int ty = iy + p.pad_t - ky;
+        if (ty < 0 || ty % p.stride) continue;
+        const int oy = ty / p.stride;
+        if (oy >= p.Ho) continue;
+        for (int kx = 0; kx < p.k; ++kx) {
+            const int tx = ix + p.pad_l - kx;
+            if (tx < 0 || tx % p.stride) continue;
+            const int ox = tx / p.stride;
+            if (ox >= p.Wo) continue;
+            const f32x4 d = *reinterpret_cast<const f32x4*>(p.dY + (((long long)b * p.Ho + oy) * p.Wo + ox) * p.C + c);
+            const f32x4 w = *reinterpret_cast<const f32x4*>(p.taps + (long long)(ky * p.k + kx) * p.C + c);
+            acc += d * w;
+        }
+    }
+    *reinterpret_cast<f32x4*>(p.dX + (((long long)b * p.H + iy) * p.W + ix) * p.C + c) = acc;
+}
+
+// partial[chunk][k*k+1][C]: taps gradient + sum of dY.  block = 64 channels x 4 pixel lanes.
+template <int KK>
+__global__ __launch_bounds__(256) void dw_bwd_dw_kernel(DwBwdArgs p) {
+    constexpr int T = KK * KK;
+    __shared__ float sm[4][T + 1][64];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const bool cv = c < p.C;
+    float acc[T + 1];
+#pragma unroll
+    for (int t = 0; t <= T; ++t) acc[t] = 0.f;
+    const long long npx = (long long)p.B * p.Ho * p.Wo;
+    const long long pb = (long long)blockIdx.x * p.px_per_chunk;
+    long long pe = pb + p.px_per_chunk;
+    if (pe > npx) pe = npx;
+    if (cv) {
+        for (long long q = pb + pl; q < pe; q += 4) {
+            const int ox = (int)(q % p.Wo);
+            const long long r = q / p.Wo;
+            const int oy = (int)(r % p.Ho);
+            const int b = (int)(r / p.Ho);
+            const float d = p.dY[q * p.C + c];
+            acc[T] += d;
+#pragma unroll
+            for (int ky = 0; ky < KK; ++ky) {
+                const int iy = oy * p.stride + ky - p.pad_t;
+                if (iy < 0 || iy >= p.H) continue;
+#pragma unroll
+                for (int kx = 0; kx < KK; ++kx) {
+                    const int ix = ox * p.stride + kx - p.pad_l;
+                    if (ix < 0 || ix >= p.W) continue;
+                    acc[ky * KK + kx] += d * p.X[(((long long)b * p.H + iy) * p.W + ix) * p.C + c];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t <= T; ++t) sm[pl][t][cl] = acc[t];
+    __syncthreads();
+    if (pl == 0 && cv) {
+        float* out = p.partial + (long long)blockIdx.x * (T + 1) * p.C;
+#pragma unroll
+        for (int t = 0; t <= T; ++t) out[(long long)t * p.C + c] = ((sm[0][t][cl] + sm[1][t][cl]) + sm[2][t][cl]) + sm[3][t][cl];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// element-wise family (4 elements per thread; channel = index % C, image = index / (hw*C))
+// ------------------------------------------------------------------------------------------------------------
+struct EwArgs {
+    int op; float* out; const float* a; const float* b; const float* c;
+    const float* v0; const float* v1; const float* v2; const float* v3;
+    float s0, s1, s2, s3; long long n; int C; long long hwC;
+};
+
+DEV float silu_grad(float z) { const float s = sigmoid_f(z); return s * (1.0f + z * (1.0f - s)); }
+
+__global__ __launch_bounds__(256) void ew_kernel(EwArgs p) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= p.n) return;
+    const int ch = (int)(i % p.C);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p.a + i);
+    f32x4 o;
+    switch (p.op) {
+    case 0:                                             // SiLU forward
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = silu_f(a[j]);
+        break;
+    case 1: {                                           // SiLU backward: a = z, b = d(out)
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.b + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = b[j] * silu_grad(a[j]);
+        break; }
+    case 2: {                                           // a + b
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.b + i);
+        o = a + b;
+        break; }
+    case 3: {                                           // per-channel affine: a * v0[c] + v1[c]   (v1 may be NULL)
+        const f32x4 s = *reinterpret_cast<const f32x4*>(p.v0 + ch);
+        o = a * s;
+        if (p.v1) o += *reinterpret_cast<const f32x4*>(p.v1 + ch);
+        break; }
+    case 4: {                                           // SE gate forward: a * v0[img, c]
+        const long long img = i / p.hwC;
+        o = a * *reinterpret_cast<const f32x4*>(p.v0 + img * p.C + ch);
+        break; }
+    case 5: {                                           // SE gate backward: a * gate[img, c] + ds[img, c] * s0
+        const long long img = i / p.hwC;
+        o = a * *reinterpret_cast<const f32x4*>(p.v0 + img * p.C + ch)
+            + *reinterpret_cast<const f32x4*>(p.v1 + img * p.C + ch) * p.s0;
+        break; }
+    case 6: {                                           // BN (batch statistics) backward:
+        // d conv = v0[c] * (dy - v1[c] - (conv - v2[c]) * v3[c]);  v0 = gamma*rstd, v1 = sum(dy)/M, v2 = mean,
+        // v3 = rstd^2 * sum(dy*(conv-mean))/M;  a = dy, b = conv output
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.b + i);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(p.v0 + ch), v1 = *reinterpret_cast<const f32x4*>(p.v1 + ch);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(p.v2 + ch), v3 = *reinterpret_cast<const f32x4*>(p.v3 + ch);
+        o = v0 * (a - v1 - (b - v2) * v3);
+        break; }
+    case 7: {                                           // FpnCombine 'fastattn': sum_i (x_i * w_i) / den  (efficientdet.py:240-242)
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.b + i);
+        o = (a * p.s0) / p.s3 + (b * p.s1) / p.s3;
+        if (p.c) o = o + (*reinterpret_cast<const f32x4*>(p.c + i) * p.s2) / p.s3;
+        break; }
+    case 8:                                             // a * s0
+        o = a * p.s0;
+        break;
+    default:                                            // 9: weighted sum without the division ('attn' / 'sum')
+    {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.b + i);
+        o = a * p.s0 + b * p.s1;
+        if (p.c) o = o + *reinterpret_cast<const f32x4*>(p.c + i) * p.s2;
+        break; }
+    }
+    *reinterpret_cast<f32x4*>(p.out + i) = o;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// per-channel reductions over the rows of [G][R][C] tensors (two-stage)
+// ------------------------------------------------------------------------------------------------------------
+struct ColArgs {
+    int mode; const float* a; const float* b; const float* v; float* partial;
+    long long R, rows_per_slice; int C, S;
+};
+// modes: 0 sum a; 1 sum a*b; 2 sum (a - v[c])^2; 3 sum a*(b - v[c])
+__global__ __launch_bounds__(256) void col_reduce_kernel(ColArgs p) {
+    __shared__ float sm[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const int gi = blockIdx.z, s = blockIdx.x;
+    const bool cv = c < p.C;
+    const long long rb = (long long)s * p.rows_per_slice;
+    long long re = rb + p.rows_per_slice;
+    if (re > p.R) re = p.R;
+    float acc = 0.f;
+    if (cv) {
+        const float vc = (p.mode >= 2) ? p.v[c] : 0.f;
+        const long long base = (long long)gi * p.R * p.C + c;
+        for (long long r = rb + rl; r < re; r += 4) {
+            const float a = p.a[base + r * p.C];
+            if (p.mode == 0) acc += a;
+            else if (p.mode == 1) acc += a * p.b[base + r * p.C];
+            else if (p.mode == 2) { const float d = a - vc; acc += d * d; }
+            else acc += a * (p.b[base + r * p.C] - vc);
+        }
+    }
+    sm[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && cv)
+        p.partial[((long long)gi * p.S + s) * p.C + c] = ((sm[0][cl] + sm[1][cl]) + sm[2][cl]) + sm[3][cl];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// spatial helpers
+// ------------------------------------------------------------------------------------------------------------
+struct SpArgs { int op; const float* in; const float* aux; float* out; int B, H, W, C, Ho, Wo, pad_t, pad_l; };
+
+__global__ __launch_bounds__(256) void spatial_kernel(SpArgs p) {
+    const int C4 = p.C / 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p.op == 0) {                                    // nearest x2 upsample: in [B,H,W,C] -> out [B,2H,2W,C]
+        const long long total = (long long)p.B * 2 * p.H * 2 * p.W * C4;
+        if (i >= total) return;
+        const int c = (int)(i % C4) * 4;
+        long long px = i / C4;
+        const int x = (int)(px % (2 * p.W)); px /= 2 * p.W;
+        const int y = (int)(px % (2 * p.H));
+        const long long b = px / (2 * p.H);
+        *reinterpret_cast<f32x4*>(p.out + ((b * 2 * p.H + y) * 2 * p.W + x) * p.C + c) =
+            *reinterpret_cast<const f32x4*>(p.in + ((b * p.H + y / 2) * p.W + x / 2) * p.C + c);
+        return;
+    }
+    const long long total = (long long)p.B * p.H * p.W * C4;
+    if (i >= total) return;
+    const int c = (int)(i % C4) * 4;
+    long long px = i / C4;
+    const int x = (int)(px % p.W); px /= p.W;
+    const int y = (int)(px % p.H);
+    const long long b = px / p.H;
+    if (p.op == 1) {                                    // upsample backward: in = d(out) [B,2H,2W,C] -> out [B,H,W,C]
+        const float* s = p.in + ((b * 2 * p.H + 2 * y) * 2 * p.W + 2 * x) * p.C + c;
+        const long long rs = (long long)2 * p.W * p.C;
+        const f32x4 o = (*reinterpret_cast<const f32x4*>(s) + *reinterpret_cast<const f32x4*>(s + p.C)) +
+                        (*reinterpret_cast<const f32x4*>(s + rs) + *reinterpret_cast<const f32x4*>(s + rs + p.C));
+        *reinterpret_cast<f32x4*>(p.out + ((b * p.H + y) * p.W + x) * p.C + c) = o;
+        return;
+    }
+    // op 2: 3x3/s2 TF-SAME max-pool backward.  in = pool input X [B,H,W,C], aux = dY [B,Ho,Wo,C].  A pixel receives dY of
+    // every window whose first maximum (row-major scan, strict >: torch.max_pool2d's choice) it is.
+    const f32x4 me = *reinterpret_cast<const f32x4*>(p.in + ((b * p.H + y) * p.W + x) * p.C + c);
+    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int oy = (y + p.pad_t - 2 + 1) / 2; oy <= (y + p.pad_t) / 2; ++oy) {
+        if (oy < 0 || oy >= p.Ho) continue;
+        for (int ox = (x + p.pad_l - 2 + 1) / 2; ox <= (x + p.pad_l) / 2; ++ox) {
+            if (ox < 0 || ox >= p.Wo) continue;
+            // is (y, x) the first maximum of window (oy, ox)?  earlier positions must be strictly smaller, later ones <=
+            bool first[4] = {true, true, true, true};
+            for (int ky = 0; ky < 3; ++ky) {
+                const int yy = oy * 2 + ky - p.pad_t;
+                if (yy < 0 || yy >= p.H) continue;
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int xx = ox * 2 + kx - p.pad_l;
+                    if (xx < 0 || xx >= p.W || (yy == y && xx == x)) continue;
+                    const f32x4 q = *reinterpret_cast<const f32x4*>(p.in + ((b * p.H + yy) * p.W + xx) * p.C + c);
+                    const bool before = yy < y || (yy == y && xx < x);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) first[j] = first[j] && (before ? q[j] < me[j] : q[j] <= me[j]);
+                }
+            }
+            const f32x4 d = *reinterpret_cast<const f32x4*>(p.aux + ((b * p.Ho + oy) * p.Wo + ox) * p.C + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += first[j] ? d[j] : 0.f;
+        }
+    }
+    *reinterpret_cast<f32x4*>(p.out + ((b * p.H + y) * p.W + x) * p.C + c) = o;
+}
+
+// conv_stem patches: X NCHW [B,3,H,W] -> col [B*Ho*Wo][32], k = (ky*3+kx)*3+ci, 27..31 zero (3x3/s2 TF-SAME)
+struct Im2colArgs { const float* X; float* col; int B, H, W, Ho, Wo, pad_t, pad_l; };
+__global__ __launch_bounds__(256) void im2col_stem_kernel(Im2colArgs p) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)p.B * p.Ho * p.Wo * 32;
+    if (i >= total) return;
+    const int k = (int)(i & 31);
+    long long px = i >> 5;
+    const int ox = (int)(px % p.Wo); px /= p.Wo;
+    const int oy = (int)(px % p.Ho);
+    const long long b = px / p.Ho;
+    float v = 0.f;
+    if (k < 27) {
+        const int ci = k % 3, kx = (k / 3) % 3, ky = k / 9;
+        const int iy = oy * 2 + ky - p.pad_t, ix = ox * 2 + kx - p.pad_l;
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = p.X[((b * 3 + ci) * p.H + iy) * p.W + ix];
+    }
+    p.col[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// SqueezeExcite backward (one workgroup per image)
+// ------------------------------------------------------------------------------------------------------------
+struct SeBwdArgs {
+    const float* pool_sum; float inv_hw; const float* gate; const float* dgate;
+    const float* W1; const float* b1; const float* W2t;
+    float* ds; float* pgrad; int C, R;
+};
+// gate = sigmoid(u), u = W2 r + b2, r = silu(rp), rp = W1 s + b1, s = pool_sum / hw.
+// pgrad[img] = { dW1 [R][C], db1 [R], dW2t [R][C], db2 [C] } for this image; ds[img][c] = d loss / d s.
+__global__ __launch_bounds__(256) void se_bwd_kernel(SeBwdArgs p) {
+    extern __shared__ float sh[];
+    float* s = sh;                    // [C]
+    float* du = sh + p.C;             // [C]
+    float* rp = du + p.C;             // [R]
+    float* drp = rp + p.R;            // [R]
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const long long bc = (long long)img * p.C;
+    float* pg = p.pgrad + (long long)img * (2LL * p.R * p.C + p.R + p.C);
+    float* dW1 = pg; float* db1 = pg + (long long)p.R * p.C; float* dW2t = db1 + p.R; float* db2 = dW2t + (long long)p.R * p.C;
+    for (int c = tid; c < p.C; c += 256) {
+        s[c] = p.pool_sum[bc + c] * p.inv_hw;
+        const float g = p.gate[bc + c];
+        const float d = p.dgate[bc + c] * g * (1.0f - g);
+        du[c] = d;
+        db2[c] = d;
+    }
+    __syncthreads();
+    for (int r = wave; r < p.R; r += 4) {
+        float a = 0.f, d = 0.f;
+        for (int c = lane; c < p.C; c += 64) {
+            a += p.W1[(long long)r * p.C + c] * s[c];
+            d += p.W2t[(long long)r * p.C + c] * du[c];
+        }
+        a = wave_reduce_sum(a);
+        d = wave_reduce_sum(d);
+        if (lane == 0) {
+            const float z = a + p.b1[r];
+            rp[r] = z;
+            const float dz = d * silu_grad(z);
+            drp[r] = dz;
+            db1[r] = dz;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < p.C; c += 256) {
+        float acc = 0.f;
+        const float sc = s[c], dc = du[c];
+        for (int r = 0; r < p.R; ++r) {
+            const float dz = drp[r];
+            acc += p.W1[(long long)r * p.C + c] * dz;
+            dW1[(long long)r * p.C + c] = dz * sc;
+            dW2t[(long long)r * p.C + c] = silu_f(rp[r]) * dc;
+        }
+        p.ds[bc + c] = acc;
+    }
+}
+
+}  // namespace
+
+// ================================================================================================================
+// C ABI
+// ================================================================================================================
+extern "C" int effdet_train_gemm_nt(void* stream, const float* A, long long a_rpi, long long a_img_stride, long long a_ld,
+                                    const float* W, const float* bias, float* C, long long c_rpi, long long c_img_stride,
+                                    long long c_ld, long long M, int K, int N, int accumulate) {
+    EFFDET_ENTER();
+    if (!A || !W || !C || M <= 0 || K <= 0 || N <= 0) return EFFDET_EINVAL;
+    GemmNtArgs p;
+    p.A = A; p.W = W; p.bias = bias; p.C = C; p.M = M; p.K = K; p.N = N; p.accumulate = accumulate;
+    p.am = make_rowmap(a_rpi, a_img_stride, a_ld, M, K);
+    p.cm = make_rowmap(c_rpi, c_img_stride, c_ld, M, N);
+    const long long gx = (M + 63) / 64;
+    if (gx > 0x7fffffffLL) return EFFDET_EINVAL;
+    const bool vec = K % 4 == 0 && p.am.ld % 4 == 0 && p.am.img_stride % 4 == 0 &&
+                     reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(W) % 16 == 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)gx, (unsigned)((N + 63) / 64));
+    if (vec) hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(256), 0, st, p);
+    return effdet_check_launch();
+}
+
+static int tn_slices(long long M, int N, int K) {
+    const long long tiles = (long long)((N + 31) / 32) * ((K + 1 + 63) / 64);
+    long long S = (2048 + tiles - 1) / tiles;                     // aim at >= 2048 workgroups
+    const long long by_rows = (M + 255) / 256;                    // at least 256 rows per slice
+    if (S > by_rows) S = by_rows;
+    const long long cap = (16LL << 20) / ((long long)N * (K + 1)); // <= 16 M floats of partials
+    if (S > cap) S = cap;
+    if (S < 1) S = 1;
+    if (S > 65535) S = 65535;
+    return (int)S;
+}
+
+extern "C" long long effdet_train_gemm_tn_workspace_floats(long long M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return EFFDET_EINVAL;
+    return (long long)tn_slices(M, N, K) * N * (K + 1);
+}
+
+extern "C" int effdet_train_gemm_tn(void* stream, const float* dY, long long y_rpi, long long y_img_stride, long long y_ld,
+                                    const float* X, long long x_rpi, long long x_img_stride, long long x_ld,
+                                    long long M, int N, int K, float* out, float* workspace, long long workspace_floats) {
+    EFFDET_ENTER();
+    if (!dY || !X || !out || !workspace || M <= 0 || N <= 0 || K <= 0) return EFFDET_EINVAL;
+    const int S = tn_slices(M, N, K);
+    if (workspace_floats < (long long)S * N * (K + 1)) return EFFDET_EINVAL;
+    GemmTnArgs p;
+    p.dY = dY; p.X = X; p.partial = workspace; p.M = M; p.N = N; p.K = K; p.S = S;
+    p.ym = make_rowmap(y_rpi, y_img_stride, y_ld, M, N);
+    p.xm = make_rowmap(x_rpi, x_img_stride, x_ld, M, K);
+    long long rps = (M + S - 1) / S;
+    rps = (rps + 15) / 16 * 16;
+    p.rows_per_slice = rps;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((N + 31) / 32), (unsigned)((K + 1 + 63) / 64), (unsigned)S);
+    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, st, p);
+    int rc = effdet_check_launch();
+    if (rc) return rc;
+    return launch_reduce_mid(st, workspace, 1, S, (long long)N * (K + 1), out, 0);
+}
+
+extern "C" int effdet_train_reduce_mid(void* stream, const float* in, int G, int S, long long L, float* out, int accumulate) {
+    EFFDET_ENTER();
+    if (!in || !out || G <= 0 || S <= 0 || L <= 0) return EFFDET_EINVAL;
+    return launch_reduce_mid(reinterpret_cast<hipStream_t>(stream), in, G, S, L, out, accumulate);
+}
+
+static int dw_fill(DwBwdArgs& a, int B, int H, int W, int C, int k, int stride) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || (k != 3 && k != 5) || (stride != 1 && stride != 2)) return EFFDET_EINVAL;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.k = k; a.stride = stride;
+    a.Ho = same_out(H, stride); a.Wo = same_out(W, stride);
+    a.pad_t = same_pad_before(H, k, stride); a.pad_l = same_pad_before(W, k, stride);
+    return 0;
+}
+
+extern "C" int effdet_train_dwconv_bwd_dx(void* stream, const float* dY, const float* taps, float* dX,
+                                          int B, int H, int W, int C, int k, int stride) {
+    EFFDET_ENTER();
+    DwBwdArgs a;
+    if (!dY || !taps || !dX || dw_fill(a, B, H, W, C, k, stride)) return EFFDET_EINVAL;
+    a.dY = dY; a.taps = taps; a.dX = dX; a.X = nullptr; a.partial = nullptr; a.px_per_chunk = 0;
+    const long long total = (long long)B * H * W * (C / 4);
+    const long long blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return EFFDET_EINVAL;
+    hipLaunchKernelGGL(dw_bwd_dx_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return effdet_check_launch();
+}
+
+static long long dw_chunks(long long npx, int C, long long* ppc) {
+    const int cgroups = (C + 63) / 64;
+    long long chunks = (2048 + cgroups - 1) / cgroups;            // aim at >= 2048 workgroups
+    long long per = (npx + chunks - 1) / chunks;
+    if (per < 64) per = 64;
+    per = (per + 3) / 4 * 4;
+    *ppc = per;
+    return (npx + per - 1) / per;
+}
+
+extern "C" long long effdet_train_dwconv_bwd_dw_workspace_floats(int B, int H, int W, int C, int k, int stride) {
+    DwBwdArgs a;
+    if (dw_fill(a, B, H, W, C, k, stride)) return EFFDET_EINVAL;
+    long long per;
+    return dw_chunks((long long)B * a.Ho * a.Wo, C, &per) * (k * k + 1) * C;
+}
+
+extern "C" int effdet_train_dwconv_bwd_dw(void* stream, const float* dY, const float* X, float* out,
+                                          int B, int H, int W, int C, int k, int stride, float* workspace, long long workspace_floats) {
+    EFFDET_ENTER();
+    DwBwdArgs a;
+    if (!dY || !X || !out || !workspace || dw_fill(a, B, H, W, C, k, stride)) return EFFDET_EINVAL;
+    long long per;
+    const long long chunks = dw_chunks((long long)B * a.Ho * a.Wo, C, &per);
+    if (workspace_floats < chunks * (k * k + 1) * C || chunks > 0x7fffffffLL) return EFFDET_EINVAL;
+    a.dY = dY; a.X = X; a.taps = nullptr; a.dX = nullptr; a.partial = workspace; a.px_per_chunk = per;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)chunks, (unsigned)((C + 63) / 64));
+    if (k == 3) hipLaunchKernelGGL(dw_bwd_dw_kernel<3>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(dw_bwd_dw_kernel<5>, grid, dim3(256), 0, st, a);
+    int rc = effdet_check_launch();
+    if (rc) return rc;
+    return launch_reduce_mid(st, workspace, 1, (int)chunks, (long long)(k * k + 1) * C, out, 0);
+}
+
+extern "C" int effdet_train_ew(void* stream, int op, float* out, const float* a, const float* b, const float* c,
+                               const float* v0, const float* v1, const float* v2, const float* v3,
+                               float s0, float s1, float s2, float s3, long long n, int C, long long hw) {
+    EFFDET_ENTER();
+    if (!out || !a || n <= 0 || n % 4 || C <= 0 || C % 4 || op < 0 || op > 9) return EFFDET_EINVAL;
+    const bool need_b = op == 1 || op == 2 || op == 6 || op == 7 || op == 9;
+    if (need_b && !b) return EFFDET_EINVAL;
+    if ((op == 3 || op == 4 || op == 5 || op == 6) && !v0) return EFFDET_EINVAL;
+    if ((op == 5 || op == 6) && !v1) return EFFDET_EINVAL;
+    if (op == 6 && (!v2 || !v3)) return EFFDET_EINVAL;
+    if ((op == 4 || op == 5) && hw <= 0) return EFFDET_EINVAL;
+    if (op == 7 && s3 == 0.f) return EFFDET_EINVAL;
+    EwArgs p{op, out, a, b, c, v0, v1, v2, v3, s0, s1, s2, s3, n, C, (hw > 0 ? hw : 1) * C};
+    const long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 0x7fffffffLL) return EFFDET_EINVAL;
+    hipLaunchKernelGGL(ew_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+    return effdet_check_launch();
+}
+
+static int col_slices(int G, long long R, int C, long long* rps) {
+    const long long cg = (long long)((C + 63) / 64) * G;
+    long long S = (1024 + cg - 1) / cg;
+    const long long by_rows = (R + 63) / 64;
+    if (S > by_rows) S = by_rows;
+    if (S < 1) S = 1;
+    long long per = (R + S - 1) / S;
+    per = (per + 3) / 4 * 4;
+    *rps = per;
+    return (int)((R + per - 1) / per);
+}
+
+extern "C" long long effdet_train_col_reduce_workspace_floats(int G, long long R, int C) {
+    if (G <= 0 || R <= 0 || C <= 0) return EFFDET_EINVAL;
+    long long rps;
+    return (long long)col_slices(G, R, C, &rps) * G * C;
+}
+
+extern "C" int effdet_train_col_reduce(void* stream, int mode, const float* a, const float* b, const float* v,
+                                       int G, long long R, int C, float* out, float* workspace, long long workspace_floats) {
+    EFFDET_ENTER();
+    if (!a || !out || !workspace || G <= 0 || G > 65535 || R <= 0 || C <= 0 || mode < 0 || mode > 3) return EFFDET_EINVAL;
+    if ((mode == 1 || mode == 3) && !b) return EFFDET_EINVAL;
+    if (mode >= 2 && !v) return EFFDET_EINVAL;
+    long long rps;
+    const int S = col_slices(G, R, C, &rps);
+    if (workspace_floats < (long long)S * G * C) return EFFDET_EINVAL;
+    ColArgs p{mode, a, b, v, workspace, R, rps, C, S};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)S, (unsigned)((C + 63) / 64), (unsigned)G), dim3(256), 0, st, p);
+    int rc = effdet_check_launch();
+    if (rc) return rc;
+    return launch_reduce_mid(st, workspace, G, S, C, out, 0);
+}
+
+extern "C" int effdet_train_spatial(void* stream, int op, const float* in, const float* aux, float* out,
+                                    int B, int H, int W, int C) {
+    EFFDET_ENTER();
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || op < 0 || op > 2 || (op == 2 && !aux)) return EFFDET_EINVAL;
+    SpArgs p{op, in, aux, out, B, H, W, C, same_out(H, 2), same_out(W, 2), same_pad_before(H, 3, 2), same_pad_before(W, 3, 2)};
+    const long long total = (long long)B * H * W * (C / 4) * (op == 0 ? 4 : 1);
+    const long long blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return EFFDET_EINVAL;
+    hipLaunchKernelGGL(spatial_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+    return effdet_check_launch();
+}
+
+extern "C" int effdet_train_im2col_stem(void* stream, const float* X, float* col, int B, int H, int W) {
+    EFFDET_ENTER();
+    if (!X || !col || B <= 0 || H <= 0 || W <= 0) return EFFDET_EINVAL;
+    Im2colArgs p{X, col, B, H, W, same_out(H, 2), same_out(W, 2), same_pad_before(H, 3, 2), same_pad_before(W, 3, 2)};
+    const long long total = (long long)B * p.Ho * p.Wo * 32;
+    const long long blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return EFFDET_EINVAL;
+    hipLaunchKernelGGL(im2col_stem_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+    return effdet_check_launch();
+}
+
+extern "C" int effdet_train_se_bwd(void* stream, const float* pool_sum, int hw, const float* gate, const float* dgate,
+                                   const float* W1, const float* b1, const float* W2t, float* ds, float* pgrad,
+                                   int B, int C, int R) {
+    EFFDET_ENTER();
+    if (!pool_sum || !gate || !dgate || !W1 || !b1 || !W2t || !ds || !pgrad || hw <= 0 || B <= 0 || C <= 0 || R <= 0) return EFFDET_EINVAL;
+    const size_t sh = (size_t)(2 * C + 2 * R) * sizeof(float);
+    if (sh > 64 * 1024) return EFFDET_EINVAL;
+    SeBwdArgs p{pool_sum, 1.0f / (float)hw, gate, dgate, W1, b1, W2t, ds, pgrad, C, R};
+    hipLaunchKernelGGL(se_bwd_kernel, dim3(B), dim3(256), sh, reinterpret_cast<hipStream_t>(stream), p);
+    return effdet_check_launch();
+}

@@ -277,6 +277,8 @@ class EfficientDet(nn.Module):
             if 'backbone' not in n:
                 (_init_weight_alt if alternate_init else _init_weight)(m, n)
         self._engine = None
+        self._train_engine = None
+        self.autograd = None        # None: differentiable forward iff self.training and grad mode and trainable params; True/False forces
         self._wver = [0]            # bumped whenever parameters may have changed; shared by shallow copies of the model
         self.ood_energy = None
         self.ood_max_logit = None
@@ -293,6 +295,7 @@ class EfficientDet(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._engine = None
+        self._train_engine = None
         self._wver[0] += 1
         return super()._apply(fn, *a, **k)
 
@@ -300,6 +303,7 @@ class EfficientDet(nn.Module):
         # the engine holds device buffers and ctypes arrays: never copied / pickled, rebuilt on demand
         d = self.__dict__.copy()
         d['_engine'] = None
+        d['_train_engine'] = None
         return d
 
     def prepare(self, batch_size, image_size=None, ood_out=None):
@@ -359,7 +363,34 @@ class EfficientDet(nn.Module):
             raise ValueError('unknown mode %r' % (mode,))
         if fast_weights is not None or ret_activs:
             raise NotImplementedError('fast_weights / ret_activs belong to the MetaHead path')
+        if mode in _TRAIN_MODES and self.wants_autograd():
+            return _run_train(self, x, mode)
         return _run(self, x, mode)
+
+    def wants_autograd(self):
+        """True when forward must be differentiable (pretrain.py:226-236): module in training mode, grad mode on and
+        trainable parameters - or `self.autograd` forced.  The differentiable path is float32, keeps activations, uses
+        batch statistics in every BatchNorm whose `.training` is set, and is several times slower than inference."""
+        if self.autograd is not None:
+            return bool(self.autograd)
+        return self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
+
+_TRAIN_MODES = ('full_net', 'bb', 'fpn_and_head')
+
+
+def _run_train(model, x, mode):
+    """Differentiable forward on the training engine (train_engine.py); outputs carry autograd history."""
+    from ..train_engine import TrainEngine, run_backbone, run_fpn_heads
+    eng = model._train_engine
+    if eng is None or eng.dev != model.backbone.conv_stem.weight.device:
+        eng = model._train_engine = TrainEngine(model)
+    model.ood_energy = model.ood_max_logit = None          # the OOD epilogue belongs to the inference kernels
+    if mode == 'bb':
+        return run_backbone(eng, x)
+    if mode == 'fpn_and_head':
+        return run_fpn_heads(eng, list(x))
+    return run_fpn_heads(eng, run_backbone(eng, x))
 
 
 def _run(model, x, mode):

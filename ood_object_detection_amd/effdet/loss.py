@@ -52,7 +52,7 @@ def _pack(outs, width):
     B = outs[0].shape[0]
     base = outs[0]._base
     if base is not None and base.dim() == 3 and base.shape[0] == B and base.shape[2] == width and base.is_contiguous() \
-            and all(o._base is base for o in outs) and not any(o.requires_grad for o in outs):
+            and all(o._base is base for o in outs):
         n = sum(o.shape[1] * o.shape[2] * o.shape[3] for o in outs) // width
         if base.shape[1] == n:
             return base

@@ -1,0 +1,742 @@
+"""Forward-with-saved-activations and backward of the pretrain step on libeffdet_hip.so.
+
+Reference: pretrain.py:226-236 (`model(x, mode='bb')` -> `model(feats, mode='fpn_and_head')` -> `loss_fn` ->
+`qry_loss.backward()`), with the module semantics of timm's EfficientNet blocks and effdet/efficientdet.py:42-469.
+float32 only (the reference trains in fp32).  BatchNorm follows each module's own `.training` flag like nn.BatchNorm2d:
+batch statistics (+ running-stat update) where it is set - by default BiFPN and heads - and running statistics where
+it is not (pretrain.py:168-176 puts the backbone's BN in eval mode; that is the only backbone mode built).
+Stochastic depth / dropout of the timm backbone (`drop_path_rate` in backbone_args) are NOT applied: the step is
+deterministic, and bitwise reproducible (all reductions are fixed-order).
+
+Division of labour: every activation-sized operation (anything O(B*H*W*C)) is a HIP kernel of csrc/train_net.hip (plus
+the forward kernels effdet_dwconv_bn_act / effdet_maxpool_same / effdet_se_gate); PyTorch does parameter-sized glue only
+(folding BN into conv weights, transposing weights, the closed-form chain rule from the kernels' raw sums to
+d weight / d gamma / d beta / d edge_weights) and owns memory, streams and the autograd graph the two stage
+functions (`BackboneFn`, `FpnHeadFn`) plug into, so `loss.backward()` fills `.grad` exactly like the reference.
+There is no CPU fallback.
+"""
+import math
+
+import torch
+
+from . import _lib
+
+
+def _same_out(n, s):
+    return (n + s - 1) // s
+
+
+class _Ops(object):
+    """Thin tensor-level wrappers of the C ABI (float32 NHWC tensors on one GPU)."""
+
+    def __init__(self, device):
+        self.lib = _lib.load()
+        self.dev = device
+        self._ws = None
+
+    def st(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def new(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.dev)
+
+    def ws(self, n):
+        n = int(n)
+        if n < 0:
+            raise RuntimeError('workspace query rejected its arguments')
+        if self._ws is None or self._ws.numel() < n:
+            self._ws = self.new(max(n, 1 << 20))
+        return self._ws
+
+    # ---- GEMMs ----------------------------------------------------------------------------------
+    def gemm_nt(self, A, W, bias=None, M=None, a_map=None, out=None, c_map=None):
+        """A [M,K] (dense, or a (ptr, rpi, img_stride, ld) map) x W[N,K]^T + bias -> out [M,N]."""
+        N, K = W.shape
+        if a_map is None:
+            M = A.numel() // K
+            ap, am = A.data_ptr(), (0, 0, 0)
+        else:
+            ap, am = a_map[0], a_map[1:]
+        if c_map is None:
+            out = self.new(M, N)
+            cp, cm = out.data_ptr(), (0, 0, 0)
+        else:
+            cp, cm = c_map[0], c_map[1:]
+        _lib.check(self.lib.effdet_train_gemm_nt(self.st(), ap, am[0], am[1], am[2], W.data_ptr(),
+                                                 None if bias is None else bias.data_ptr(), cp, cm[0], cm[1], cm[2], M, K, N, 0),
+                   'effdet_train_gemm_nt')
+        return out
+
+    def gemm_tn(self, dY, X, N, K, M=None, y_map=None, x_map=None):
+        """-> (dW [N,K], dsum [N]) = dY^T [X | 1]"""
+        if y_map is None:
+            M = dY.numel() // N
+            yp, ym = dY.data_ptr(), (0, 0, 0)
+        else:
+            yp, ym = y_map[0], y_map[1:]
+        if x_map is None:
+            xp, xm = X.data_ptr(), (0, 0, 0)
+        else:
+            xp, xm = x_map[0], x_map[1:]
+        n = self.lib.effdet_train_gemm_tn_workspace_floats(M, N, K)
+        ws = self.ws(n)
+        out = self.new(N, K + 1)
+        _lib.check(self.lib.effdet_train_gemm_tn(self.st(), yp, ym[0], ym[1], ym[2], xp, xm[0], xm[1], xm[2], M, N, K,
+                                                 out.data_ptr(), ws.data_ptr(), ws.numel()), 'effdet_train_gemm_tn')
+        return out[:, :K], out[:, K]
+
+    # ---- depthwise ------------------------------------------------------------------------------
+    def dw_fwd(self, x, taps, scale, shift, k, s):
+        B, H, W, C = x.shape
+        y = self.new(B, _same_out(H, s), _same_out(W, s), C)
+        _lib.check(self.lib.effdet_dwconv_bn_act(self.st(), 0, x.data_ptr(), y.data_ptr(), taps.data_ptr(), scale.data_ptr(),
+                                                 shift.data_ptr(), 0, None, B, H, W, C, k, s), 'effdet_dwconv_bn_act')
+        return y
+
+    def dw_bwd(self, dy, x, taps, k, s):
+        """-> dx, dtaps [k*k, C], dsum [C]   (taps already carry any folded BN scale)"""
+        B, H, W, C = x.shape
+        dx = self.new(B, H, W, C)
+        _lib.check(self.lib.effdet_train_dwconv_bwd_dx(self.st(), dy.data_ptr(), taps.data_ptr(), dx.data_ptr(), B, H, W, C, k, s),
+                   'effdet_train_dwconv_bwd_dx')
+        n = self.lib.effdet_train_dwconv_bwd_dw_workspace_floats(B, H, W, C, k, s)
+        ws = self.ws(n)
+        out = self.new(k * k + 1, C)
+        _lib.check(self.lib.effdet_train_dwconv_bwd_dw(self.st(), dy.data_ptr(), x.data_ptr(), out.data_ptr(), B, H, W, C, k, s,
+                                                       ws.data_ptr(), ws.numel()), 'effdet_train_dwconv_bwd_dw')
+        return dx, out[:k * k], out[k * k]
+
+    # ---- element-wise ---------------------------------------------------------------------------
+    def ew(self, op, a, b=None, c=None, v=(None, None, None, None), s=(0.0, 0.0, 0.0, 0.0), hw=0):
+        out = torch.empty_like(a)
+        C = a.shape[-1]
+        p = lambda t: None if t is None else t.data_ptr()
+        _lib.check(self.lib.effdet_train_ew(self.st(), op, out.data_ptr(), a.data_ptr(), p(b), p(c), p(v[0]), p(v[1]), p(v[2]), p(v[3]),
+                                            s[0], s[1], s[2], s[3], a.numel(), C, hw), 'effdet_train_ew(%d)' % op)
+        return out
+
+    def silu(self, z):
+        return self.ew(0, z)
+
+    def silu_bwd(self, z, da):
+        return self.ew(1, z, da)
+
+    def add(self, a, b):
+        return self.ew(2, a, b)
+
+    def col_reduce(self, mode, a, b=None, v=None, per_image=False):
+        """a: [..., C]; -> [C] (or [B, C] per image)"""
+        C = a.shape[-1]
+        G = a.shape[0] if per_image else 1
+        R = a.numel() // (C * G)
+        n = self.lib.effdet_train_col_reduce_workspace_floats(G, R, C)
+        ws = self.ws(n)
+        out = self.new(G, C)
+        _lib.check(self.lib.effdet_train_col_reduce(self.st(), mode, a.data_ptr(), None if b is None else b.data_ptr(),
+                                                    None if v is None else v.data_ptr(), G, R, C, out.data_ptr(),
+                                                    ws.data_ptr(), ws.numel()), 'effdet_train_col_reduce')
+        return out if per_image else out[0]
+
+    def spatial(self, op, x, aux=None):
+        B, H, W, C = x.shape
+        if op == 0:
+            out = self.new(B, 2 * H, 2 * W, C)
+            h, w = H, W
+        elif op == 1:
+            h, w = H // 2, W // 2
+            out = self.new(B, h, w, C)
+        else:
+            out = self.new(B, H, W, C)
+            h, w = H, W
+        _lib.check(self.lib.effdet_train_spatial(self.st(), op, x.data_ptr(), None if aux is None else aux.data_ptr(),
+                                                 out.data_ptr(), B, h, w, C), 'effdet_train_spatial(%d)' % op)
+        return out
+
+    def maxpool(self, x):
+        B, H, W, C = x.shape
+        y = self.new(B, _same_out(H, 2), _same_out(W, 2), C)
+        _lib.check(self.lib.effdet_maxpool_same(self.st(), 0, x.data_ptr(), 0, y.data_ptr(), 0, B, H, W, C), 'effdet_maxpool_same')
+        return y
+
+    def reduce_rows(self, t):
+        """[S, L] -> [L] in row order"""
+        S, L = t.shape
+        out = self.new(L)
+        _lib.check(self.lib.effdet_train_reduce_mid(self.st(), t.data_ptr(), 1, S, L, out.data_ptr(), 0), 'effdet_train_reduce_mid')
+        return out
+
+
+def _bn_vectors(bn):
+    """(gamma, beta, mean, rstd, scale, shift) of a BatchNorm in eval mode."""
+    g, b = bn.weight.detach(), bn.bias.detach()
+    mean = bn.running_mean.detach()
+    rstd = torch.rsqrt(bn.running_var.detach() + bn.eps)
+    scale = g * rstd
+    return g, b, mean, rstd, scale, b - mean * scale
+
+
+class TrainEngine(object):
+    """Stage functions `bb_forward/backward`, `fh_forward/backward` over one model (its parameters are read live, so an
+    optimizer step needs no re-preparation)."""
+
+    def __init__(self, model):
+        p0 = model.backbone.conv_stem.weight
+        if p0.device.type != 'cuda':
+            raise RuntimeError('the training path needs the model on a GPU (cuda:N); there is no CPU fallback')
+        if p0.dtype != torch.float32:
+            raise RuntimeError('the training path is float32 (the reference trains in fp32; pretrain.py:226)')
+        self.model = model
+        self.dev = p0.device
+        self.ops = _Ops(self.dev)
+        self.lib = self.ops.lib
+        cfg = model.config
+        self.cfg = cfg
+        self.F = cfg.fpn_channels
+        self.L = cfg.num_levels
+        self.A = model.num_anchors
+        self._ones = {}
+
+    def _const(self, C, v):
+        key = (C, v)
+        if key not in self._ones:
+            self._ones[key] = torch.full((C,), float(v), dtype=torch.float32, device=self.dev)
+        return self._ones[key]
+
+    # =============================================================================================
+    # conv (+BN) building blocks.  Every *_fwd returns (output, record); *_bwd(record, dy, grads) returns dx.
+    # =============================================================================================
+    def _pw_bneval_fwd(self, x, conv, bn, names):
+        """1x1 conv (no bias) + BN with running statistics, folded: z = x (scale*W)^T + shift."""
+        if bn.training:
+            raise NotImplementedError('backbone BatchNorm in batch-statistics mode is not built: put the backbone BN in eval '
+                                      'mode as pretrain.py:168-176 does (model.backbone.apply(set_bn_eval))')
+        N = conv.weight.shape[0]
+        W = conv.weight.detach().reshape(N, -1)
+        g, b, mean, rstd, scale, shift = _bn_vectors(bn)
+        Wf = (W * scale[:, None]).contiguous()
+        B, H, Wd, K = x.shape
+        z = self.ops.gemm_nt(x, Wf, shift.contiguous()).view(B, H, Wd, N)
+        return z, dict(x=x, W=W, Wf=Wf, mean=mean, rstd=rstd, scale=scale, names=names, wshape=conv.weight.shape)
+
+    def _pw_bneval_bwd(self, rec, dz, grads, need_dx=True):
+        N, K = rec['Wf'].shape
+        dWraw, dsum = self.ops.gemm_tn(dz, rec['x'], N, K)
+        wn, gn, bn_ = rec['names']
+        grads[wn] = (rec['scale'][:, None] * dWraw).reshape(rec['wshape'])
+        grads[gn] = rec['rstd'] * ((rec['W'] * dWraw).sum(1) - rec['mean'] * dsum)
+        grads[bn_] = dsum.clone()
+        if not need_dx:
+            return None
+        B, H, Wd, _ = dz.shape
+        return self.ops.gemm_nt(dz, rec['Wf'].t().contiguous()).view(B, H, Wd, K)
+
+    def _dw_bneval_fwd(self, x, conv, bn, k, s, names):
+        if bn.training:
+            raise NotImplementedError('backbone BatchNorm in batch-statistics mode is not built (see pretrain.py:168-176)')
+        C = conv.weight.shape[0]
+        taps = conv.weight.detach().permute(2, 3, 0, 1).reshape(k * k, C).contiguous()
+        g, b, mean, rstd, scale, shift = _bn_vectors(bn)
+        z = self.ops.dw_fwd(x, taps, scale.contiguous(), shift.contiguous(), k, s)
+        return z, dict(x=x, taps=taps, mean=mean, rstd=rstd, scale=scale, k=k, s=s, names=names, wshape=conv.weight.shape)
+
+    def _dw_bneval_bwd(self, rec, dz, grads):
+        k, s = rec['k'], rec['s']
+        dx, dtaps, dsum = self.ops.dw_bwd(dz, rec['x'], (rec['taps'] * rec['scale'][None, :]).contiguous(), k, s)
+        wn, gn, bn_ = rec['names']
+        C = dtaps.shape[1]
+        grads[wn] = (dtaps * rec['scale'][None, :]).reshape(k, k, C, 1).permute(2, 3, 0, 1).reshape(rec['wshape'])
+        grads[gn] = rec['rstd'] * ((rec['taps'] * dtaps).sum(0) - rec['mean'] * dsum)
+        grads[bn_] = dsum.clone()
+        return dx
+
+    def _bn_fwd(self, c, bn, prefix):
+        """BatchNorm2d on a raw conv output c [..., C] following bn.training (batch vs running statistics)."""
+        C = c.shape[-1]
+        M = c.numel() // C
+        g, b = bn.weight.detach(), bn.bias.detach()
+        if bn.training:
+            mean = self.ops.col_reduce(0, c) / M
+            var = self.ops.col_reduce(2, c, v=mean) / M
+            with torch.no_grad():
+                mom = bn.momentum if bn.momentum is not None else 0.1
+                bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+                bn.running_var.mul_(1 - mom).add_(var * (M / max(M - 1, 1)), alpha=mom)
+                bn.num_batches_tracked += 1
+        else:
+            mean, var = bn.running_mean.detach().clone(), bn.running_var.detach().clone()
+        rstd = torch.rsqrt(var + bn.eps)
+        scale = g * rstd
+        shift = b - mean * scale
+        y = self.ops.ew(3, c, v=(scale.contiguous(), shift.contiguous(), None, None))
+        return y, dict(c=c, mean=mean.contiguous(), rstd=rstd, scale=scale.contiguous(), train=bn.training, M=M, prefix=prefix)
+
+    def _bn_bwd(self, rec, dy, grads):
+        c, mean, rstd = rec['c'], rec['mean'], rec['rstd']
+        s1 = self.ops.col_reduce(0, dy)
+        s2c = self.ops.col_reduce(3, dy, c, v=mean)
+        self._acc(grads, rec['prefix'] + 'weight', s2c * rstd)
+        self._acc(grads, rec['prefix'] + 'bias', s1)
+        if rec['train']:
+            M = rec['M']
+            return self.ops.ew(6, dy, c, v=(rec['scale'], (s1 / M).contiguous(), mean, (rstd * rstd * s2c / M).contiguous()))
+        return self.ops.ew(3, dy, v=(rec['scale'], None, None, None))
+
+    @staticmethod
+    def _acc(grads, name, g):
+        grads[name] = g if name not in grads else grads[name] + g
+
+    def _pw_fwd(self, x, conv, prefix, c_map=None):
+        """1x1 conv with optional bias, raw output (BN, if any, is applied by _bn_fwd)."""
+        N = conv.weight.shape[0]
+        W = conv.weight.detach().reshape(N, -1).contiguous()
+        bias = None if conv.bias is None else conv.bias.detach().contiguous()
+        B, H, Wd, K = x.shape
+        if c_map is None:
+            c = self.ops.gemm_nt(x, W, bias).view(B, H, Wd, N)
+        else:
+            self.ops.gemm_nt(x, W, bias, M=B * H * Wd, a_map=(x.data_ptr(), 0, 0, 0), c_map=c_map)
+            c = None
+        return c, dict(x=x, W=W, prefix=prefix, wshape=conv.weight.shape, has_bias=bias is not None)
+
+    def _pw_bwd(self, rec, dc, grads, y_map=None, need_dx=True):
+        N, K = rec['W'].shape
+        B, H, Wd, _ = rec['x'].shape
+        M = B * H * Wd
+        dW, dsum = self.ops.gemm_tn(dc, rec['x'], N, K, M=M, y_map=y_map)
+        self._acc(grads, rec['prefix'] + 'weight', dW.reshape(rec['wshape']))
+        if rec['has_bias']:
+            self._acc(grads, rec['prefix'] + 'bias', dsum)
+        if not need_dx:
+            return None
+        Wt = rec['W'].t().contiguous()
+        if y_map is None:
+            return self.ops.gemm_nt(dc, Wt).view(B, H, Wd, K)
+        return self.ops.gemm_nt(None, Wt, M=M, a_map=y_map).view(B, H, Wd, K)
+
+    def _dw_fwd(self, x, conv, prefix):
+        """depthwise 3x3/s1 without BN (SeparableConv2d.conv_dw, efficientdet.py:66-69)"""
+        C = conv.weight.shape[0]
+        k = conv.weight.shape[-1]
+        taps = conv.weight.detach().permute(2, 3, 0, 1).reshape(k * k, C).contiguous()
+        d = self.ops.dw_fwd(x, taps, self._const(C, 1.0), self._const(C, 0.0), k, 1)
+        return d, dict(x=x, taps=taps, k=k, prefix=prefix, wshape=conv.weight.shape)
+
+    def _dw_bwd(self, rec, dd, grads):
+        k = rec['k']
+        dx, dtaps, _ = self.ops.dw_bwd(dd, rec['x'], rec['taps'], k, 1)
+        C = dtaps.shape[1]
+        self._acc(grads, rec['prefix'] + 'weight', dtaps.reshape(k, k, C, 1).permute(2, 3, 0, 1).reshape(rec['wshape']))
+        return dx
+
+    # =============================================================================================
+    # backbone
+    # =============================================================================================
+    def _se_fwd(self, a, se, R):
+        B, H, W, C = a.shape
+        pool = self.ops.col_reduce(0, a, per_image=True)                   # [B, C] sums
+        W1 = se.conv_reduce.weight.detach().reshape(R, C).contiguous()
+        b1 = se.conv_reduce.bias.detach().contiguous()
+        W2t = se.conv_expand.weight.detach().reshape(C, R).t().contiguous()
+        b2 = se.conv_expand.bias.detach().contiguous()
+        gate = self.ops.new(B, C)
+        _lib.check(self.lib.effdet_se_gate(self.ops.st(), pool.data_ptr(), 1, H * W, W1.data_ptr(), b1.data_ptr(), W2t.data_ptr(),
+                                           b2.data_ptr(), gate.data_ptr(), B, C, R), 'effdet_se_gate')
+        ag = self.ops.ew(4, a, v=(gate, None, None, None), hw=H * W)
+        return ag, dict(a=a, pool=pool, gate=gate, W1=W1, b1=b1, W2t=W2t, R=R)
+
+    def _se_bwd(self, rec, dag, grads, prefix):
+        a, gate, R = rec['a'], rec['gate'], rec['R']
+        B, H, W, C = a.shape
+        dgate = self.ops.col_reduce(1, dag, a, per_image=True)
+        ds = self.ops.new(B, C)
+        L = 2 * R * C + R + C
+        pg = self.ops.new(B, L)
+        _lib.check(self.lib.effdet_train_se_bwd(self.ops.st(), rec['pool'].data_ptr(), H * W, gate.data_ptr(), dgate.data_ptr(),
+                                                rec['W1'].data_ptr(), rec['b1'].data_ptr(), rec['W2t'].data_ptr(), ds.data_ptr(),
+                                                pg.data_ptr(), B, C, R), 'effdet_train_se_bwd')
+        g = self.ops.reduce_rows(pg)
+        grads[prefix + 'conv_reduce.weight'] = g[:R * C].reshape(R, C, 1, 1)
+        grads[prefix + 'conv_reduce.bias'] = g[R * C:R * C + R].clone()
+        grads[prefix + 'conv_expand.weight'] = g[R * C + R:2 * R * C + R].reshape(R, C).t().reshape(C, R, 1, 1)
+        grads[prefix + 'conv_expand.bias'] = g[2 * R * C + R:].clone()
+        return self.ops.ew(5, dag, v=(gate, ds, None, None), s=(1.0 / (H * W), 0.0, 0.0, 0.0), hw=H * W)
+
+    def bb_forward(self, x):
+        """x: [B,3,H,W] float32 (normalised) or uint8 (raw; loader normalisation applied).  -> (feats NHWC list, saved)"""
+        bb = self.model.backbone
+        ops = self.ops
+        if x.device != self.dev:
+            raise RuntimeError('input must live on %s (no CPU fallback)' % (self.dev,))
+        B, _, H, W = x.shape
+        if x.dtype == torch.uint8:
+            import ctypes
+            mean = (ctypes.c_float * 3)(*[255.0 * v for v in self.model.input_mean])
+            std = (ctypes.c_float * 3)(*[255.0 * v for v in self.model.input_std])
+            xf = ops.new(B, 3, H, W)
+            _lib.check(self.lib.effdet_normalize_u8(ops.st(), 0, x.contiguous().data_ptr(), mean, std, xf.data_ptr(), B, 3, H * W),
+                       'effdet_normalize_u8')
+            x = xf
+        elif x.dtype != torch.float32:
+            raise RuntimeError('training input must be float32 or uint8')
+        x = x.contiguous()
+        stem_c, stages = bb.arch
+        Ho, Wo = _same_out(H, 2), _same_out(W, 2)
+        col = ops.new(B, Ho, Wo, 32)
+        _lib.check(self.lib.effdet_train_im2col_stem(ops.st(), x.data_ptr(), col.data_ptr(), B, H, W), 'effdet_train_im2col_stem')
+        saved = dict(blocks=[])
+
+        class _StemConv(object):                      # conv_stem as a 1x1 conv over the 32-wide patches
+            pass
+        sc = _StemConv()
+        w = bb.conv_stem.weight.detach().permute(0, 2, 3, 1).reshape(stem_c, 27)
+        sc.weight = torch.cat([w, w.new_zeros(stem_c, 5)], 1)
+        z0, rec = self._pw_bneval_fwd(col, sc, bb.bn1, ('conv_stem.weight', 'bn1.weight', 'bn1.bias'))
+        rec['wshape'] = (stem_c, 32)
+        saved['stem'] = (rec, z0)
+        cur = ops.silu(z0)
+        feats = []
+        for si, blocks in enumerate(stages):
+            for bi, b in enumerate(blocks):
+                m = bb.blocks[si][bi]
+                p = 'blocks.%d.%d.' % (si, bi)
+                r = dict(b=b, p=p, x=cur)
+                if b['type'] == 'ir':
+                    z1, r['pw'] = self._pw_bneval_fwd(cur, m.conv_pw, m.bn1, (p + 'conv_pw.weight', p + 'bn1.weight', p + 'bn1.bias'))
+                    r['z1'] = z1
+                    a1 = ops.silu(z1)
+                    z2, r['dw'] = self._dw_bneval_fwd(a1, m.conv_dw, m.bn2, b['k'], b['s'],
+                                                      (p + 'conv_dw.weight', p + 'bn2.weight', p + 'bn2.bias'))
+                    proj, bnp, pn = m.conv_pwl, m.bn3, (p + 'conv_pwl.weight', p + 'bn3.weight', p + 'bn3.bias')
+                else:
+                    z2, r['dw'] = self._dw_bneval_fwd(cur, m.conv_dw, m.bn1, b['k'], b['s'],
+                                                      (p + 'conv_dw.weight', p + 'bn1.weight', p + 'bn1.bias'))
+                    proj, bnp, pn = m.conv_pw, m.bn2, (p + 'conv_pw.weight', p + 'bn2.weight', p + 'bn2.bias')
+                r['z2'] = z2
+                a2 = ops.silu(z2)
+                ag, r['se'] = self._se_fwd(a2, m.se, b['se'])
+                z3, r['proj'] = self._pw_bneval_fwd(ag, proj, bnp, pn)
+                cur = ops.add(z3, cur) if b['residual'] else z3
+                saved['blocks'].append(r)
+            if si in (2, 4, 6):
+                feats.append(cur)
+        return feats, saved
+
+    def bb_backward(self, dfeats, saved):
+        """dfeats: d loss / d feature maps (NHWC, None allowed) -> {param name (relative to backbone): grad}"""
+        ops = self.ops
+        grads = {}
+        stem_c, stages = self.model.backbone.arch
+        flat = [(si, bi) for si, blocks in enumerate(stages) for bi in range(len(blocks))]
+        feat_of_stage = {2: 0, 4: 1, 6: 2}
+        dcur = None
+        for idx in range(len(flat) - 1, -1, -1):
+            si, bi = flat[idx]
+            r = saved['blocks'][idx]
+            b = r['b']
+            if bi == len(stages[si]) - 1 and si in feat_of_stage:
+                df = dfeats[feat_of_stage[si]]
+                if df is not None:
+                    dcur = df if dcur is None else ops.add(dcur, df)
+            if dcur is None:
+                raise RuntimeError('no gradient reached the last backbone stage')
+            dag = self._pw_bneval_bwd(r['proj'], dcur, grads)
+            da2 = self._se_bwd(r['se'], dag, grads, r['p'] + 'se.')
+            dz2 = ops.silu_bwd(r['z2'], da2)
+            dx = self._dw_bneval_bwd(r['dw'], dz2, grads)
+            if b['type'] == 'ir':
+                dz1 = ops.silu_bwd(r['z1'], dx)
+                dx = self._pw_bneval_bwd(r['pw'], dz1, grads)
+            dcur = ops.add(dx, dcur) if b['residual'] else dx
+        rec, z0 = saved['stem']
+        dz0 = ops.silu_bwd(z0, dcur)
+        self._pw_bneval_bwd(rec, dz0, grads, need_dx=False)
+        g = grads['conv_stem.weight']                              # [C0, 32] patch layout -> [C0, 3, 3, 3]
+        grads['conv_stem.weight'] = g[:, :27].reshape(stem_c, 3, 3, 3).permute(0, 3, 1, 2).contiguous()
+        return grads
+
+    # =============================================================================================
+    # BiFPN + heads
+    # =============================================================================================
+    def _convbn_fwd(self, x, cba, prefix):
+        """ConvBnAct2d without activation (efficientdet.py:42-57): 1x1 conv (+bias) -> BN"""
+        c, rpw = self._pw_fwd(x, cba.conv, prefix + 'conv.')
+        if cba.bn is None:
+            return c, dict(pw=rpw, bn=None)
+        y, rbn = self._bn_fwd(c, cba.bn, prefix + 'bn.')
+        return y, dict(pw=rpw, bn=rbn)
+
+    def _convbn_bwd(self, rec, dy, grads):
+        dc = dy if rec['bn'] is None else self._bn_bwd(rec['bn'], dy, grads)
+        return self._pw_bwd(rec['pw'], dc, grads)
+
+    def _resample_fwd(self, x, rs, prefix, delta):
+        """ResampleFeatureMap (efficientdet.py:140-177): conv(+BN) when channels differ, then max-pool (delta = -1: the input
+        is one level finer) or nearest x2 upsample (delta = +1)."""
+        rec = dict(conv=None, delta=delta)
+        if hasattr(rs, 'conv'):
+            x, rec['conv'] = self._convbn_fwd(x, rs.conv, prefix + 'conv.')
+        if delta == -1:
+            rec['pool_in'] = x
+            x = self.ops.maxpool(x)
+        elif delta == 1:
+            x = self.ops.spatial(0, x)
+        elif delta != 0:
+            raise NotImplementedError('BiFPN edge spanning %d levels' % delta)
+        return x, rec
+
+    def _resample_bwd(self, rec, dy, grads):
+        if rec['delta'] == -1:
+            dy = self.ops.spatial(2, rec['pool_in'], dy)
+        elif rec['delta'] == 1:
+            dy = self.ops.spatial(1, dy)
+        if rec['conv'] is not None:
+            dy = self._convbn_bwd(rec['conv'], dy, grads)
+        return dy
+
+    def fh_forward(self, feats, want_cls=True, want_box=True):
+        """feats: backbone feature maps (NHWC).  -> (cls_all [B,N,C], box_all [B,N,4], saved)"""
+        model, ops, F, L = self.model, self.ops, self.F, self.L
+        fpn = model.fpn
+        info = fpn.in_feature_info
+        nbb = len(info)
+        red0 = info[0]['reduction']
+        saved = dict(extra=[], nodes=[], nbb=nbb)
+        x = [dict(t=f, level=i, src=('feat', i)) for i, f in enumerate(feats)]
+        chs = [i['num_chs'] for i in info]
+        for level in range(nbb, L):
+            y, rec = self._resample_fwd(x[-1]['t'], fpn.resample[str(level)], 'fpn.resample.%d.' % level, -1)
+            saved['extra'].append((rec, len(x) - 1))
+            x.append(dict(t=y, level=level))
+            chs.append(F)
+        nodes = fpn.fpn_config.nodes
+        # x grows by 8 nodes per cell and is cut back to the last L; `ids` tracks global tensor ids for the backward pass
+        tensors = list(x)
+        ids = list(range(len(x)))
+        for ci in range(len(fpn.cell)):
+            layer = fpn.cell[ci]
+            for ni, node in enumerate(nodes):
+                fn = layer.fnode[ni]
+                lvl = int(round(math.log2(node['reduction'] / red0)))
+                p = 'fpn.cell.%d.fnode.%d.' % (ci, ni)
+                ins, recs, src_ids = [], [], []
+                for off in node['inputs_offsets']:
+                    src = tensors[ids[off]]
+                    y, rec = self._resample_fwd(src['t'], fn.combine.resample[str(off)], '%scombine.resample.%d.' % (p, off),
+                                                src['level'] - lvl)
+                    ins.append(y)
+                    recs.append(rec)
+                    src_ids.append(ids[off])
+                method = node['weight_method']
+                ew_param = fn.combine.edge_weights
+                if method == 'fastattn':
+                    wv = torch.relu(ew_param.detach())
+                    den = float((wv.sum() + 0.0001).item())
+                    wl = [float(v) for v in wv.tolist()] + [0.0]
+                    fused = ops.ew(7, ins[0], ins[1], ins[2] if len(ins) > 2 else None, s=(wl[0], wl[1], wl[2], den))
+                elif method == 'attn':
+                    wv = torch.softmax(ew_param.detach(), 0)
+                    wl = [float(v) for v in wv.tolist()] + [0.0]
+                    den = 1.0
+                    fused = ops.ew(9, ins[0], ins[1], ins[2] if len(ins) > 2 else None, s=(wl[0], wl[1], wl[2], 0.0))
+                else:
+                    wl, den = [1.0, 1.0, 1.0 if len(ins) > 2 else 0.0], 1.0
+                    fused = ops.ew(9, ins[0], ins[1], ins[2] if len(ins) > 2 else None, s=(wl[0], wl[1], wl[2], 0.0))
+                act = ops.silu(fused)
+                sc = fn.after_combine.conv
+                d, rdw = self._dw_fwd(act, sc.conv_dw, p + 'after_combine.conv.conv_dw.')
+                c, rpw = self._pw_fwd(d, sc.conv_pw, p + 'after_combine.conv.conv_pw.')
+                y, rbn = self._bn_fwd(c, sc.bn, p + 'after_combine.conv.bn.')
+                tensors.append(dict(t=y, level=lvl))
+                ids.append(len(tensors) - 1)
+                saved['nodes'].append(dict(p=p, ins=ins, recs=recs, src_ids=src_ids, method=method, w=wl, den=den, fused=fused,
+                                           dw=rdw, pw=rpw, bn=rbn, out_id=len(tensors) - 1, n_in=len(ins)))
+            ids = ids[-L:]
+        pyr = [tensors[i] for i in ids]
+        saved['pyr_ids'] = list(ids)
+        saved['n_tensors'] = len(tensors)
+        saved['levels'] = [(t['t'].shape[1], t['t'].shape[2]) for t in pyr]
+        # ---- heads
+        B = feats[0].shape[0]
+        hw = saved['levels']
+        P = sum(h * w for h, w in hw)
+        offs, o = [], 0
+        for h, w in hw:
+            offs.append(o)
+            o += h * w
+        A = self.A
+        outs = []
+        saved['heads'] = []
+        for head, name, K, want in ((model.class_net, 'class_net.', self.cfg.num_classes, want_cls), (model.box_net, 'box_net.', 4, want_box)):
+            if not want:
+                outs.append(None)
+                saved['heads'].append(None)
+                continue
+            if not hasattr(head, 'conv_rep') or not hasattr(head, 'bn_rep'):
+                raise NotImplementedError('the training path needs HeadNet heads (MetaHead gradients are not built)')
+            NO = A * K
+            out_t = ops.new(B, A * P, K)
+            hrec = dict(name=name, NO=NO, levels=[], out=out_t)
+            for l in range(L):
+                t = pyr[l]['t']
+                h, w = hw[l]
+                lrec = dict(reps=[])
+                for r in range(len(head.conv_rep)):
+                    conv = head.conv_rep[r]
+                    d, rdw = self._dw_fwd(t, conv.conv_dw, '%sconv_rep.%d.conv_dw.' % (name, r))
+                    c, rpw = self._pw_fwd(d, conv.conv_pw, '%sconv_rep.%d.conv_pw.' % (name, r))
+                    y, rbn = self._bn_fwd(c, head.bn_rep[r][l].bn, '%sbn_rep.%d.%d.bn.' % (name, r, l))
+                    t = ops.silu(y)
+                    lrec['reps'].append((rdw, rpw, rbn, y))
+                d, rdw = self._dw_fwd(t, head.predict.conv_dw, name + 'predict.conv_dw.')
+                cmap = (out_t.data_ptr() + offs[l] * NO * 4, h * w, P * NO, NO)
+                _, rpw = self._pw_fwd(d, head.predict.conv_pw, name + 'predict.conv_pw.', c_map=cmap)
+                lrec['predict'] = (rdw, rpw)
+                lrec['map_off'] = offs[l] * NO
+                hrec['levels'].append(lrec)
+            outs.append(out_t)
+            saved['heads'].append(hrec)
+        saved['P'] = P
+        return outs[0], outs[1], saved
+
+    def fh_backward(self, g_cls, g_box, saved, need_dfeats=True):
+        """-> (d feats list (NHWC), {param name: grad})"""
+        ops, L = self.ops, self.L
+        grads = {}
+        P = saved['P']
+        hw = saved['levels']
+        dt = [None] * saved['n_tensors']                      # gradient per global tensor id
+
+        def add_to(i, g):
+            dt[i] = g if dt[i] is None else ops.add(dt[i], g)
+
+        for hrec, g in zip(saved['heads'], (g_cls, g_box)):
+            if hrec is None or g is None:
+                continue
+            g = g.contiguous()
+            NO = hrec['NO']
+            for l in range(L):
+                lrec = hrec['levels'][l]
+                h, w = hw[l]
+                ymap = (g.data_ptr() + lrec['map_off'] * 4, h * w, P * NO, NO)
+                rdw, rpw = lrec['predict']
+                dd = self._pw_bwd(rpw, None, grads, y_map=ymap)
+                da = self._dw_bwd(rdw, dd, grads)
+                for (rdw, rpw, rbn, y) in reversed(lrec['reps']):
+                    dy = ops.silu_bwd(y, da)
+                    dc = self._bn_bwd(rbn, dy, grads)
+                    dd = self._pw_bwd(rpw, dc, grads)
+                    da = self._dw_bwd(rdw, dd, grads)
+                add_to(saved['pyr_ids'][l], da)
+        for nrec in reversed(saved['nodes']):
+            dy = dt[nrec['out_id']]
+            if dy is None:
+                continue
+            p = nrec['p']
+            dc = self._bn_bwd(nrec['bn'], dy, grads)
+            dd = self._pw_bwd(nrec['pw'], dc, grads)
+            dact = self._dw_bwd(nrec['dw'], dd, grads)
+            dfused = ops.silu_bwd(nrec['fused'], dact)
+            n = nrec['n_in']
+            w, den = nrec['w'], nrec['den']
+            if nrec['method'] in ('fastattn', 'attn'):
+                S = torch.stack([ops.col_reduce(1, dfused, nrec['ins'][i]).sum() for i in range(n)])
+                ewp = self.model.get_parameter(p + 'combine.edge_weights').detach()
+                wt = torch.tensor(w[:n], dtype=torch.float32, device=self.dev)
+                if nrec['method'] == 'fastattn':
+                    dw = S / den - (S * wt).sum() / (den * den)
+                    grads[p + 'combine.edge_weights'] = dw * (ewp > 0).to(dw.dtype)
+                else:
+                    grads[p + 'combine.edge_weights'] = wt * (S - (wt * S).sum())
+            for i in range(n):
+                coef = w[i] / den
+                di = ops.ew(8, dfused, s=(coef, 0.0, 0.0, 0.0))
+                di = self._resample_bwd(nrec['recs'][i], di, grads)
+                add_to(nrec['src_ids'][i], di)
+        nbb = saved['nbb']
+        for k in range(len(saved['extra']) - 1, -1, -1):
+            rec, src = saved['extra'][k]
+            dy = dt[nbb + k]
+            if dy is None:
+                continue
+            add_to(src, self._resample_bwd(rec, dy, grads))
+        return dt[:nbb], grads
+
+
+# =================================================================================================
+# autograd plumbing
+# =================================================================================================
+def _param_list(module, prefix):
+    return [(prefix + n, p) for n, p in module.named_parameters()]
+
+
+class BackboneFn(torch.autograd.Function):
+    """x -> backbone features (NHWC tensors); gradients for the backbone parameters."""
+
+    @staticmethod
+    def forward(ctx, eng, names, x, *params):
+        feats, saved = eng.bb_forward(x)
+        ctx.eng, ctx.saved, ctx.names = eng, saved, names
+        return tuple(feats)
+
+    @staticmethod
+    def backward(ctx, *dfeats):
+        dfeats = [None if d is None else d.contiguous() for d in dfeats]
+        grads = ctx.eng.bb_backward(dfeats, ctx.saved)
+        ctx.saved = None
+        out = []
+        for i, n in enumerate(ctx.names):
+            g = grads.get(n) if ctx.needs_input_grad[3 + i] else None
+            out.append(None if g is None else g.contiguous())
+        return (None, None, None) + tuple(out)
+
+
+class FpnHeadFn(torch.autograd.Function):
+    """backbone features (NHWC) -> packed head outputs cls [B,N,C], box [B,N,4]; gradients for BiFPN / head parameters."""
+
+    @staticmethod
+    def forward(ctx, eng, names, n_feats, *tensors):
+        feats = [t.contiguous() for t in tensors[:n_feats]]
+        cls_all, box_all, saved = eng.fh_forward(feats)
+        ctx.eng, ctx.saved, ctx.names, ctx.n_feats = eng, saved, names, n_feats
+        return cls_all, box_all
+
+    @staticmethod
+    def backward(ctx, g_cls, g_box):
+        dfeats, grads = ctx.eng.fh_backward(g_cls, g_box, ctx.saved)
+        ctx.saved = None
+        out = [d if ctx.needs_input_grad[3 + i] else None for i, d in enumerate(dfeats)]
+        for i, n in enumerate(ctx.names):
+            g = grads.get(n) if ctx.needs_input_grad[3 + ctx.n_feats + i] else None
+            out.append(None if g is None else g.contiguous())
+        return (None, None, None) + tuple(out)
+
+
+def run_backbone(eng, x):
+    """-> NCHW-shaped views of the NHWC feature maps, attached to the autograd graph"""
+    pl = _param_list(eng.model.backbone, '')
+    names = [n for n, _ in pl]
+    feats = BackboneFn.apply(eng, names, x, *[p for _, p in pl])
+    return [f.permute(0, 3, 1, 2) for f in feats]
+
+
+def run_fpn_heads(eng, feats_nchw):
+    model = eng.model
+    pl = _param_list(model.fpn, 'fpn.') + _param_list(model.class_net, 'class_net.') + _param_list(model.box_net, 'box_net.')
+    names = [n for n, _ in pl]
+    feats = [f.permute(0, 2, 3, 1) for f in feats_nchw]
+    cls_all, box_all = FpnHeadFn.apply(eng, names, len(feats), *(feats + [p for _, p in pl]))
+    hw = [(f.shape[2], f.shape[3]) for f in feats_nchw]
+    while len(hw) < eng.L:
+        hw.append((_same_out(hw[-1][0], 2), _same_out(hw[-1][1], 2)))
+    A = eng.A
+
+    def views(t, K):
+        out, off = [], 0
+        B = t.shape[0]
+        for h, w in hw:
+            v = t[:, off * A:(off + h * w) * A, :].reshape(B, h, w, A * K)
+            out.append(v.permute(0, 3, 1, 2))
+            off += h * w
+        return out
+
+    return views(cls_all, model.config.num_classes), views(box_all, 4)

@@ -119,7 +119,17 @@ def maxpool_pad(x, k, s, pad_type):
 CALIBRATE = False
 
 
+# Training restatement (pretrain.py:168-176, 226-236): BatchNorm layers whose state-dict prefix starts with one of these
+# strings run as nn.BatchNorm2d does in training mode - batch statistics, running stats updated in place with
+# BN_MOMENTUM (config norm_kwargs momentum .01) - the rest use running statistics.  Default: none (inference).
+BN_BATCH_STATS_PREFIXES = ()
+BN_MOMENTUM = 0.01
+
+
 def bn_eval(x, sd, prefix, eps):
+    if BN_BATCH_STATS_PREFIXES and prefix.startswith(tuple(BN_BATCH_STATS_PREFIXES)):
+        return F.batch_norm(x, sd[prefix + 'running_mean'], sd[prefix + 'running_var'],
+                            sd[prefix + 'weight'], sd[prefix + 'bias'], True, BN_MOMENTUM, eps)
     if CALIBRATE:
         F.batch_norm(x, sd[prefix + 'running_mean'], sd[prefix + 'running_var'], None, None, True, 1.0, eps)
     return F.batch_norm(x, sd[prefix + 'running_mean'], sd[prefix + 'running_var'],

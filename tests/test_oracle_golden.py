@@ -184,3 +184,23 @@ def test_resize_pad_matches_pil(hw):
     got, inv_scale = opre.resize_pad(img, target, fill)
     assert np.array_equal(got, np.asarray(new_img))
     assert inv_scale == 1.0 / s
+
+
+@pytest.mark.parametrize('tag,alpha,w,ls', [('pre', 0.15, 50.0, 0.0), ('inf', 0.25, 5.0, 0.0), ('ls', 0.25, 5.0, 0.1)])
+def test_detection_loss_oracle_matches_reference(golden, tag, alpha, w, ls):
+    """oracle/train.py::detection_loss (values + autograd gradients) vs the reference's loss_fn (effdet/loss.py:224-298)"""
+    from oracle import train as ot
+    g = golden('loss')
+    B, C, A = [int(v) for v in g['meta'][:3]]
+    sizes = [int(v) for v in g['meta'][3:]]
+    cls_out = [torch.from_numpy(seeded_array(4, 'c%d' % i, (B, A * C, s, s), scale=1.5)).requires_grad_() for i, s in enumerate(sizes)]
+    box_out = [torch.from_numpy(seeded_array(4, 'b%d' % i, (B, A * 4, s, s), scale=0.3)).requires_grad_() for i, s in enumerate(sizes)]
+    cls_t = [torch.from_numpy(g['cls_t%d' % i]) for i in range(5)]
+    box_t = [torch.from_numpy(g['box_t%d' % i]) for i in range(5)]
+    total, cl, bl = ot.detection_loss(cls_out, box_out, cls_t, box_t, torch.from_numpy(g['npos']), C, alpha, 0.1, w, ls)
+    got = torch.stack([total, cl, bl]).detach().numpy()
+    assert np.allclose(got, g[tag + '_loss'], rtol=1e-6, atol=1e-7), (got, g[tag + '_loss'])
+    grads = torch.autograd.grad(total, cls_out + box_out)
+    for i in range(5):
+        assert np.allclose(grads[i].numpy(), g['%s_gc%d' % (tag, i)], rtol=1e-5, atol=1e-8)
+        assert np.allclose(grads[5 + i].numpy(), g['%s_gb%d' % (tag, i)], rtol=1e-5, atol=1e-8)

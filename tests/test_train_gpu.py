@@ -1,0 +1,339 @@
+"""Training path (pretrain.py:226-236): the HIP operators of csrc/train_net.hip against torch autograd on
+the CPU, and the whole differentiable forward / backward of EfficientDet against autograd through the oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _seeded import seeded_array
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _ops():
+    from ood_object_detection_amd.train_engine import _Ops
+    return _Ops(torch.device(DEV))
+
+
+def _rnd(seed, key, shape, scale=1.0):
+    return torch.from_numpy(seeded_array(seed, key, shape, scale=scale))
+
+
+def _close(got, ref, rtol, what=''):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = float((got - ref).abs().max())
+    lim = rtol * max(float(ref.abs().max()), 1e-6)
+    assert err <= lim, '%s: L-inf %.3e > %.3e (max|ref| %.3e)' % (what, err, lim, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize('M,K,N', [(1000, 64, 64), (777, 32, 96), (300, 810, 64), (260, 64, 810), (130, 40, 36), (4096, 16, 8)])
+def test_gemm_nt(M, K, N):
+    ops = _ops()
+    A, W, b = _rnd(1, 'A', (M, K)), _rnd(1, 'W', (N, K)), _rnd(1, 'b', (N,))
+    out = ops.gemm_nt(A.to(DEV), W.to(DEV), b.to(DEV))
+    _close(out, A.double() @ W.double().t() + b.double(), 2e-6 * math.sqrt(K), 'gemm_nt')
+
+
+def test_gemm_row_maps_packed_levels():
+    """the predict layers write / read one pyramid level inside the packed [B, N, C] head output"""
+    ops = _ops()
+    B, hw, NO, K, P = 3, 12, 54, 64, 30            # level occupies pixels [10, 22) of P = 30
+    x = _rnd(2, 'x', (B, hw, K))
+    W = _rnd(2, 'W', (NO, K))
+    packed = torch.zeros(B, P, NO, device=DEV)
+    cmap = (packed.data_ptr() + 10 * NO * 4, hw, P * NO, NO)
+    xd = x.to(DEV)
+    ops.gemm_nt(xd, W.to(DEV), None, M=B * hw, a_map=(xd.data_ptr(), 0, 0, 0), c_map=cmap)
+    ref = torch.zeros(B, P, NO)
+    ref[:, 10:22] = (x.double() @ W.double().t()).float()
+    _close(packed, ref, 1e-5, 'packed write')
+    g = _rnd(2, 'g', (B, P, NO)).to(DEV)
+    ymap = (g.data_ptr() + 10 * NO * 4, hw, P * NO, NO)
+    dW, dsum = ops.gemm_tn(None, xd, NO, K, M=B * hw, y_map=ymap)
+    gl = g.cpu()[:, 10:22].reshape(-1, NO).double()
+    _close(dW, gl.t() @ x.reshape(-1, K).double(), 1e-5, 'dW from packed dY')
+    _close(dsum, gl.sum(0), 1e-5, 'dsum from packed dY')
+    dx = ops.gemm_nt(None, W.t().contiguous().to(DEV), M=B * hw, a_map=ymap)
+    _close(dx, gl @ W.double(), 1e-5, 'dX from packed dY')
+
+
+@pytest.mark.parametrize('M,N,K', [(5000, 64, 64), (70000, 96, 16), (333, 810, 64), (2048, 24, 144), (100, 8, 32)])
+def test_gemm_tn(M, N, K):
+    ops = _ops()
+    dY, X = _rnd(3, 'dY', (M, N)), _rnd(3, 'X', (M, K))
+    dW, dsum = ops.gemm_tn(dY.to(DEV), X.to(DEV), N, K)
+    _close(dW, dY.double().t() @ X.double(), 3e-6 * math.sqrt(M), 'dW')
+    _close(dsum, dY.double().sum(0), 3e-6 * math.sqrt(M), 'dsum')
+
+
+def _same_pad(x, k, s):
+    from oracle.model import same_pad_amounts
+    pt, pb = same_pad_amounts(x.shape[-2], k, s)
+    pl, pr = same_pad_amounts(x.shape[-1], k, s)
+    return F.pad(x, [pl, pr, pt, pb])
+
+
+@pytest.mark.parametrize('k,s,H,W,C', [(3, 1, 9, 7, 8), (3, 2, 16, 16, 24), (5, 1, 10, 10, 40), (5, 2, 17, 12, 16), (3, 2, 5, 5, 96)])
+def test_dwconv_backward(k, s, H, W, C):
+    ops = _ops()
+    B = 2
+    x = _rnd(4, 'x', (B, C, H, W)).requires_grad_()
+    w = _rnd(4, 'w', (C, 1, k, k)).requires_grad_()
+    y = F.conv2d(_same_pad(x, k, s), w, None, s, 0, 1, C)
+    dy = _rnd(4, 'dy', tuple(y.shape))
+    gx, gw = torch.autograd.grad(y, (x, w), dy)
+    taps = w.detach().permute(2, 3, 0, 1).reshape(k * k, C).contiguous().to(DEV)
+    dx, dtaps, dsum = ops.dw_bwd(dy.permute(0, 2, 3, 1).contiguous().to(DEV), x.detach().permute(0, 2, 3, 1).contiguous().to(DEV), taps, k, s)
+    _close(dx.permute(0, 3, 1, 2), gx, 1e-5, 'dw dx')
+    _close(dtaps.reshape(k, k, C, 1).permute(2, 3, 0, 1), gw, 2e-5, 'dw dtaps')
+    _close(dsum, dy.sum((0, 2, 3)), 2e-5, 'dw dsum')
+
+
+def test_elementwise_family():
+    ops = _ops()
+    B, H, W, C = 2, 5, 6, 16
+    a, b, c = _rnd(5, 'a', (B, H, W, C)), _rnd(5, 'b', (B, H, W, C)), _rnd(5, 'c', (B, H, W, C))
+    v = [_rnd(5, 'v%d' % i, (C,)) for i in range(4)]
+    gv = [_rnd(5, 'g%d' % i, (B, C)) for i in range(2)]
+    ad, bd, cd = a.to(DEV), b.to(DEV), c.to(DEV)
+    vd = [t.to(DEV) for t in v]
+    gd = [t.to(DEV) for t in gv]
+    _close(ops.ew(0, ad), a * torch.sigmoid(a), 1e-6, 'silu')
+    z = a.clone().requires_grad_()
+    (gz,) = torch.autograd.grad(z * torch.sigmoid(z), z, b)
+    _close(ops.ew(1, ad, bd), gz, 2e-6, 'silu bwd')
+    _close(ops.ew(2, ad, bd), a + b, 0, 'add')
+    _close(ops.ew(3, ad, v=(vd[0], vd[1], None, None)), a * v[0] + v[1], 1e-6, 'affine')
+    _close(ops.ew(4, ad, v=(gd[0], None, None, None), hw=H * W), a * gv[0][:, None, None, :], 0, 'gate')
+    _close(ops.ew(5, ad, v=(gd[0], gd[1], None, None), s=(0.25, 0, 0, 0), hw=H * W),
+           a * gv[0][:, None, None, :] + gv[1][:, None, None, :] * 0.25, 1e-6, 'gate bwd')
+    _close(ops.ew(6, ad, bd, v=tuple(vd)), v[0] * (a - v[1] - (b - v[2]) * v[3]), 1e-6, 'bn bwd')
+    w = torch.tensor([0.7, 1.3, 0.2])
+    den = float(w.sum() + 0.0001)
+    ref = torch.stack([(t * w[i]) / (w.sum() + 0.0001) for i, t in enumerate((a, b, c))], -1).sum(-1)
+    got = ops.ew(7, ad, bd, cd, s=(float(w[0]), float(w[1]), float(w[2]), den))
+    assert torch.equal(got.cpu(), ref), 'fastattn fusion must round like the reference expression'
+    ref2 = torch.stack([(t * w[i]) / (w[:2].sum() + 0.0001) for i, t in enumerate((a, b))], -1).sum(-1)
+    assert torch.equal(ops.ew(7, ad, bd, None, s=(float(w[0]), float(w[1]), 0.0, float(w[:2].sum() + 0.0001))).cpu(), ref2)
+    _close(ops.ew(8, ad, s=(0.3, 0, 0, 0)), a * 0.3, 1e-7, 'scale')
+
+
+def test_col_reduce_modes():
+    ops = _ops()
+    B, R, C = 3, 1234, 40
+    a, b, v = _rnd(6, 'a', (B, R, C)), _rnd(6, 'b', (B, R, C)), _rnd(6, 'v', (C,))
+    ad, bd, vd = a.to(DEV), b.to(DEV), v.to(DEV)
+    A2, B2 = a.double().reshape(-1, C), b.double().reshape(-1, C)
+    _close(ops.col_reduce(0, ad), A2.sum(0), 1e-5, 'sum')
+    _close(ops.col_reduce(1, ad, bd), (A2 * B2).sum(0), 1e-5, 'dot')
+    _close(ops.col_reduce(2, ad, v=vd), ((A2 - v.double()) ** 2).sum(0), 1e-5, 'centred sumsq')
+    _close(ops.col_reduce(3, ad, bd, v=vd), (A2 * (B2 - v.double())).sum(0), 1e-5, 'centred dot')
+    _close(ops.col_reduce(1, ad, bd, per_image=True), (a.double() * b.double()).sum(1), 1e-5, 'per-image dot')
+    # bitwise reproducible
+    assert torch.equal(ops.col_reduce(1, ad, bd), ops.col_reduce(1, ad, bd))
+
+
+@pytest.mark.parametrize('H,W', [(8, 8), (10, 6), (5, 5), (1, 1), (2, 2)])
+def test_maxpool_backward_and_upsample(H, W):
+    ops = _ops()
+    B, C = 2, 8
+    x = _rnd(7, 'x', (B, C, H, W))
+    x[:, :, 0, 0] = x[:, :, min(1, H - 1), min(1, W - 1)]          # ties: the first maximum takes the gradient
+    x = x.requires_grad_()
+    from oracle.model import maxpool_pad
+    y = maxpool_pad(x, 3, 2, 'same')
+    dy = _rnd(7, 'dy', tuple(y.shape))
+    (gx,) = torch.autograd.grad(y, x, dy)
+    got = ops.spatial(2, x.detach().permute(0, 2, 3, 1).contiguous().to(DEV), dy.permute(0, 2, 3, 1).contiguous().to(DEV))
+    _close(got.permute(0, 3, 1, 2), gx, 1e-6, 'maxpool bwd')
+    xs = _rnd(7, 'u', (B, C, H, W)).requires_grad_()
+    up = F.interpolate(xs, scale_factor=2.0, mode='nearest')
+    du = _rnd(7, 'du', tuple(up.shape))
+    (gu,) = torch.autograd.grad(up, xs, du)
+    assert torch.equal(ops.spatial(0, xs.detach().permute(0, 2, 3, 1).contiguous().to(DEV)).permute(0, 3, 1, 2).cpu(), up.detach())
+    _close(ops.spatial(1, du.permute(0, 2, 3, 1).contiguous().to(DEV)).permute(0, 3, 1, 2), gu, 1e-6, 'upsample bwd')
+
+
+def test_im2col_stem_matches_conv():
+    from ood_object_detection_amd import _lib
+    ops = _ops()
+    B, H, W, C0 = 2, 18, 14, 32
+    x, w = _rnd(8, 'x', (B, 3, H, W)), _rnd(8, 'w', (C0, 3, 3, 3))
+    ref = F.conv2d(_same_pad(x, 3, 2), w, None, 2)
+    Ho, Wo = ref.shape[2:]
+    col = ops.new(B, Ho, Wo, 32)
+    xd = x.to(DEV)
+    _lib.check(ops.lib.effdet_train_im2col_stem(ops.st(), xd.data_ptr(), col.data_ptr(), B, H, W), 'im2col')
+    wk = torch.cat([w.permute(0, 2, 3, 1).reshape(C0, 27), torch.zeros(C0, 5)], 1).to(DEV)
+    out = ops.gemm_nt(col, wk).view(B, Ho, Wo, C0)
+    _close(out.permute(0, 3, 1, 2), ref, 1e-5, 'stem via im2col')
+
+
+def test_se_backward():
+    from ood_object_detection_amd import _lib
+    ops = _ops()
+    B, H, W, C, R = 3, 6, 5, 48, 4
+    a = _rnd(9, 'a', (B, C, H, W)).requires_grad_()
+    w1, b1 = _rnd(9, 'w1', (R, C, 1, 1), 0.3).requires_grad_(), _rnd(9, 'b1', (R,), 0.1).requires_grad_()
+    w2, b2 = _rnd(9, 'w2', (C, R, 1, 1), 0.3).requires_grad_(), _rnd(9, 'b2', (C,), 0.1).requires_grad_()
+    s = a.mean((2, 3), keepdim=True)
+    r = F.conv2d(s, w1, b1)
+    r = r * torch.sigmoid(r)
+    gate = torch.sigmoid(F.conv2d(r, w2, b2))
+    y = a * gate
+    dy = _rnd(9, 'dy', tuple(y.shape))
+    ga, gw1, gb1, gw2, gb2 = torch.autograd.grad(y, (a, w1, b1, w2, b2), dy)
+    an = a.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    dyn = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    pool = ops.col_reduce(0, an, per_image=True)
+    g = gate.detach().reshape(B, C).to(DEV).contiguous()
+    dgate = ops.col_reduce(1, dyn, an, per_image=True)
+    ds, pg = ops.new(B, C), ops.new(B, 2 * R * C + R + C)
+    W1 = w1.detach().reshape(R, C).contiguous().to(DEV)
+    W2t = w2.detach().reshape(C, R).t().contiguous().to(DEV)
+    _lib.check(ops.lib.effdet_train_se_bwd(ops.st(), pool.data_ptr(), H * W, g.data_ptr(), dgate.data_ptr(), W1.data_ptr(),
+                                           b1.detach().to(DEV).data_ptr(), W2t.data_ptr(), ds.data_ptr(), pg.data_ptr(), B, C, R), 'se_bwd')
+    da = ops.ew(5, dyn, v=(g, ds, None, None), s=(1.0 / (H * W), 0, 0, 0), hw=H * W)
+    _close(da.permute(0, 3, 1, 2), ga, 1e-5, 'SE d input')
+    tot = ops.reduce_rows(pg)
+    _close(tot[:R * C].reshape(R, C, 1, 1), gw1, 1e-5, 'SE d conv_reduce.weight')
+    _close(tot[R * C:R * C + R], gb1, 1e-5, 'SE d conv_reduce.bias')
+    _close(tot[R * C + R:2 * R * C + R].reshape(R, C).t().reshape(C, R, 1, 1), gw2, 1e-5, 'SE d conv_expand.weight')
+    _close(tot[2 * R * C + R:], gb2, 1e-5, 'SE d conv_expand.bias')
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# whole network
+# ------------------------------------------------------------------------------------------------------------------
+def _train_setup(size=256, B=3, C=20, seed=21):
+    from _models import seeded_model
+    model, cfg, nodes, sd = seeded_model('tf_efficientdet_d0', size, C, seed=seed)
+    x = torch.from_numpy(seeded_array(seed, 'input', (B, 3, size, size)))
+    return model, cfg, nodes, sd, x
+
+
+def _targets(cfg, size, B, C, seed):
+    """synthetic per-level label tensors in the reference layout (cls [B,H,W,A] int64, box [B,H,W,4A])"""
+    rs = np.random.RandomState(seed)
+    cls_t, box_t = [], []
+    for l in range(cfg.num_levels):
+        s = size // (2 ** (cfg.min_level + l))
+        cls_t.append(torch.from_numpy(rs.choice([-2, -1, -1, -1, -1, -1, 0, 3, C - 1], size=(B, s, s, 9)).astype(np.int64)))
+        t = rs.normal(0, 0.2, (B, s, s, 36)).astype(np.float32)
+        t[rs.uniform(size=t.shape) < 0.7] = 0.0
+        box_t.append(torch.from_numpy(t))
+    return cls_t, box_t, torch.tensor([7.0, 4.0, 9.0][:B])
+
+
+def _oracle_step(sd, cfg, nodes, x, cls_t, box_t, npos, C, batch_stats=True):
+    from oracle import model as om
+    from oracle import train as ot
+    sd = {k: (v.clone().float().requires_grad_() if v.is_floating_point() and 'running' not in k else v.clone()) for k, v in sd.items()}
+    om.BN_BATCH_STATS_PREFIXES = ('fpn.', 'class_net.', 'box_net.') if batch_stats else ()
+    try:
+        info = om.backbone_feature_info(cfg.backbone_name)
+        feats = om.backbone_forward(sd, cfg.backbone_name, x, pad_type=cfg.pad_type)
+        activs = om.bifpn_forward(sd, cfg, feats, nodes, info)
+        cls_o, box_o = om.head_forward(sd, cfg, activs, 'class_net.'), om.head_forward(sd, cfg, activs, 'box_net.')
+    finally:
+        om.BN_BATCH_STATS_PREFIXES = ()
+    total, cl, bl = ot.detection_loss(cls_o, box_o, cls_t, box_t, npos, C, 0.15, 0.1, 50.0)
+    names = [k for k, v in sd.items() if torch.is_tensor(v) and v.requires_grad]
+    grads = torch.autograd.grad(total, [sd[k] for k in names], allow_unused=True)
+    return (total.detach(), cl.detach(), bl.detach()), dict(zip(names, grads)), cls_o, box_o, sd
+
+
+@pytest.mark.parametrize('batch_stats', [True, False])
+def test_pretrain_step_gradients_match_oracle_autograd(batch_stats):
+    """pretrain.py:226-236: forward (backbone BN eval, BiFPN / head BN in batch-statistics mode), loss, backward; every
+    parameter gradient against torch autograd through the CPU oracle.  Tolerance: 2e-3 of the largest gradient entry of
+    the tensor (fp32 on both sides; the seeded network amplifies rounding ~100x through its depth)."""
+    from ood_object_detection_amd.effdet.loss import DetectionLoss
+    size, B, C = 256, 3, 20
+    model, cfg, nodes, sd, x = _train_setup(size, B, C)
+    cls_t, box_t, npos = _targets(cfg, size, B, C, 5)
+    (ref_total, ref_cl, ref_bl), ref_g, cls_ref, box_ref, sd_after = _oracle_step(sd, cfg, nodes, x, cls_t, box_t, npos, C, batch_stats)
+
+    model = model.to(DEV).float()
+    model.train()
+    if batch_stats:
+        model.backbone.apply(lambda m: m.eval() if isinstance(m, torch.nn.BatchNorm2d) else None)       # pretrain.py:168-176
+    else:
+        model.apply(lambda m: m.eval() if isinstance(m, torch.nn.BatchNorm2d) else None)                 # --freeze_bn
+    cfg.alpha, cfg.box_loss_weight = 0.15, 50.0                                                          # pretrain.py:60-62
+    loss_fn = DetectionLoss(cfg)
+    feats = model(x.to(DEV), mode='bb')
+    cls_o, box_o = model(feats, mode='fpn_and_head')
+    for a, r in zip(list(cls_o) + list(box_o), list(cls_ref) + list(box_ref)):
+        _close(a, r, 1e-3, 'head output (training forward)')
+    total, cl, bl = loss_fn(cls_o, box_o, [t.to(DEV) for t in cls_t], [t.to(DEV) for t in box_t], npos.to(DEV))
+    assert abs(total.item() - float(ref_total)) <= 1e-4 * abs(float(ref_total)), (total.item(), float(ref_total))
+    total.backward()
+    torch.cuda.synchronize()
+    # a tensor's gradient is compared relative to its own largest entry, with a floor of 1e-5 of the largest gradient
+    # entry of the whole model: conv biases that feed a batch-statistics BN have an analytically ZERO gradient (both
+    # sides hold rounding noise ~1e-9 there)
+    gmax = max(float(r.abs().max()) for r in ref_g.values() if r is not None)
+    rows, missing = [], []
+    for name, p in model.named_parameters():
+        r = ref_g.get(name)
+        if r is None:
+            continue
+        if p.grad is None:
+            missing.append(name)
+            continue
+        floor = 1e-5 * gmax
+        if batch_stats and 'predict' not in name and (name.endswith('conv_pw.bias') or name.endswith('conv.conv.bias')):
+            floor = 1e-4 * gmax          # bias in front of a batch-statistics BN: d/d bias = sum(d conv) == 0 analytically
+        err = float((p.grad.cpu() - r).abs().max()) / max(float(r.abs().max()), floor)
+        rows.append((err, name, float(r.abs().max())))
+    rows.sort(reverse=True)
+    assert not missing, 'no gradient for %s' % missing[:5]
+    assert rows[0][0] <= 2e-3, 'gmax %.3e; worst relative gradient errors: %s' % (gmax, rows[:8])
+    print('gradient parity: %d tensors, gmax %.3e, worst %s' % (len(rows), gmax, rows[:3]))
+    if batch_stats:
+        # running statistics were updated like nn.BatchNorm2d(momentum=.01) does
+        k = 'fpn.cell.0.fnode.0.after_combine.conv.bn.running_var'
+        _close(model.state_dict()[k], sd_after[k], 1e-4, 'running_var update')
+        k = 'class_net.bn_rep.1.2.bn.running_mean'
+        _close(model.state_dict()[k], sd_after[k], 1e-4, 'running_mean update')
+
+
+def test_full_net_autograd_and_reproducible():
+    """mode='full_net' in training mode is differentiable too, and two identical steps give bit-identical gradients."""
+    from ood_object_detection_amd.effdet.loss import DetectionLoss
+    size, B, C = 128, 2, 20
+    model, cfg, nodes, sd, x = _train_setup(size, B, C, seed=23)
+    cls_t, box_t, npos = _targets(cfg, size, B, C, 6)
+    model = model.to(DEV).float().train()
+    model.backbone.apply(lambda m: m.eval() if isinstance(m, torch.nn.BatchNorm2d) else None)
+    loss_fn = DetectionLoss(cfg)
+    runs = []
+    for _ in range(2):
+        model.load_state_dict(sd)
+        model.zero_grad(set_to_none=True)
+        cls_o, box_o = model(x.to(DEV))
+        total, _, _ = loss_fn(cls_o, box_o, [t.to(DEV) for t in cls_t], [t.to(DEV) for t in box_t], npos.to(DEV))
+        total.backward()
+        runs.append({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert len(runs[0]) == len(list(model.parameters()))
+    for n in runs[0]:
+        assert torch.equal(runs[0][n], runs[1][n]), n
+    # inference path untouched by the training hooks: eval + no_grad goes through the fused engine
+    model.eval()
+    with torch.no_grad():
+        c2, _ = model(x.to(DEV))
+    assert not c2[0].requires_grad
+
+
+def test_training_path_rejects_unsupported():
+    model, cfg, nodes, sd, x = _train_setup(128, 2, 20, seed=23)
+    model = model.to(DEV).float().train()               # backbone BN left in training mode: not built, must say so
+    with pytest.raises(NotImplementedError):
+        model(x.to(DEV), mode='bb')
+    with pytest.raises(RuntimeError):
+        model.to(torch.bfloat16)(x.to(DEV).to(torch.bfloat16), mode='bb')
