@@ -1,0 +1,86 @@
+"""One iteration of the reference's pretrain loop (pretrain.py:220-276) on the HIP path.
+
+    meta_optimizer.zero_grad()
+    qry_imgs = (qry_imgs.float() - imagenet_mean) / imagenet_std          pretrain.py:226   (uint8 input: effdet_normalize_u8)
+    feats = model(qry_imgs, mode='bb')                                    :229
+    class_out, box_out = model(feats, mode='fpn_and_head')                :232
+    qry_loss, ... = loss_fn(class_out, box_out, cls_anchors, bbox_anchors, num_positives)   :233
+    qry_loss.backward()                                                   :236
+    clip_grad_norm_(model.parameters(), 10.); meta_optimizer.step()       :272-276
+
+Data-parallel training (BASELINE config 5) adds ONE collective: the flat float32 gradient buffer of `FlatAdam`
+(15.6 MB for d0) is all-reduced (mean) over RCCL between backward and the optimizer step - one large message, the
+shape a point-to-point xGMI fabric wants.  BN stays per replica (no SyncBN in the reference).  Defaults mirror the
+script's flags: Adam lr 1e-3, alpha .15, box weight 50, delta .1 (pretrain.py:57-62), backbone BN frozen in eval mode
+(`freeze_bb_bn`, :168-176), BiFPN / head BN in batch-statistics mode.
+"""
+import torch
+import torch.nn as nn
+
+from .optim import FlatAdam
+
+
+def set_bn_eval(module):
+    """pretrain.py:169-171"""
+    if isinstance(module, nn.modules.batchnorm._BatchNorm):
+        module.eval()
+
+
+class PretrainStep(object):
+    def __init__(self, model, lr=1e-3, max_grad_norm=10.0, alpha=0.15, box_loss_weight=50.0, freeze_bn=False,
+                 labeler=True):
+        from .effdet.anchors import Anchors, AnchorLabeler
+        from .effdet.config import set_config_writeable
+        from .effdet.loss import DetectionLoss
+        self.model = model
+        model.train()
+        if freeze_bn:
+            model.apply(set_bn_eval)
+        else:
+            model.backbone.apply(set_bn_eval)
+        cfg = model.config
+        set_config_writeable(cfg)
+        cfg.alpha, cfg.box_loss_weight = alpha, box_loss_weight
+        self.loss_fn = DetectionLoss(cfg)
+        self.opt = FlatAdam(model.parameters(), lr=lr, max_grad_norm=max_grad_norm)
+        self.anchors = Anchors.from_config(cfg).to(model.backbone.conv_stem.weight.device)
+        self.labeler = AnchorLabeler(self.anchors, cfg.num_classes, match_threshold=0.5) if labeler else None
+        self.num_levels = cfg.num_levels
+        self.world = 1
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            self.world = dist.get_world_size()
+        self.last_allreduce_ms = 0.0
+
+    def targets(self, target):
+        """target: {'bbox': [per-image [M,4] yxyx], 'cls': [per-image [M]]} (labelled on the GPU, effdet/anchors.py:384-438)
+        or the loader's pre-labelled {'label_cls_l', 'label_bbox_l', 'label_num_positives'} (effdet/bench.py:127-133)."""
+        if 'label_num_positives' in target:
+            return ([target['label_cls_%d' % l] for l in range(self.num_levels)],
+                    [target['label_bbox_%d' % l] for l in range(self.num_levels)], target['label_num_positives'])
+        if self.labeler is None:
+            raise ValueError('pre-labelled targets or labeler=True needed')
+        return self.labeler.batch_label_anchors(target['bbox'], target['cls'])
+
+    def __call__(self, x, target, time_allreduce=False):
+        model, opt = self.model, self.opt
+        opt.zero_grad()
+        cls_t, box_t, npos = self.targets(target)
+        feats = model(x, mode='bb')
+        class_out, box_out = model(feats, mode='fpn_and_head')
+        loss, class_loss, box_loss = self.loss_fn(class_out, box_out, cls_t, box_t, npos)
+        loss.backward()
+        if self.world > 1:
+            import torch.distributed as dist
+            if time_allreduce:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            dist.all_reduce(opt.flat_grad, op=dist.ReduceOp.SUM)
+            opt.flat_grad.div_(self.world)
+            if time_allreduce:
+                e1.record()
+                e1.synchronize()
+                self.last_allreduce_ms = e0.elapsed_time(e1)
+        norm = opt.step()
+        model.invalidate()                      # the inference engine's packed weights are stale now
+        return {'loss': loss.detach(), 'class_loss': class_loss, 'box_loss': box_loss, 'grad_norm': norm}

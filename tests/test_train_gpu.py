@@ -337,3 +337,56 @@ def test_training_path_rejects_unsupported():
         model(x.to(DEV), mode='bb')
     with pytest.raises(RuntimeError):
         model.to(torch.bfloat16)(x.to(DEV).to(torch.bfloat16), mode='bb')
+
+
+def test_pretrain_step_updates_like_clip_adam():
+    """One PretrainStep (pretrain.py:220-276) = forward, loss, backward, clip_grad_norm_(10) + Adam(1e-3): loss, pre-clip
+    gradient norm and the updated weights against torch.optim.Adam on the oracle's autograd gradients."""
+    from ood_object_detection_amd.pretrain import PretrainStep
+    size, B, C = 256, 3, 20
+    model, cfg, nodes, sd, x = _train_setup(size, B, C)
+    cls_t, box_t, npos = _targets(cfg, size, B, C, 5)
+    (ref_total, _, _), ref_g, _, _, _ = _oracle_step(sd, cfg, nodes, x, cls_t, box_t, npos, C, True)
+    names = [n for n, _ in model.named_parameters()]
+    ref_p = [sd[n].clone().float().requires_grad_() for n in names]
+    for p, n in zip(ref_p, names):
+        p.grad = ref_g[n].clone()
+    ref_norm = torch.nn.utils.clip_grad_norm_(ref_p, 10.0)
+    torch.optim.Adam(ref_p, lr=1e-3).step()
+
+    model = model.to(DEV).float()
+    step = PretrainStep(model, labeler=False)
+    target = {'label_num_positives': npos.to(DEV)}
+    for l in range(5):
+        target['label_cls_%d' % l], target['label_bbox_%d' % l] = cls_t[l].to(DEV), box_t[l].to(DEV)
+    out = step(x.to(DEV), target)
+    assert abs(out['loss'].item() - float(ref_total)) <= 1e-4 * abs(float(ref_total))
+    assert abs(out['grad_norm'].item() - float(ref_norm)) <= 1e-3 * float(ref_norm), (out['grad_norm'].item(), float(ref_norm))
+    # the first Adam step moves every weight by lr * g / (|g| + eps): only entries whose gradient is clearly non-zero are
+    # comparable (a 1e-9 rounding-noise gradient still moves its weight by the full 1e-3 in either direction)
+    gmax = max(float(g.abs().max()) for g in ref_g.values())
+    worst = 0.0
+    for (n, p), r in zip(model.named_parameters(), ref_p):
+        mask = ref_g[n].abs() > 1e-4 * gmax
+        if mask.any():
+            worst = max(worst, float((p.detach().cpu() - r.detach())[mask].abs().max()))
+    assert worst <= 2e-5, worst
+    # a second step runs on the updated weights (parameters alias FlatAdam's flat buffer; the engine reads them live)
+    out2 = step(x.to(DEV), target)
+    assert torch.isfinite(out2['loss']) and out2['loss'].item() != out['loss'].item()
+
+
+def test_pretrain_step_labels_on_device_and_uint8_input():
+    """raw uint8 batch + ground-truth boxes: loader normalisation, anchor labelling, forward, loss, backward, update"""
+    from ood_object_detection_amd.pretrain import PretrainStep
+    size, B, C = 128, 2, 20
+    model, cfg, nodes, sd, _ = _train_setup(size, B, C, seed=23)
+    model = model.to(DEV).float()
+    step = PretrainStep(model)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(0, 256, (B, 3, size, size), generator=g, dtype=torch.uint8).to(DEV)
+    boxes = [torch.tensor([[10., 12., 70., 90.], [40., 30., 120., 100.]]), torch.tensor([[5., 5., 60., 50.]])]
+    cls = [torch.tensor([3, 7]), torch.tensor([1])]
+    losses = [step(x, {'bbox': [b.to(DEV) for b in boxes], 'cls': [c.to(DEV) for c in cls]})['loss'].item() for _ in range(6)]
+    assert all(math.isfinite(v) for v in losses)
+    assert losses[-1] < losses[0], losses                      # the same batch six times: the loss goes down

@@ -1,0 +1,107 @@
+#!/usr/bin/env python
+"""BASELINE config 5: pretrain.py's training iteration on tf_efficientdet_d0 at 640x640, float32, B images per GPU,
+synthetic ground truth (M ~ U{1..20} boxes per image, min side 16 px, classes U{1..C}), labels assigned on
+the GPU, DDP = one RCCL all-reduce of the flat gradient buffer per step.
+
+    python tools/pretrain_bench.py --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/pretrain_bench.py --gpus N
+
+Rank 0 prints one JSON line: steps/s, images/s (whole job), ms per step (max over ranks), all-reduce ms."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+
+def synthetic_targets(B, size, C, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    boxes, cls = [], []
+    for _ in range(B):
+        m = int(torch.randint(1, 21, (1,), generator=g))
+        y0 = torch.rand(m, generator=g) * (size - 16)
+        x0 = torch.rand(m, generator=g) * (size - 16)
+        h = 16 + torch.rand(m, generator=g) * (size - 16 - y0)
+        w = 16 + torch.rand(m, generator=g) * (size - 16 - x0)
+        boxes.append(torch.stack([y0, x0, y0 + h, x0 + w], 1).to(dev))
+        cls.append(torch.randint(1, C + 1, (m,), generator=g).to(dev))
+    return {'bbox': boxes, 'cls': cls}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--image', type=int, default=640)
+    ap.add_argument('--classes', type=int, default=90)
+    ap.add_argument('--model', default='tf_efficientdet_d0')
+    args = ap.parse_args()
+    rank, local_rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+    if not torch.cuda.is_available():
+        raise SystemExit('needs an MI355X: the product path has no CPU fallback')
+    backend = os.environ.get('EFFDET_DIST_BACKEND', 'nccl')
+    dev = torch.device('cuda', local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend, rank=rank, world_size=world, **({'device_id': dev} if backend == 'nccl' else {}))
+    from bench import build_model
+    from ood_object_detection_amd.pretrain import PretrainStep
+    model = build_model(args.model, args.image, args.classes).to(dev).float()
+    with torch.no_grad():
+        model.class_net.predict.conv_pw.bias.fill_(-4.59511985)          # reference init (-log(99)), efficientdet.py:513
+    step = PretrainStep(model)
+    B = args.batch
+    x = torch.randint(0, 256, (B, 3, args.image, args.image), dtype=torch.uint8, device=dev,
+                      generator=torch.Generator(device=dev).manual_seed(100 + rank))
+    target = synthetic_targets(B, args.image, args.classes, 7 + rank, dev)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    losses = []
+    for _ in range(args.warmup):
+        losses.append(step(x, target)['loss'].item())
+    barrier()
+    ar = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(x, target, time_allreduce=world > 1)
+        ar += step.last_allreduce_ms
+    barrier()
+    elapsed = time.perf_counter() - t0
+    losses.append(out['loss'].item())
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'pretrain steps/sec, %s %dpx float32 (forward + loss + backward + grad all-reduce + clip + Adam)' % (args.model, args.image),
+            'value': round(args.steps / elapsed, 3), 'unit': 'steps/sec', 'images_per_sec': round(world * B * args.steps / elapsed, 2),
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 2),
+            'allreduce_ms_per_step': round(ar / max(args.steps, 1), 3), 'allreduce_bytes': int(step.opt.flat_grad.numel() * 4),
+            'higher_is_better': True, 'scaling': 'weak', 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s %dx%d batch=%d/GPU C=%d pretrain step, labels assigned on the GPU' % (
+                args.model, args.image, args.image, B, args.classes), 'global_batch': world * B,
+                'parallelism': 'dp%d, one flat-gradient all-reduce per step' % world},
+            'loss_first_last': [round(losses[0], 4), round(losses[-1], 4)],
+            'peak_mem_GB': round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
