@@ -161,19 +161,37 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
 // out[g][l] (+)= sum_s in[g][s][l] in index order
 struct ReduceMidArgs { const float* in; float* out; long long L; int G, S, accumulate; };
 __global__ __launch_bounds__(256) void reduce_mid_kernel(ReduceMidArgs p) {
-    const long long l = (long long)blockIdx.x * 256 + threadIdx.x;
+    // 16 consecutive l per workgroup x 16 lanes over s: lane j sums s = j, j+16, ... in order, then the 16 lane sums are
+    // added in lane order - a fixed association, so the result is bitwise reproducible
+    __shared__ float sm[16][17];
+    const int li = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const long long l = (long long)blockIdx.x * 16 + li;
     const int gi = blockIdx.y;
-    if (l >= p.L) return;
-    const float* src = p.in + (long long)gi * p.S * p.L + l;
     float s = 0.f;
-    for (int i = 0; i < p.S; ++i) s += src[(long long)i * p.L];
-    float* dst = p.out + (long long)gi * p.L + l;
-    *dst = p.accumulate ? *dst + s : s;
+    if (l < p.L) {
+        const float* src = p.in + (long long)gi * p.S * p.L + l;
+        int i = sl;
+        for (; i + 48 < p.S; i += 64) {
+            const float a0 = src[(long long)i * p.L], a1 = src[(long long)(i + 16) * p.L];
+            const float a2 = src[(long long)(i + 32) * p.L], a3 = src[(long long)(i + 48) * p.L];
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; i < p.S; i += 16) s += src[(long long)i * p.L];
+    }
+    sm[sl][li] = s;
+    __syncthreads();
+    if (sl == 0 && l < p.L) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += sm[j][li];
+        float* dst = p.out + (long long)gi * p.L + l;
+        *dst = p.accumulate ? *dst + t : t;
+    }
 }
 
 int launch_reduce_mid(hipStream_t st, const float* in, int G, int S, long long L, float* out, int accumulate) {
     ReduceMidArgs a{in, out, L, G, S, accumulate};
-    const long long blocks = (L + 255) / 256;
+    const long long blocks = (L + 15) / 16;
     if (blocks > 0x7fffffffLL || G > 65535) return EFFDET_EINVAL;
     hipLaunchKernelGGL(reduce_mid_kernel, dim3((unsigned)blocks, (unsigned)G), dim3(256), 0, st, a);
     return effdet_check_launch();
@@ -540,7 +558,7 @@ extern "C" int effdet_train_gemm_nt(void* stream, const float* A, long long a_rp
 
 static int tn_slices(long long M, int N, int K) {
     const long long tiles = (long long)((N + 31) / 32) * ((K + 1 + 63) / 64);
-    long long S = (2048 + tiles - 1) / tiles;                     // aim at >= 2048 workgroups
+    long long S = (1024 + tiles - 1) / tiles;                     // aim at >= 1024 workgroups
     const long long by_rows = (M + 255) / 256;                    // at least 256 rows per slice
     if (S > by_rows) S = by_rows;
     const long long cap = (16LL << 20) / ((long long)N * (K + 1)); // <= 16 M floats of partials
@@ -606,7 +624,7 @@ extern "C" int effdet_train_dwconv_bwd_dx(void* stream, const float* dY, const f
 
 static long long dw_chunks(long long npx, int C, long long* ppc) {
     const int cgroups = (C + 63) / 64;
-    long long chunks = (2048 + cgroups - 1) / cgroups;            // aim at >= 2048 workgroups
+    long long chunks = (1024 + cgroups - 1) / cgroups;            // aim at >= 1024 workgroups
     long long per = (npx + chunks - 1) / chunks;
     if (per < 64) per = 64;
     per = (per + 3) / 4 * 4;

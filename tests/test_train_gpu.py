@@ -290,6 +290,10 @@ def test_pretrain_step_gradients_match_oracle_autograd(batch_stats):
         if batch_stats and 'predict' not in name and (name.endswith('conv_pw.bias') or name.endswith('conv.conv.bias')):
             floor = 1e-4 * gmax          # bias in front of a batch-statistics BN: d/d bias = sum(d conv) == 0 analytically
         err = float((p.grad.cpu() - r).abs().max()) / max(float(r.abs().max()), floor)
+        if name.endswith('edge_weights'):
+            # d/d w_j = nw_k (S_j - S_k) / den, S_i = <d fused, x_i>: a difference of two nearly equal dot products, which
+            # amplifies the ~1e-5 relative error the incoming gradient already carries; checked to 1e-2 instead of 2e-3
+            err *= 0.2
         rows.append((err, name, float(r.abs().max())))
     rows.sort(reverse=True)
     assert not missing, 'no gradient for %s' % missing[:5]
