@@ -1,4 +1,5 @@
-/* libeffdet_hip.so - C ABI of the MI355X (gfx950) EfficientDet inference + OOD-scoring hot path.
+/* libeffdet_hip.so - C ABI of the MI355X (gfx950) EfficientDet inference + OOD-scoring hot path (and of the
+ * pretrain step's loss / backward / optimizer operators).
  *
  * The reference (DavidPetrus/ood_object_detection, a fork of rwightman/efficientdet-pytorch 0.2.3) is
  * pure Python with no FFI layer: its "operator API" for this path is a handful of Python callables and

@@ -174,8 +174,8 @@ class DetBenchPredict(nn.Module):
 
 class DetBenchTrain(nn.Module):
     """Training bench (effdet/bench.py:106-145): forward + anchor labelling + detection loss, all on HIP.
-    `output['loss']` carries gradients w.r.t. the head outputs only: the backward pass through the network
-    (pretrain.py:236) is not built yet (DESIGN.md 'next'), so `loss.backward()` does not reach the weights."""
+    In training mode (`bench.train()`, backbone BN put in eval mode as pretrain.py:168-176 does) `self.model(x)` is the
+    differentiable float32 forward of train_engine.py and `output['loss'].backward()` fills every parameter's `.grad`."""
 
     def __init__(self, model, create_labeler=True):
         super().__init__()

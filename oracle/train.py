@@ -1,5 +1,9 @@
 """ORACLE (test infrastructure only - never imported by the product path).
 
+`detection_loss` (below) restates the fork's loss_fn (effdet/loss.py:224-298) in differentiable torch ops - pinned
+against the fixture the reference's own loss_fn produced (tests/golden/loss.npz) - so that, with oracle/model.py in
+training-BN mode, torch autograd on the CPU is the checker for the HIP backward pass.
+
 Restatement of the optimizer half of the reference's pretrain step (pretrain.py:272-276):
 `torch.nn.utils.clip_grad_norm_(model.parameters(), 10.)` then `torch.optim.Adam(...).step()` (pretrain.py:179-185,
 lr FLAGS.meta_lr = 1e-3, default betas / eps).  Pinned in tests/test_oracle_golden.py against torch's own
