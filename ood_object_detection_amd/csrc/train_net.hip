@@ -202,7 +202,7 @@ int launch_reduce_mid(hipStream_t st, const float* in, int G, int S, long long L
 // ------------------------------------------------------------------------------------------------------------
 struct DwBwdArgs {
     const float* dY; const float* X; const float* taps; float* dX; float* partial;
-    int B, H, W, C, k, stride, Ho, Wo, pad_t, pad_l; long long px_per_chunk;
+    int B, H, W, C, k, stride, Ho, Wo, pad_t, pad_l; long long segs_per_chunk; int seg;
 };
 
 // dX[b,iy,ix,c] = sum_taps dY[b,(iy+pad-ky)/s,(ix+pad-kx)/s,c] * w[ky,kx,c]   (4 channels per thread)
@@ -235,8 +235,10 @@ __global__ __launch_bounds__(256) void dw_bwd_dx_kernel(DwBwdArgs p) {
     *reinterpret_cast<f32x4*>(p.dX + (((long long)b * p.H + iy) * p.W + ix) * p.C + c) = acc;
 }
 
-// partial[chunk][k*k+1][C]: taps gradient + sum of dY.  block = 64 channels x 4 pixel lanes.
-template <int KK>
+// partial[chunk][k*k+1][C]: taps gradient + sum of dY.  block = 64 channels x 4 lanes; a lane walks row segments of
+// `seg` output pixels with a k x k register window of X that slides by the stride: S*k loads per output pixel instead
+// of k*k (the kernel is load-issue bound).
+template <int KK, int S>
 __global__ __launch_bounds__(256) void dw_bwd_dw_kernel(DwBwdArgs p) {
     constexpr int T = KK * KK;
     __shared__ float sm[4][T + 1][64];
@@ -246,28 +248,54 @@ __global__ __launch_bounds__(256) void dw_bwd_dw_kernel(DwBwdArgs p) {
     float acc[T + 1];
 #pragma unroll
     for (int t = 0; t <= T; ++t) acc[t] = 0.f;
-    const long long npx = (long long)p.B * p.Ho * p.Wo;
-    const long long pb = (long long)blockIdx.x * p.px_per_chunk;
-    long long pe = pb + p.px_per_chunk;
-    if (pe > npx) pe = npx;
+    const int segs_x = (p.Wo + p.seg - 1) / p.seg;
+    const long long nseg = (long long)p.B * p.Ho * segs_x;
+    const long long sb = (long long)blockIdx.x * p.segs_per_chunk;
+    long long se = sb + p.segs_per_chunk;
+    if (se > nseg) se = nseg;
     if (cv) {
-        for (long long q = pb + pl; q < pe; q += 4) {
-            const int ox = (int)(q % p.Wo);
-            const long long r = q / p.Wo;
+        for (long long sg = sb + pl; sg < se; sg += 4) {
+            const int sx = (int)(sg % segs_x);
+            const long long r = sg / segs_x;
             const int oy = (int)(r % p.Ho);
-            const int b = (int)(r / p.Ho);
-            const float d = p.dY[q * p.C + c];
-            acc[T] += d;
+            const long long b = r / p.Ho;
+            const int x0 = sx * p.seg;
+            const int x1 = x0 + p.seg < p.Wo ? x0 + p.seg : p.Wo;
+            const float* Xb = p.X + b * p.H * p.W * p.C + c;
+            const float* dYr = p.dY + (b * p.Ho + oy) * p.Wo * p.C + c;
+            long long rowoff[KK];
+            bool rv[KK];
 #pragma unroll
             for (int ky = 0; ky < KK; ++ky) {
-                const int iy = oy * p.stride + ky - p.pad_t;
-                if (iy < 0 || iy >= p.H) continue;
+                const int iy = oy * S + ky - p.pad_t;
+                rv[ky] = iy >= 0 && iy < p.H;
+                rowoff[ky] = (long long)(rv[ky] ? iy : 0) * p.W * p.C;
+            }
+            float xw[KK][KK];
 #pragma unroll
-                for (int kx = 0; kx < KK; ++kx) {
-                    const int ix = ox * p.stride + kx - p.pad_l;
-                    if (ix < 0 || ix >= p.W) continue;
-                    acc[ky * KK + kx] += d * p.X[(((long long)b * p.H + iy) * p.W + ix) * p.C + c];
+            for (int ky = 0; ky < KK; ++ky)
+#pragma unroll
+                for (int kx = S; kx < KK; ++kx) {
+                    const int ix = x0 * S + (kx - S) - p.pad_l;
+                    xw[ky][kx] = (rv[ky] && ix >= 0 && ix < p.W) ? Xb[rowoff[ky] + (long long)ix * p.C] : 0.f;
                 }
+            for (int ox = x0; ox < x1; ++ox) {
+#pragma unroll
+                for (int ky = 0; ky < KK; ++ky) {
+#pragma unroll
+                    for (int kx = 0; kx < KK - S; ++kx) xw[ky][kx] = xw[ky][kx + S];
+#pragma unroll
+                    for (int kx = KK - S; kx < KK; ++kx) {
+                        const int ix = ox * S + kx - p.pad_l;
+                        xw[ky][kx] = (rv[ky] && ix >= 0 && ix < p.W) ? Xb[rowoff[ky] + (long long)ix * p.C] : 0.f;
+                    }
+                }
+                const float d = dYr[(long long)ox * p.C];
+                acc[T] += d;
+#pragma unroll
+                for (int ky = 0; ky < KK; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < KK; ++kx) acc[ky * KK + kx] += d * xw[ky][kx];
             }
         }
     }
@@ -614,7 +642,7 @@ extern "C" int effdet_train_dwconv_bwd_dx(void* stream, const float* dY, const f
     EFFDET_ENTER();
     DwBwdArgs a;
     if (!dY || !taps || !dX || dw_fill(a, B, H, W, C, k, stride)) return EFFDET_EINVAL;
-    a.dY = dY; a.taps = taps; a.dX = dX; a.X = nullptr; a.partial = nullptr; a.px_per_chunk = 0;
+    a.dY = dY; a.taps = taps; a.dX = dX; a.X = nullptr; a.partial = nullptr; a.segs_per_chunk = 0; a.seg = 0;
     const long long total = (long long)B * H * W * (C / 4);
     const long long blocks = (total + 255) / 256;
     if (blocks > 0x7fffffffLL) return EFFDET_EINVAL;
@@ -622,21 +650,24 @@ extern "C" int effdet_train_dwconv_bwd_dx(void* stream, const float* dY, const f
     return effdet_check_launch();
 }
 
-static long long dw_chunks(long long npx, int C, long long* ppc) {
-    const int cgroups = (C + 63) / 64;
+static long long dw_chunks(const DwBwdArgs& a, long long* spc, int* seg) {
+    *seg = a.Wo <= 48 ? a.Wo : 32;
+    const long long nseg = (long long)a.B * a.Ho * ((a.Wo + *seg - 1) / *seg);
+    const int cgroups = (a.C + 63) / 64;
     long long chunks = (1024 + cgroups - 1) / cgroups;            // aim at >= 1024 workgroups
-    long long per = (npx + chunks - 1) / chunks;
-    if (per < 64) per = 64;
+    long long per = (nseg + chunks - 1) / chunks;
+    if (per < 4) per = 4;
     per = (per + 3) / 4 * 4;
-    *ppc = per;
-    return (npx + per - 1) / per;
+    *spc = per;
+    return (nseg + per - 1) / per;
 }
 
 extern "C" long long effdet_train_dwconv_bwd_dw_workspace_floats(int B, int H, int W, int C, int k, int stride) {
     DwBwdArgs a;
     if (dw_fill(a, B, H, W, C, k, stride)) return EFFDET_EINVAL;
     long long per;
-    return dw_chunks((long long)B * a.Ho * a.Wo, C, &per) * (k * k + 1) * C;
+    int seg;
+    return dw_chunks(a, &per, &seg) * (k * k + 1) * C;
 }
 
 extern "C" int effdet_train_dwconv_bwd_dw(void* stream, const float* dY, const float* X, float* out,
@@ -645,13 +676,16 @@ extern "C" int effdet_train_dwconv_bwd_dw(void* stream, const float* dY, const f
     DwBwdArgs a;
     if (!dY || !X || !out || !workspace || dw_fill(a, B, H, W, C, k, stride)) return EFFDET_EINVAL;
     long long per;
-    const long long chunks = dw_chunks((long long)B * a.Ho * a.Wo, C, &per);
+    int seg;
+    const long long chunks = dw_chunks(a, &per, &seg);
     if (workspace_floats < chunks * (k * k + 1) * C || chunks > 0x7fffffffLL) return EFFDET_EINVAL;
-    a.dY = dY; a.X = X; a.taps = nullptr; a.dX = nullptr; a.partial = workspace; a.px_per_chunk = per;
+    a.dY = dY; a.X = X; a.taps = nullptr; a.dX = nullptr; a.partial = workspace; a.segs_per_chunk = per; a.seg = seg;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)chunks, (unsigned)((C + 63) / 64));
-    if (k == 3) hipLaunchKernelGGL(dw_bwd_dw_kernel<3>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(dw_bwd_dw_kernel<5>, grid, dim3(256), 0, st, a);
+    if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_bwd_dw_kernel<3, 1>), grid, dim3(256), 0, st, a);
+    else if (k == 3) hipLaunchKernelGGL((dw_bwd_dw_kernel<3, 2>), grid, dim3(256), 0, st, a);
+    else if (stride == 1) hipLaunchKernelGGL((dw_bwd_dw_kernel<5, 1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((dw_bwd_dw_kernel<5, 2>), grid, dim3(256), 0, st, a);
     int rc = effdet_check_launch();
     if (rc) return rc;
     return launch_reduce_mid(st, workspace, 1, (int)chunks, (long long)(k * k + 1) * C, out, 0);

@@ -22,8 +22,10 @@ class FlatAdam(object):
                 raise RuntimeError('FlatAdam needs float32 parameters on one GPU (no CPU fallback)')
         self.lib = _lib.load()
         self.lr, self.betas, self.eps, self.max_grad_norm = float(lr), (float(betas[0]), float(betas[1])), float(eps), max_grad_norm
-        n = sum(p.numel() for p in self.params)
-        self.flat_param = torch.empty(n, dtype=torch.float32, device=dev)
+        # every parameter starts on a 64-byte boundary of the flat buffers (16-byte vector loads of the kernels that read
+        # the weights in place); the padding stays zero: zero gradient, zero moments, zero update
+        n = sum(self._padded(p.numel()) for p in self.params)
+        self.flat_param = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -34,10 +36,14 @@ class FlatAdam(object):
                 self.flat_param[off:off + k].copy_(p.reshape(-1))
                 p.data = self.flat_param[off:off + k].view(p.shape)          # parameters now alias the flat buffer
                 p.grad = self.flat_grad[off:off + k].view(p.shape)           # autograd accumulates in place
-                off += k
+                off += self._padded(k)
         self._ws = torch.empty(int(self.lib.effdet_sqnorm_workspace_floats()), dtype=torch.float32, device=dev)
         self._sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.steps = 0
+
+    @staticmethod
+    def _padded(k):
+        return (k + 15) // 16 * 16
 
     def zero_grad(self):
         self.flat_grad.zero_()

@@ -558,7 +558,14 @@ def test_flat_adam_matches_oracle():
         got = np.concatenate([q.detach().cpu().numpy().ravel() for q in params])
         assert abs(float(norm) - float(n)) < 1e-5 * max(1.0, float(n))
         assert np.abs(got - p).max() < 2e-6
-        assert np.abs(opt.exp_avg.cpu().numpy() - m).max() < 1e-6 and np.abs(opt.exp_avg_sq.cpu().numpy() - v).max() < 1e-6
+        # parameters sit on 64-byte boundaries of the flat buffers; the padding stays zero
+        off, ma, va = 0, [], []
+        for q in params:
+            ma.append(opt.exp_avg[off:off + q.numel()])
+            va.append(opt.exp_avg_sq[off:off + q.numel()])
+            assert q.data_ptr() % 64 == 0
+            off += opt._padded(q.numel())
+        assert np.abs(torch.cat(ma).cpu().numpy() - m).max() < 1e-6 and np.abs(torch.cat(va).cpu().numpy() - v).max() < 1e-6
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
