@@ -291,6 +291,23 @@ int effdet_sqnorm(void* stream, const float* g, long long n, float* workspace, f
 int effdet_adam_clip_step(void* stream, float* p, const float* g, float* m, float* v, long long n,
                           float lr, float beta1, float beta2, float eps, int step, float max_norm, const float* sqnorm);
 
+/* ---- detection evaluation (the effdet/evaluation package, driven by pretrain.py:246-252) ----------------------- */
+
+/* Per-image greedy matching (per_image_evaluation.py:377-405) + CorLoc (:143-176).  det [B,max_det,6] rows
+ * x1,y1,x2,y2,score,class (1-based) in descending score order, det_count [B]; gt_boxes [B,M,4] yxyx, gt_cls [B,M]
+ * 1-based (<= 0: padding).  tp [B,max_det]: 1 true positive, 0 false positive, -1 dropped (padding row, box with
+ * ymax <= ymin or xmax <= xmin, class out of range).  gt_count / gt_imgs / correct_imgs [num_classes] int32 are
+ * accumulated (+=): ground-truth instances, images containing the class, images whose top-scoring detection of the
+ * class is correctly localised. */
+int effdet_eval_match(void* stream, const float* det, const int* det_count, const float* gt_boxes, const long long* gt_cls,
+                      int B, int max_det, int M, int num_classes, float iou_threshold,
+                      int* tp, int* gt_count, int* gt_imgs, int* correct_imgs);
+/* VOC all-points average precision per class (metrics.py:4-90) over n accumulated detections: scores [n], classes [n]
+ * 0-based, tp [n] as above; ap [num_classes] float64, NaN for classes without ground truth.  n <= 65536. */
+long long effdet_eval_ap_workspace_bytes(int n);
+int effdet_eval_ap(void* stream, const float* scores, const int* classes, const int* tp, int n, int num_classes,
+                   const int* gt_count, double* ap, void* workspace, long long workspace_bytes);
+
 /* ---- OOD evaluation helpers -------------------------------------------- */
 
 /* Image-level OOD score out[b] = max_a(-energy[b, a]) over the per-anchor energies [B, N]. */

@@ -97,6 +97,10 @@ SIGNATURES = {
     'effdet_train_im2col_stem': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
     'effdet_train_se_bwd': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int, c_int, c_int]),
+    'effdet_eval_match': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                                  c_void_p, c_void_p, c_void_p, c_void_p]),
+    'effdet_eval_ap_workspace_bytes': (c_ll, [c_int]),
+    'effdet_eval_ap': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_ll]),
     'effdet_gather_ood': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_int, c_int, c_int,
                                   c_void_p, c_void_p]),
 }

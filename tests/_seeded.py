@@ -48,3 +48,34 @@ def seeded_array(seed, key, shape, kind='normal', scale=1.0):
     if kind == 'uniform':
         return (rs.uniform(0.0, scale, shape)).astype(np.float32)
     raise ValueError(kind)
+
+
+def eval_case(seed, n_img, C, n_det):
+    """seeded evaluation inputs shared with the tests: per image ground truth (1..5 boxes) and detections = jittered copies of
+    ground-truth boxes + random boxes + a few degenerate (invalid) ones, distinct scores (no ties), sorted descending."""
+    rs = np.random.RandomState(seed)
+    images = []
+    for _ in range(n_img):
+        m = rs.randint(0, 6)
+        y0 = rs.uniform(0, 80, m); x0 = rs.uniform(0, 80, m)
+        gt = np.stack([y0, x0, y0 + rs.uniform(8, 60, m), x0 + rs.uniform(8, 60, m)], 1).astype(np.float32).reshape(-1, 4)
+        gc = rs.randint(1, C + 1, m)
+        det, dc = [], []
+        for _k in range(n_det):
+            r = rs.uniform()
+            if m > 0 and r < 0.6:
+                j = rs.randint(0, m)
+                det.append(gt[j] + rs.normal(0, 3.0, 4).astype(np.float32))
+                dc.append(gc[j] if rs.uniform() < 0.8 else rs.randint(1, C + 1))
+            elif r < 0.95:
+                yy, xx = rs.uniform(0, 80), rs.uniform(0, 80)
+                det.append(np.array([yy, xx, yy + rs.uniform(5, 50), xx + rs.uniform(5, 50)], np.float32))
+                dc.append(rs.randint(1, C + 1))
+            else:
+                yy, xx = rs.uniform(0, 80), rs.uniform(0, 80)
+                det.append(np.array([yy, xx, yy - 1.0, xx + 5.0], np.float32))           # invalid: ymax < ymin
+                dc.append(rs.randint(1, C + 1))
+        sc = np.sort(rs.permutation(10000)[:n_det].astype(np.float32) / 10000.0)[::-1].copy()
+        images.append(dict(gt_boxes=gt, gt_classes=np.asarray(gc, np.int64), det_boxes=np.stack(det).astype(np.float32),
+                           det_scores=sc, det_classes=np.asarray(dc, np.int64)))
+    return images

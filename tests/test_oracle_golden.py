@@ -204,3 +204,19 @@ def test_detection_loss_oracle_matches_reference(golden, tag, alpha, w, ls):
     for i in range(5):
         assert np.allclose(grads[i].numpy(), g['%s_gc%d' % (tag, i)], rtol=1e-5, atol=1e-8)
         assert np.allclose(grads[5 + i].numpy(), g['%s_gb%d' % (tag, i)], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
+def test_evaluation_oracle_matches_reference(golden, tag):
+    """oracle/evaluation.py vs the reference's ObjectDetectionEvaluator (mAP, CorLoc, per class)"""
+    from _seeded import eval_case
+    from oracle import evaluation as oe
+    g = golden('evaluation')
+    seed, n_img, C, n_det = [int(v) for v in g[tag + '_meta']]
+    ims = [dict(det_boxes=im['det_boxes'], det_scores=im['det_scores'], det_classes=im['det_classes'] - 1,
+                gt_boxes=im['gt_boxes'], gt_classes=im['gt_classes'] - 1) for im in eval_case(seed, n_img, C, n_det)]
+    with np.errstate(all='ignore'):
+        r = oe.evaluate(ims, C)
+    assert abs(r['mean_ap'] - float(g[tag + '_map'])) < 1e-12 and abs(r['mean_corloc'] - float(g[tag + '_corloc'])) < 1e-12
+    assert np.allclose(r['per_class_ap'], g[tag + '_ap'], rtol=0, atol=1e-12, equal_nan=True)
+    assert np.allclose(r['per_class_corloc'], g[tag + '_cl'], rtol=0, atol=1e-12, equal_nan=True)

@@ -15,6 +15,7 @@ Fixtures written
     generate_detections.npz   anchors.generate_detections (soft path: pure reference; hard path:
                               NMS step comes from the oracle via the torchvision stub)
     loss.npz                  loss.loss_fn values and autograd gradients
+    evaluation.npz            ObjectDetectionEvaluator mAP / CorLoc on seeded detections
     labeler.npz               anchors.AnchorLabeler.batch_label_anchors
     config.npz                model_config.get_efficientdet_config + fpn_config.bifpn_config dumps
     bifpn_head.npz            EfficientDet(config) forward (reference BiFpn/HeadNet code on stub
@@ -33,7 +34,7 @@ sys.path[:0] = [os.path.join(ROOT, 'tests', 'oracle_stubs'), '/root/reference', 
 import numpy as np
 import torch
 
-from _seeded import seeded_array, seeded_tensor
+from _seeded import eval_case, seeded_array, seeded_tensor
 
 OUT = os.path.join(ROOT, 'tests', 'golden')
 torch.set_num_threads(4)
@@ -257,9 +258,31 @@ def gen_bifpn_head():
     save('bifpn_head', **out)
 
 
+def gen_evaluation():
+    """mAP / CorLoc of the reference's ObjectDetectionEvaluator (effdet/evaluation/detection_evaluator.py:96-316) the way
+    pretrain.py:246-252 drives it."""
+    np.float, np.bool, np.NAN = float, bool, np.nan      # aliases numpy >= 1.24 / 2.0 dropped; the reference predates that
+    from effdet.evaluation.detection_evaluator import ObjectDetectionEvaluator
+    out = {}
+    for tag, seed, n_img, C, n_det in (('a', 31, 10, 6, 40), ('b', 32, 3, 20, 100), ('c', 33, 1, 4, 12)):
+        cats = [{'id': i + 1, 'name': 'c%d' % i} for i in range(C)]
+        ev = ObjectDetectionEvaluator(cats, evaluate_corlocs=True)
+        for i, im in enumerate(eval_case(seed, n_img, C, n_det)):
+            ev.add_single_ground_truth_image_info(i, {'bbox': im['gt_boxes'], 'cls': im['gt_classes']})
+            ev.add_single_detected_image_info(i, {'bbox': im['det_boxes'], 'scores': im['det_scores'], 'cls': im['det_classes']})
+        with np.errstate(all='ignore'):
+            m = ev.evaluate(['c%d' % i for i in range(C)])
+        out[tag + '_meta'] = np.array([seed, n_img, C, n_det])
+        out[tag + '_map'] = np.array(m['Precision/mAP@0.5IOU'])
+        out[tag + '_corloc'] = np.array(m['Precision/meanCorLoc@0.5IOU'])
+        out[tag + '_ap'] = np.array([m['AP@0.5IOU/c%d' % i] for i in range(C)])
+        out[tag + '_cl'] = np.array([m['CorLoc@0.5IOU/c%d' % i] for i in range(C)])
+    save('evaluation', **out)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['anchors', 'post_process', 'decode', 'soft_nms', 'generate_detections', 'loss',
-                             'labeler', 'config', 'bifpn_head']
+                             'labeler', 'config', 'bifpn_head', 'evaluation']
     for w in which:
         globals()['gen_' + w]()
