@@ -62,7 +62,37 @@ class PretrainStep(object):
             raise ValueError('pre-labelled targets or labeler=True needed')
         return self.labeler.batch_label_anchors(target['bbox'], target['cls'])
 
-    def __call__(self, x, target, time_allreduce=False):
+    def detections(self, class_out, box_out):
+        """pretrain.py:238-245: _post_process + generate_detections(hard NMS, no clipping) for the whole batch.
+        -> det [B, 100, 6] (x1,y1,x2,y2,score,class 1-based, zero padded), count [B]"""
+        from .effdet.anchors import batched_detections
+        from .effdet.bench import _post_process
+        cfg = self.model.config
+        with torch.no_grad():
+            co, bo = [t.detach() for t in class_out], [t.detach() for t in box_out]
+            ct, bt, idx, cl = _post_process(co, bo, cfg.num_levels, cfg.num_classes, cfg.max_detection_points)
+            B, k = idx.shape
+            det, count, _ = batched_detections(ct.reshape(B, k), bt, self.anchors.boxes, idx, cl, None, None,
+                                               max_det_per_image=cfg.max_det_per_image, soft_nms=False)
+        return det, count
+
+    def evaluate(self, class_out, box_out, target, evaluator):
+        """pretrain.py:246-252: add the batch's detections and ground truth (target['bbox'] yxyx / target['cls'] 1-based lists)
+        to a device `ObjectDetectionEvaluator` (cleared by the caller per iteration, as the script does)."""
+        det, count = self.detections(class_out, box_out)
+        B = det.shape[0]
+        M = max(1, max(int(b.shape[0]) for b in target['bbox']))
+        gtb = torch.zeros(B, M, 4, dtype=torch.float32, device=det.device)
+        gtc = torch.full((B, M), -1, dtype=torch.int64, device=det.device)
+        for i, (b, c) in enumerate(zip(target['bbox'], target['cls'])):
+            m = int(b.shape[0])
+            if m:
+                gtb[i, :m] = b.to(det.device, torch.float32)
+                gtc[i, :m] = c.to(det.device, torch.int64)
+        evaluator.add_batch(det, count, gtb, gtc)
+        return det, count
+
+    def __call__(self, x, target, time_allreduce=False, evaluator=None):
         model, opt = self.model, self.opt
         opt.zero_grad()
         cls_t, box_t, npos = self.targets(target)
@@ -70,6 +100,8 @@ class PretrainStep(object):
         class_out, box_out = model(feats, mode='fpn_and_head')
         loss, class_loss, box_loss = self.loss_fn(class_out, box_out, cls_t, box_t, npos)
         loss.backward()
+        if evaluator is not None:
+            self.evaluate(class_out, box_out, target, evaluator)
         if self.world > 1:
             import torch.distributed as dist
             if time_allreduce:
