@@ -259,10 +259,12 @@ int effdet_train_dwconv_bwd_dw(void* stream, const float* dY, const float* X, fl
  *  0 silu(a)   1 b*silu'(a)   2 a+b   3 a*v0[c]+v1[c] (v1 optional)   4 a*v0[img,c]   5 a*v0[img,c]+v1[img,c]*s0
  *  6 v0[c]*(a - v1[c] - (b - v2[c])*v3[c])  (batch-statistics BN backward)
  *  7 (a*s0)/s3 + (b*s1)/s3 [+ (c*s2)/s3]  (FpnCombine 'fastattn', effdet/efficientdet.py:240-242)   8 a*s0
- *  9 a*s0 + b*s1 [+ c*s2] */
+ *  9 a*s0 + b*s1 [+ c*s2]
+ * sdev (optional): device float[4] that replaces s0..s3 at run time, so that a captured hipGraph of the training step
+ * sees the current BiFPN edge weights. */
 int effdet_train_ew(void* stream, int op, float* out, const float* a, const float* b, const float* c,
                     const float* v0, const float* v1, const float* v2, const float* v3,
-                    float s0, float s1, float s2, float s3, long long n, int C, long long hw);
+                    float s0, float s1, float s2, float s3, long long n, int C, long long hw, const float* sdev);
 /* Per-channel reductions over the rows of dense [G][R][C] tensors -> out [G][C]:
  * mode 0 sum a; 1 sum a*b; 2 sum (a - v[c])^2; 3 sum a*(b - v[c]). */
 long long effdet_train_col_reduce_workspace_floats(int G, long long R, int C);
@@ -290,6 +292,10 @@ long long effdet_sqnorm_workspace_floats(void);
 int effdet_sqnorm(void* stream, const float* g, long long n, float* workspace, float* out, int accumulate);
 int effdet_adam_clip_step(void* stream, float* p, const float* g, float* m, float* v, long long n,
                           float lr, float beta1, float beta2, float eps, int step, float max_norm, const float* sqnorm);
+/* The same with the two bias corrections read from device memory (bc_dev[0] = 1 - beta1^step, bc_dev[1] = sqrt(1 - beta2^step)):
+ * the launch can sit in a captured hipGraph while the host refreshes bc_dev before every replay. */
+int effdet_adam_clip_step_dev(void* stream, float* p, const float* g, float* m, float* v, long long n,
+                              float lr, float beta1, float beta2, float eps, const float* bc_dev, float max_norm, const float* sqnorm);
 
 /* ---- detection evaluation (the effdet/evaluation package, driven by pretrain.py:246-252) ----------------------- */
 

@@ -54,6 +54,8 @@ SIGNATURES = {
     'effdet_sqnorm': (c_int, [c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_int]),
     'effdet_adam_clip_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_float, c_float, c_float, c_float,
                                       c_int, c_float, c_void_p]),
+    'effdet_adam_clip_step_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_float, c_float, c_float, c_float,
+                                          c_void_p, c_float, c_void_p]),
     'effdet_ood_image_score': (c_int, [c_void_p, c_void_p, c_int, c_ll, c_void_p]),
     'effdet_auroc_counts': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'effdet_sepconv_meta': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
@@ -90,7 +92,7 @@ SIGNATURES = {
     'effdet_train_dwconv_bwd_dw': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                            c_void_p, c_ll]),
     'effdet_train_ew': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                c_float, c_float, c_float, c_float, c_ll, c_int, c_ll]),
+                                c_float, c_float, c_float, c_float, c_ll, c_int, c_ll, c_void_p]),
     'effdet_train_col_reduce_workspace_floats': (c_ll, [c_int, c_ll, c_int]),
     'effdet_train_col_reduce': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_ll, c_int, c_void_p, c_void_p, c_ll]),
     'effdet_train_spatial': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),

@@ -316,6 +316,7 @@ struct EwArgs {
     int op; float* out; const float* a; const float* b; const float* c;
     const float* v0; const float* v1; const float* v2; const float* v3;
     float s0, s1, s2, s3; long long n; int C; long long hwC;
+    const float* sdev;                         // optional device float[4] overriding s0..s3 (graph-capturable steps)
 };
 
 DEV float silu_grad(float z) { const float s = sigmoid_f(z); return s * (1.0f + z * (1.0f - s)); }
@@ -323,6 +324,7 @@ DEV float silu_grad(float z) { const float s = sigmoid_f(z); return s * (1.0f + 
 __global__ __launch_bounds__(256) void ew_kernel(EwArgs p) {
     const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= p.n) return;
+    if (p.sdev) { p.s0 = p.sdev[0]; p.s1 = p.sdev[1]; p.s2 = p.sdev[2]; p.s3 = p.sdev[3]; }
     const int ch = (int)(i % p.C);
     const f32x4 a = *reinterpret_cast<const f32x4*>(p.a + i);
     f32x4 o;
@@ -693,7 +695,7 @@ extern "C" int effdet_train_dwconv_bwd_dw(void* stream, const float* dY, const f
 
 extern "C" int effdet_train_ew(void* stream, int op, float* out, const float* a, const float* b, const float* c,
                                const float* v0, const float* v1, const float* v2, const float* v3,
-                               float s0, float s1, float s2, float s3, long long n, int C, long long hw) {
+                               float s0, float s1, float s2, float s3, long long n, int C, long long hw, const float* sdev) {
     EFFDET_ENTER();
     if (!out || !a || n <= 0 || n % 4 || C <= 0 || C % 4 || op < 0 || op > 9) return EFFDET_EINVAL;
     const bool need_b = op == 1 || op == 2 || op == 6 || op == 7 || op == 9;
@@ -702,8 +704,8 @@ extern "C" int effdet_train_ew(void* stream, int op, float* out, const float* a,
     if ((op == 5 || op == 6) && !v1) return EFFDET_EINVAL;
     if (op == 6 && (!v2 || !v3)) return EFFDET_EINVAL;
     if ((op == 4 || op == 5) && hw <= 0) return EFFDET_EINVAL;
-    if (op == 7 && s3 == 0.f) return EFFDET_EINVAL;
-    EwArgs p{op, out, a, b, c, v0, v1, v2, v3, s0, s1, s2, s3, n, C, (hw > 0 ? hw : 1) * C};
+    if (op == 7 && s3 == 0.f && !sdev) return EFFDET_EINVAL;
+    EwArgs p{op, out, a, b, c, v0, v1, v2, v3, s0, s1, s2, s3, n, C, (hw > 0 ? hw : 1) * C, sdev};
     const long long blocks = (n / 4 + 255) / 256;
     if (blocks > 0x7fffffffLL) return EFFDET_EINVAL;
     hipLaunchKernelGGL(ew_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);

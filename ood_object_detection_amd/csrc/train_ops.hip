@@ -328,6 +328,7 @@ struct AdamArgs {
     float* p; const float* g; float* m; float* v; long long n;
     float lr, beta1, beta2, eps, bc1, bc2_sqrt, max_norm;
     const float* sqnorm;                       // total squared gradient norm (all groups), or null: no clipping
+    const float* bc_dev;                       // optional device {bc1, bc2_sqrt} overriding the host values
 };
 
 // clip coefficient exactly as clip_grad_norm_: clamp(max_norm / (total_norm + 1e-6), max = 1), applied to the gradient;
@@ -338,6 +339,7 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(AdamArgs a) {
         coef = a.max_norm / (sqrtf(a.sqnorm[0]) + 1e-6f);
         coef = coef > 1.f ? 1.f : coef;
     }
+    if (a.bc_dev != nullptr) { a.bc1 = a.bc_dev[0]; a.bc2_sqrt = a.bc_dev[1]; }
     const float step_size = a.lr / a.bc1;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
         const float g = a.g[i] * coef;
@@ -371,7 +373,18 @@ extern "C" int effdet_adam_clip_step(void* stream, float* p, const float* g, flo
     EFFDET_ENTER();
     if (!p || !g || !m || !v || n <= 0 || step <= 0 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f)) return EFFDET_EINVAL;
     AdamArgs a{p, g, m, v, n, lr, beta1, beta2, eps,
-               (float)(1.0 - pow((double)beta1, step)), (float)sqrt(1.0 - pow((double)beta2, step)), max_norm, sqnorm};
+               (float)(1.0 - pow((double)beta1, step)), (float)sqrt(1.0 - pow((double)beta2, step)), max_norm, sqnorm, nullptr};
+    long long nb = (n + 255) / 256; if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(adam_clip_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return effdet_check_launch();
+}
+
+extern "C" int effdet_adam_clip_step_dev(void* stream, float* p, const float* g, float* m, float* v, long long n,
+                                         float lr, float beta1, float beta2, float eps, const float* bc_dev,
+                                         float max_norm, const float* sqnorm) {
+    EFFDET_ENTER();
+    if (!p || !g || !m || !v || !bc_dev || n <= 0 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f)) return EFFDET_EINVAL;
+    AdamArgs a{p, g, m, v, n, lr, beta1, beta2, eps, 1.f, 1.f, max_norm, sqnorm, bc_dev};
     long long nb = (n + 255) / 256; if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(adam_clip_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     return effdet_check_launch();

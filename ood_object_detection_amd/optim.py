@@ -39,6 +39,7 @@ class FlatAdam(object):
                 off += self._padded(k)
         self._ws = torch.empty(int(self.lib.effdet_sqnorm_workspace_floats()), dtype=torch.float32, device=dev)
         self._sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._bc = torch.ones(2, dtype=torch.float32, device=dev)      # device copy of Adam's bias corrections (captured steps)
         self.steps = 0
 
     @staticmethod
@@ -66,4 +67,27 @@ class FlatAdam(object):
             st, self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
             self.flat_param.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.steps,
             float(self.max_grad_norm or 0.0), self._sq.data_ptr() if self.max_grad_norm is not None else None), 'effdet_adam_clip_step')
+        return norm
+
+    # ---- hipGraph-friendly variant: nothing the launches depend on lives in host scalars that change per step ----------
+    def advance(self):
+        """Eagerly, before replaying a captured `step_captured`: count the step and refresh the device bias corrections."""
+        import math
+        import struct
+        self.steps += 1
+        # the same arithmetic as effdet_adam_clip_step's host side: the betas arrive there as C floats, powers in double
+        b1, b2 = (struct.unpack('f', struct.pack('f', b))[0] for b in self.betas)
+        bc = torch.tensor([1.0 - b1 ** self.steps, math.sqrt(1.0 - b2 ** self.steps)], dtype=torch.float32)
+        self._bc.copy_(bc)
+
+    def step_captured(self):
+        """The launches of `step()` with the bias corrections read from device memory (capturable; call `advance()` first)."""
+        st = torch.cuda.current_stream(self.flat_grad.device).cuda_stream
+        norm = None
+        if self.max_grad_norm is not None:
+            norm = self.grad_norm()
+        _lib.check(self.lib.effdet_adam_clip_step_dev(
+            st, self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+            self.flat_param.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self._bc.data_ptr(),
+            float(self.max_grad_norm or 0.0), self._sq.data_ptr() if self.max_grad_norm is not None else None), 'effdet_adam_clip_step_dev')
         return norm

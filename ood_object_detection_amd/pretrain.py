@@ -28,7 +28,10 @@ def set_bn_eval(module):
 
 class PretrainStep(object):
     def __init__(self, model, lr=1e-3, max_grad_norm=10.0, alpha=0.15, box_loss_weight=50.0, freeze_bn=False,
-                 labeler=True):
+                 labeler=True, graph=False, graph_warmup=2):
+        """graph=True: after `graph_warmup` eager iterations the whole iteration (zero_grad, forward, loss, backward and -
+        single GPU - clip + Adam) is captured into one hipGraph and replayed; the ~5 000 launches of a step then cost one
+        submission.  Shapes must stay fixed; labels are assigned eagerly and copied into the graph's static buffers."""
         from .effdet.anchors import Anchors, AnchorLabeler
         from .effdet.config import set_config_writeable
         from .effdet.loss import DetectionLoss
@@ -51,6 +54,10 @@ class PretrainStep(object):
         if dist.is_available() and dist.is_initialized():
             self.world = dist.get_world_size()
         self.last_allreduce_ms = 0.0
+        self.graph = bool(graph)
+        self._graph_warmup = int(graph_warmup)
+        self._calls = 0
+        self._cap = None                        # (graph, optimizer graph or None, static inputs, static outputs)
 
     def targets(self, target):
         """target: {'bbox': [per-image [M,4] yxyx], 'cls': [per-image [M]]} (labelled on the GPU, effdet/anchors.py:384-438)
@@ -92,8 +99,71 @@ class PretrainStep(object):
         evaluator.add_batch(det, count, gtb, gtc)
         return det, count
 
+    # ---- captured iteration ---------------------------------------------------------------------------------
+    def _capture(self, x, cls_t, box_t, npos):
+        model, opt = self.model, self.opt
+        sx = x.clone()
+        s_cls = [t.clone() for t in cls_t]
+        s_box = [t.clone() for t in box_t]
+        s_np = npos.clone()
+        torch.cuda.synchronize()
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            opt.zero_grad()
+            feats = model(sx, mode='bb')
+            class_out, box_out = model(feats, mode='fpn_and_head')
+            loss, class_loss, box_loss = self.loss_fn(class_out, box_out, s_cls, s_box, s_np)
+            loss.backward()
+            norm = opt.step_captured() if self.world == 1 else None
+            outs = [loss.detach(), class_loss, box_loss, norm]
+        g2 = None
+        if self.world > 1:
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                outs[3] = opt.step_captured()
+        del feats, class_out, box_out, loss
+        self._cap = (g1, g2, (sx, s_cls, s_box, s_np), outs)
+
+    def _replay(self, x, cls_t, box_t, npos, time_allreduce):
+        g1, g2, (sx, s_cls, s_box, s_np), outs = self._cap
+        if tuple(x.shape) != tuple(sx.shape) or x.dtype != sx.dtype:
+            raise ValueError('graph mode: input shape / dtype changed (%s %s, captured %s %s)' % (tuple(x.shape), x.dtype, tuple(sx.shape), sx.dtype))
+        sx.copy_(x)
+        for d, t in zip(s_cls, cls_t):
+            d.copy_(t)
+        for d, t in zip(s_box, box_t):
+            d.copy_(t)
+        s_np.copy_(npos)
+        self.opt.advance()
+        g1.replay()
+        if g2 is not None:
+            self._allreduce(time_allreduce)
+            g2.replay()
+        self.model.invalidate()
+        return {'loss': outs[0].clone(), 'class_loss': outs[1].clone(), 'box_loss': outs[2].clone(),
+                'grad_norm': None if outs[3] is None else outs[3].clone()}
+
+    def _allreduce(self, time_allreduce):
+        import torch.distributed as dist
+        opt = self.opt
+        if time_allreduce:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        dist.all_reduce(opt.flat_grad, op=dist.ReduceOp.SUM)
+        opt.flat_grad.div_(self.world)
+        if time_allreduce:
+            e1.record()
+            e1.synchronize()
+            self.last_allreduce_ms = e0.elapsed_time(e1)
+
     def __call__(self, x, target, time_allreduce=False, evaluator=None):
         model, opt = self.model, self.opt
+        self._calls += 1
+        if self.graph and evaluator is None and self._calls > self._graph_warmup:
+            cls_t, box_t, npos = self.targets(target)
+            if self._cap is None:
+                self._capture(x, cls_t, box_t, npos)
+            return self._replay(x, cls_t, box_t, npos, time_allreduce)
         opt.zero_grad()
         cls_t, box_t, npos = self.targets(target)
         feats = model(x, mode='bb')
@@ -103,16 +173,7 @@ class PretrainStep(object):
         if evaluator is not None:
             self.evaluate(class_out, box_out, target, evaluator)
         if self.world > 1:
-            import torch.distributed as dist
-            if time_allreduce:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            dist.all_reduce(opt.flat_grad, op=dist.ReduceOp.SUM)
-            opt.flat_grad.div_(self.world)
-            if time_allreduce:
-                e1.record()
-                e1.synchronize()
-                self.last_allreduce_ms = e0.elapsed_time(e1)
+            self._allreduce(time_allreduce)
         norm = opt.step()
         model.invalidate()                      # the inference engine's packed weights are stale now
         return {'loss': loss.detach(), 'class_loss': class_loss, 'box_loss': box_loss, 'grad_norm': norm}

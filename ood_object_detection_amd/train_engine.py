@@ -107,12 +107,13 @@ class _Ops(object):
         return dx, out[:k * k], out[k * k]
 
     # ---- element-wise ---------------------------------------------------------------------------
-    def ew(self, op, a, b=None, c=None, v=(None, None, None, None), s=(0.0, 0.0, 0.0, 0.0), hw=0):
+    def ew(self, op, a, b=None, c=None, v=(None, None, None, None), s=(0.0, 0.0, 0.0, 0.0), hw=0, sdev=None):
+        """sdev: device float[4] replacing the scalars s (no host read-back: the step stays graph-capturable)"""
         out = torch.empty_like(a)
         C = a.shape[-1]
         p = lambda t: None if t is None else t.data_ptr()
         _lib.check(self.lib.effdet_train_ew(self.st(), op, out.data_ptr(), a.data_ptr(), p(b), p(c), p(v[0]), p(v[1]), p(v[2]), p(v[3]),
-                                            s[0], s[1], s[2], s[3], a.numel(), C, hw), 'effdet_train_ew(%d)' % op)
+                                            s[0], s[1], s[2], s[3], a.numel(), C, hw, p(sdev)), 'effdet_train_ew(%d)' % op)
         return out
 
     def silu(self, z):
@@ -528,19 +529,24 @@ class TrainEngine(object):
                     src_ids.append(ids[off])
                 method = node['weight_method']
                 ew_param = fn.combine.edge_weights
+                n_in = len(ins)
+                third = ins[2] if n_in > 2 else None
+                # fusion weights stay on the device (a float[4] = w0, w1, w2, den read by the kernel): no host read-back
                 if method == 'fastattn':
-                    wv = torch.relu(ew_param.detach())
-                    den = float((wv.sum() + 0.0001).item())
-                    wl = [float(v) for v in wv.tolist()] + [0.0]
-                    fused = ops.ew(7, ins[0], ins[1], ins[2] if len(ins) > 2 else None, s=(wl[0], wl[1], wl[2], den))
+                    wv = torch.relu(ew_param.detach())                            # efficientdet.py:238-242
+                    den = wv.sum() + 0.0001
+                    sdev = torch.cat([wv, wv.new_zeros(3 - n_in), den.reshape(1)]).contiguous()
+                    fused = ops.ew(7, ins[0], ins[1], third, sdev=sdev)
                 elif method == 'attn':
                     wv = torch.softmax(ew_param.detach(), 0)
-                    wl = [float(v) for v in wv.tolist()] + [0.0]
-                    den = 1.0
-                    fused = ops.ew(9, ins[0], ins[1], ins[2] if len(ins) > 2 else None, s=(wl[0], wl[1], wl[2], 0.0))
+                    den = wv.new_ones(())
+                    sdev = torch.cat([wv, wv.new_zeros(3 - n_in), den.reshape(1)]).contiguous()
+                    fused = ops.ew(9, ins[0], ins[1], third, sdev=sdev)
                 else:
-                    wl, den = [1.0, 1.0, 1.0 if len(ins) > 2 else 0.0], 1.0
-                    fused = ops.ew(9, ins[0], ins[1], ins[2] if len(ins) > 2 else None, s=(wl[0], wl[1], wl[2], 0.0))
+                    wv = torch.ones(n_in, dtype=torch.float32, device=self.dev)
+                    den = wv.new_ones(())
+                    sdev = torch.cat([wv, wv.new_zeros(3 - n_in), den.reshape(1)]).contiguous()
+                    fused = ops.ew(9, ins[0], ins[1], third, sdev=sdev)
                 act = ops.silu(fused)
                 sc = fn.after_combine.conv
                 d, rdw = self._dw_fwd(act, sc.conv_dw, p + 'after_combine.conv.conv_dw.')
@@ -548,7 +554,7 @@ class TrainEngine(object):
                 y, rbn = self._bn_fwd(c, sc.bn, p + 'after_combine.conv.bn.')
                 tensors.append(dict(t=y, level=lvl))
                 ids.append(len(tensors) - 1)
-                saved['nodes'].append(dict(p=p, ins=ins, recs=recs, src_ids=src_ids, method=method, w=wl, den=den, fused=fused,
+                saved['nodes'].append(dict(p=p, ins=ins, recs=recs, src_ids=src_ids, method=method, w=wv, den=den, fused=fused,
                                            dw=rdw, pw=rpw, bn=rbn, out_id=len(tensors) - 1, n_in=len(ins)))
             ids = ids[-L:]
         pyr = [tensors[i] for i in ids]
@@ -637,19 +643,18 @@ class TrainEngine(object):
             dact = self._dw_bwd(nrec['dw'], dd, grads)
             dfused = ops.silu_bwd(nrec['fused'], dact)
             n = nrec['n_in']
-            w, den = nrec['w'], nrec['den']
+            wt, den = nrec['w'], nrec['den']                                  # device tensors [n], []
             if nrec['method'] in ('fastattn', 'attn'):
                 S = torch.stack([ops.col_reduce(1, dfused, nrec['ins'][i]).sum() for i in range(n)])
                 ewp = self.model.get_parameter(p + 'combine.edge_weights').detach()
-                wt = torch.tensor(w[:n], dtype=torch.float32, device=self.dev)
                 if nrec['method'] == 'fastattn':
                     dw = S / den - (S * wt).sum() / (den * den)
                     grads[p + 'combine.edge_weights'] = dw * (ewp > 0).to(dw.dtype)
                 else:
                     grads[p + 'combine.edge_weights'] = wt * (S - (wt * S).sum())
+            coef = torch.cat([wt / den, wt.new_zeros(4 - n)]).contiguous()
             for i in range(n):
-                coef = w[i] / den
-                di = ops.ew(8, dfused, s=(coef, 0.0, 0.0, 0.0))
+                di = ops.ew(8, dfused, sdev=coef[i:i + 1].repeat(4))
                 di = self._resample_bwd(nrec['recs'][i], di, grads)
                 add_to(nrec['src_ids'][i], di)
         nbb = saved['nbb']

@@ -434,3 +434,33 @@ def test_pretrain_step_with_device_evaluator():
     for a, b in ((m2['Precision/mAP@0.5IOU'], r['mean_ap']), (m2['Precision/meanCorLoc@0.5IOU'], r['mean_corloc'])):
         assert (np.isnan(a) and np.isnan(b)) or abs(a - b) < 1e-12
     assert 'Precision/mAP@0.5IOU' in m
+
+
+def test_pretrain_step_hipgraph_matches_eager():
+    """graph=True replays the captured iteration: losses, gradient norms and weights after five steps equal the eager path's
+    bit for bit (same kernels, same order; only the submission differs)"""
+    from ood_object_detection_amd.pretrain import PretrainStep
+    size, B, C = 128, 2, 20
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randint(0, 256, (B, 3, size, size), generator=g, dtype=torch.uint8).to(DEV) for _ in range(5)]
+    boxes = [torch.tensor([[10., 12., 70., 90.], [40., 30., 120., 100.]]), torch.tensor([[5., 5., 60., 50.]])]
+    cls = [torch.tensor([3, 7]), torch.tensor([1])]
+    target = {'bbox': [b.to(DEV) for b in boxes], 'cls': [c.to(DEV) for c in cls]}
+    runs = []
+    for graph in (False, True):
+        model, cfg, nodes, sd, _ = _train_setup(size, B, C, seed=23)
+        model = model.to(DEV).float()
+        step = PretrainStep(model, graph=graph, graph_warmup=2)
+        hist = []
+        for x in xs:
+            o = step(x, target)
+            hist.append((o['loss'].item(), o['grad_norm'].item()))
+        runs.append((hist, {n: p.detach().clone() for n, p in model.named_parameters()},
+                     {n: b.detach().clone() for n, b in model.named_buffers()}))
+        if graph:
+            assert step._cap is not None
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    for n in runs[0][1]:
+        assert torch.equal(runs[0][1][n], runs[1][1][n]), n
+    for n in runs[0][2]:
+        assert torch.equal(runs[0][2][n], runs[1][2][n]), n

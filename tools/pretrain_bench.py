@@ -41,6 +41,7 @@ def main():
     ap.add_argument('--image', type=int, default=640)
     ap.add_argument('--classes', type=int, default=90)
     ap.add_argument('--model', default='tf_efficientdet_d0')
+    ap.add_argument('--graph', action='store_true', help='replay the iteration from one captured hipGraph')
     args = ap.parse_args()
     rank, local_rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
     if not torch.cuda.is_available():
@@ -58,7 +59,7 @@ def main():
     model = build_model(args.model, args.image, args.classes).to(dev).float()
     with torch.no_grad():
         model.class_net.predict.conv_pw.bias.fill_(-4.59511985)          # reference init (-log(99)), efficientdet.py:513
-    step = PretrainStep(model)
+    step = PretrainStep(model, graph=args.graph)
     B = args.batch
     x = torch.randint(0, 256, (B, 3, args.image, args.image), dtype=torch.uint8, device=dev,
                       generator=torch.Generator(device=dev).manual_seed(100 + rank))
@@ -71,7 +72,7 @@ def main():
         torch.cuda.synchronize(dev)
 
     losses = []
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 4 if args.graph else 0)):
         losses.append(step(x, target)['loss'].item())
     barrier()
     ar = 0.0
@@ -95,7 +96,8 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s %dx%d batch=%d/GPU C=%d pretrain step, labels assigned on the GPU' % (
                 args.model, args.image, args.image, B, args.classes), 'global_batch': world * B,
-                'parallelism': 'dp%d, one flat-gradient all-reduce per step' % world},
+                'parallelism': 'dp%d, one flat-gradient all-reduce per step' % world,
+                'launch': 'hipgraph' if args.graph else 'eager'},
             'loss_first_last': [round(losses[0], 4), round(losses[-1], 4)],
             'peak_mem_GB': round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)}), flush=True)
     if dist is not None:
