@@ -266,10 +266,10 @@ int effdet_train_ew(void* stream, int op, float* out, const float* a, const floa
                     const float* v0, const float* v1, const float* v2, const float* v3,
                     float s0, float s1, float s2, float s3, long long n, int C, long long hw, const float* sdev);
 /* Per-channel reductions over the rows of dense [G][R][C] tensors -> out [G][C]:
- * mode 0 sum a; 1 sum a*b; 2 sum (a - v[c])^2; 3 sum a*(b - v[c]). */
+ * mode 0 sum a; 1 sum a*b; 2 sum (a - v[c])^2; 3 sum a*(b - v[c]); every result is multiplied by alpha (1/M gives means). */
 long long effdet_train_col_reduce_workspace_floats(int G, long long R, int C);
 int effdet_train_col_reduce(void* stream, int mode, const float* a, const float* b, const float* v,
-                            int G, long long R, int C, float* out, float* workspace, long long workspace_floats);
+                            int G, long long R, int C, float* out, float* workspace, long long workspace_floats, float alpha);
 /* op 0: nearest x2 upsample in [B,H,W,C] -> out [B,2H,2W,C];  op 1: its backward, in = d out [B,2H,2W,C] -> [B,H,W,C];
  * op 2: 3x3/s2 TF-SAME max-pool backward, in = pool input [B,H,W,C], aux = dY [B,ceil(H/2),ceil(W/2),C] -> dX
  * (gradient goes to the first maximum of a window in row-major order, as torch's max_pool2d does). */
@@ -281,6 +281,29 @@ int effdet_train_im2col_stem(void* stream, const float* X, float* col, int B, in
  * {d conv_reduce.weight, d conv_reduce.bias, d conv_expand.weight^T, d conv_expand.bias}. */
 int effdet_train_se_bwd(void* stream, const float* pool_sum, int hw, const float* gate, const float* dgate,
                         const float* W1, const float* b1, const float* W2t, float* ds, float* pgrad, int B, int C, int R);
+
+/* Parameter-sized helpers of conv + BatchNorm on running statistics (one launch each instead of a dozen tensor ops):
+ * fold: scale = gamma / sqrt(var + eps), shift = beta - mean * scale, rstd; Wf [N][K] = W * scale[n], WfT [K][N] = Wf^T,
+ * WT [K][N] = W^T (each matrix optional).  grads: from dWext = effdet_train_gemm_tn's [N][K+1] (or the depthwise
+ * [(K+1)][N] layout when transposed != 0): dW [N][K] = scale * dWraw, d gamma = rstd * (sum_k W * dWraw - mean * dsum),
+ * d beta = dsum. */
+int effdet_train_fold_bn(void* stream, const float* W, int N, int K, const float* gamma, const float* beta,
+                         const float* mean, const float* var, float eps,
+                         float* Wf, float* WfT, float* WT, float* scale, float* shift, float* rstd);
+int effdet_train_convbn_grads(void* stream, const float* dWext, int N, int K, int transposed, const float* W,
+                              const float* scale, const float* rstd, const float* mean,
+                              float* dW, float* dgamma, float* dbeta);
+
+/* nn.BatchNorm2d bookkeeping of the layers that are not folded (BiFPN / heads), one launch each.  finalize: from the batch
+ * (train != 0: running stats updated with `momentum`, running_var with var * unbias, num_batches_tracked += 1) or running
+ * (train == 0; pass them as mean / var) statistics -> rstd, scale = gamma * rstd, shift = beta - mean * scale.
+ * bwd_prep: s1 = sum(dy), s2c = sum(dy (c - mean)) -> d gamma, d beta and the two vectors v1 = s1/M, v3 = rstd^2 s2c/M that
+ * op 6 of effdet_train_ew needs. */
+int effdet_train_bn_finalize(void* stream, const float* mean, const float* var, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, long long* num_batches_tracked, int C, int train,
+                             float momentum, float unbias, float eps, float* scale, float* shift, float* rstd);
+int effdet_train_bn_bwd_prep(void* stream, const float* s1, const float* s2c, const float* rstd, int C, float inv_m,
+                             float* dgamma, float* dbeta, float* v1, float* v3);
 
 /* ---- optimizer half of the pretrain step (pretrain.py:272-276) ------------------------------------ */
 

@@ -94,7 +94,7 @@ SIGNATURES = {
     'effdet_train_ew': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_float, c_float, c_float, c_float, c_ll, c_int, c_ll, c_void_p]),
     'effdet_train_col_reduce_workspace_floats': (c_ll, [c_int, c_ll, c_int]),
-    'effdet_train_col_reduce': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_ll, c_int, c_void_p, c_void_p, c_ll]),
+    'effdet_train_col_reduce': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_ll, c_int, c_void_p, c_void_p, c_ll, c_float]),
     'effdet_train_spatial': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
     'effdet_train_im2col_stem': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
     'effdet_train_se_bwd': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -103,6 +103,13 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_void_p, c_void_p]),
     'effdet_eval_ap_workspace_bytes': (c_ll, [c_int]),
     'effdet_eval_ap': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_ll]),
+    'effdet_train_fold_bn': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'effdet_train_convbn_grads': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p]),
+    'effdet_train_bn_finalize': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                         c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    'effdet_train_bn_bwd_prep': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'effdet_gather_ood': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_int, c_int, c_int,
                                   c_void_p, c_void_p]),
 }

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
 }
 
 // out[g][l] (+)= sum_s in[g][s][l] in index order
-struct ReduceMidArgs { const float* in; float* out; long long L; int G, S, accumulate; };
+struct ReduceMidArgs { const float* in; float* out; long long L; int G, S, accumulate; float alpha; };
 __global__ __launch_bounds__(256) void reduce_mid_kernel(ReduceMidArgs p) {
     // 16 consecutive l per workgroup x 16 lanes over s: lane j sums s = j, j+16, ... in order, then the 16 lane sums are
     // added in lane order - a fixed association, so the result is bitwise reproducible
@@ -185,12 +185,13 @@ __global__ __launch_bounds__(256) void reduce_mid_kernel(ReduceMidArgs p) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) t += sm[j][li];
         float* dst = p.out + (long long)gi * p.L + l;
+        t *= p.alpha;
         *dst = p.accumulate ? *dst + t : t;
     }
 }
 
-int launch_reduce_mid(hipStream_t st, const float* in, int G, int S, long long L, float* out, int accumulate) {
-    ReduceMidArgs a{in, out, L, G, S, accumulate};
+int launch_reduce_mid(hipStream_t st, const float* in, int G, int S, long long L, float* out, int accumulate, float alpha = 1.0f) {
+    ReduceMidArgs a{in, out, L, G, S, accumulate, alpha};
     const long long blocks = (L + 15) / 16;
     if (blocks > 0x7fffffffLL || G > 65535) return EFFDET_EINVAL;
     hipLaunchKernelGGL(reduce_mid_kernel, dim3((unsigned)blocks, (unsigned)G), dim3(256), 0, st, a);
@@ -561,6 +562,96 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(SeBwdArgs p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// parameter-sized helpers of conv + BatchNorm(running statistics): one launch instead of a dozen tiny tensor ops
+// ------------------------------------------------------------------------------------------------------------
+struct FoldArgs {
+    const float* W; int N, K; const float* gamma; const float* beta; const float* mean; const float* var; float eps;
+    float* Wf; float* WfT; float* WT; float* scale; float* shift; float* rstd;
+};
+// scale = gamma * rsqrt(var + eps), shift = beta - mean * scale; Wf [N][K] = W * scale[n], WfT [K][N] its transpose,
+// WT [K][N] = W transposed (each optional).  One workgroup per output channel.
+__global__ __launch_bounds__(256) void fold_bn_kernel(FoldArgs p) {
+    const int n = blockIdx.x;
+    const float rs = 1.0f / sqrtf(p.var[n] + p.eps);
+    const float sc = p.gamma[n] * rs;
+    if (threadIdx.x == 0) {
+        p.scale[n] = sc;
+        p.shift[n] = p.beta[n] - p.mean[n] * sc;
+        p.rstd[n] = rs;
+    }
+    for (int k = threadIdx.x; k < p.K; k += 256) {
+        const float w = p.W[(long long)n * p.K + k];
+        if (p.Wf) p.Wf[(long long)n * p.K + k] = w * sc;
+        if (p.WfT) p.WfT[(long long)k * p.N + n] = w * sc;
+        if (p.WT) p.WT[(long long)k * p.N + n] = w;
+    }
+}
+
+struct FinArgs {
+    const float* dWext; int N, K, transposed; const float* W; const float* scale; const float* rstd; const float* mean;
+    float* dW; float* dgamma; float* dbeta;
+};
+// z = scale * conv(x; W) + shift, dWraw = dz^T x, dsum = sum dz  ->  dW = scale * dWraw,
+// d gamma = rstd * (sum_k W * dWraw - mean * dsum), d beta = dsum.   dWext: [N][K+1] (or [(K+1)][N] when transposed).
+__global__ __launch_bounds__(256) void convbn_grads_kernel(FinArgs p) {
+    __shared__ float sm[4];
+    const int n = blockIdx.x;
+    const float sc = p.scale[n];
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < p.K; k += 256) {
+        const float v = p.transposed ? p.dWext[(long long)k * p.N + n] : p.dWext[(long long)n * (p.K + 1) + k];
+        p.dW[(long long)n * p.K + k] = sc * v;
+        acc += p.W[(long long)n * p.K + k] * v;
+    }
+    acc = wave_reduce_sum(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tot = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+        const float dsum = p.transposed ? p.dWext[(long long)p.K * p.N + n] : p.dWext[(long long)n * (p.K + 1) + p.K];
+        p.dgamma[n] = p.rstd[n] * (tot - p.mean[n] * dsum);
+        p.dbeta[n] = dsum;
+    }
+}
+
+struct BnFinArgs {
+    const float* mean; const float* var; const float* gamma; const float* beta;
+    float* running_mean; float* running_var; long long* nbt; int C, train; float momentum, unbias, eps;
+    float* scale; float* shift; float* rstd;
+};
+// nn.BatchNorm2d bookkeeping in one launch: running statistics (training: r = (1-m) r + m * batch, unbiased variance),
+// rstd = 1/sqrt(var + eps), scale = gamma * rstd, shift = beta - mean * scale
+__global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinArgs p) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c == 0 && p.train && p.nbt) *p.nbt += 1;
+    if (c >= p.C) return;
+    const float m = p.mean[c], v = p.var[c];
+    if (p.train) {
+        p.running_mean[c] = p.running_mean[c] * (1.0f - p.momentum) + p.momentum * m;
+        p.running_var[c] = p.running_var[c] * (1.0f - p.momentum) + p.momentum * (v * p.unbias);
+    }
+    const float rs = 1.0f / sqrtf(v + p.eps);
+    const float sc = p.gamma[c] * rs;
+    p.rstd[c] = rs;
+    p.scale[c] = sc;
+    p.shift[c] = p.beta[c] - m * sc;
+}
+
+struct BnBwdArgs { const float* s1; const float* s2c; const float* rstd; int C; float invM; float* dgamma; float* dbeta; float* v1; float* v3; };
+// d gamma = rstd * sum(dy (c - mean)), d beta = sum(dy); v1 = sum(dy)/M, v3 = rstd^2 * sum(dy (c - mean))/M for op 6 of the
+// element-wise family
+__global__ __launch_bounds__(256) void bn_bwd_prep_kernel(BnBwdArgs p) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= p.C) return;
+    const float rs = p.rstd[c], s1 = p.s1[c], s2 = p.s2c[c];
+    p.dgamma[c] = s2 * rs;
+    p.dbeta[c] = s1;
+    p.v1[c] = s1 * p.invM;
+    p.v3[c] = rs * rs * s2 * p.invM;
+}
+
 }  // namespace
 
 // ================================================================================================================
@@ -731,7 +822,7 @@ extern "C" long long effdet_train_col_reduce_workspace_floats(int G, long long R
 }
 
 extern "C" int effdet_train_col_reduce(void* stream, int mode, const float* a, const float* b, const float* v,
-                                       int G, long long R, int C, float* out, float* workspace, long long workspace_floats) {
+                                       int G, long long R, int C, float* out, float* workspace, long long workspace_floats, float alpha) {
     EFFDET_ENTER();
     if (!a || !out || !workspace || G <= 0 || G > 65535 || R <= 0 || C <= 0 || mode < 0 || mode > 3) return EFFDET_EINVAL;
     if ((mode == 1 || mode == 3) && !b) return EFFDET_EINVAL;
@@ -744,7 +835,7 @@ extern "C" int effdet_train_col_reduce(void* stream, int mode, const float* a, c
     hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)S, (unsigned)((C + 63) / 64), (unsigned)G), dim3(256), 0, st, p);
     int rc = effdet_check_launch();
     if (rc) return rc;
-    return launch_reduce_mid(st, workspace, G, S, C, out, 0);
+    return launch_reduce_mid(st, workspace, G, S, C, out, 0, alpha);
 }
 
 extern "C" int effdet_train_spatial(void* stream, int op, const float* in, const float* aux, float* out,
@@ -779,5 +870,45 @@ extern "C" int effdet_train_se_bwd(void* stream, const float* pool_sum, int hw, 
     if (sh > 64 * 1024) return EFFDET_EINVAL;
     SeBwdArgs p{pool_sum, 1.0f / (float)hw, gate, dgate, W1, b1, W2t, ds, pgrad, C, R};
     hipLaunchKernelGGL(se_bwd_kernel, dim3(B), dim3(256), sh, reinterpret_cast<hipStream_t>(stream), p);
+    return effdet_check_launch();
+}
+
+extern "C" int effdet_train_fold_bn(void* stream, const float* W, int N, int K, const float* gamma, const float* beta,
+                                    const float* mean, const float* var, float eps,
+                                    float* Wf, float* WfT, float* WT, float* scale, float* shift, float* rstd) {
+    EFFDET_ENTER();
+    if (!W || !gamma || !beta || !mean || !var || !scale || !shift || !rstd || N <= 0 || K <= 0) return EFFDET_EINVAL;
+    FoldArgs p{W, N, K, gamma, beta, mean, var, eps, Wf, WfT, WT, scale, shift, rstd};
+    hipLaunchKernelGGL(fold_bn_kernel, dim3((unsigned)N), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+    return effdet_check_launch();
+}
+
+extern "C" int effdet_train_convbn_grads(void* stream, const float* dWext, int N, int K, int transposed, const float* W,
+                                         const float* scale, const float* rstd, const float* mean,
+                                         float* dW, float* dgamma, float* dbeta) {
+    EFFDET_ENTER();
+    if (!dWext || !W || !scale || !rstd || !mean || !dW || !dgamma || !dbeta || N <= 0 || K <= 0) return EFFDET_EINVAL;
+    FinArgs p{dWext, N, K, transposed, W, scale, rstd, mean, dW, dgamma, dbeta};
+    hipLaunchKernelGGL(convbn_grads_kernel, dim3((unsigned)N), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+    return effdet_check_launch();
+}
+
+extern "C" int effdet_train_bn_finalize(void* stream, const float* mean, const float* var, const float* gamma, const float* beta,
+                                        float* running_mean, float* running_var, long long* num_batches_tracked, int C, int train,
+                                        float momentum, float unbias, float eps, float* scale, float* shift, float* rstd) {
+    EFFDET_ENTER();
+    if (!mean || !var || !gamma || !beta || !scale || !shift || !rstd || C <= 0) return EFFDET_EINVAL;
+    if (train && (!running_mean || !running_var)) return EFFDET_EINVAL;
+    BnFinArgs p{mean, var, gamma, beta, running_mean, running_var, num_batches_tracked, C, train, momentum, unbias, eps, scale, shift, rstd};
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+    return effdet_check_launch();
+}
+
+extern "C" int effdet_train_bn_bwd_prep(void* stream, const float* s1, const float* s2c, const float* rstd, int C, float inv_m,
+                                        float* dgamma, float* dbeta, float* v1, float* v3) {
+    EFFDET_ENTER();
+    if (!s1 || !s2c || !rstd || !dgamma || !dbeta || !v1 || !v3 || C <= 0) return EFFDET_EINVAL;
+    BnBwdArgs p{s1, s2c, rstd, C, inv_m, dgamma, dbeta, v1, v3};
+    hipLaunchKernelGGL(bn_bwd_prep_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
     return effdet_check_launch();
 }

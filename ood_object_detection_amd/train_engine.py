@@ -125,8 +125,8 @@ class _Ops(object):
     def add(self, a, b):
         return self.ew(2, a, b)
 
-    def col_reduce(self, mode, a, b=None, v=None, per_image=False):
-        """a: [..., C]; -> [C] (or [B, C] per image)"""
+    def col_reduce(self, mode, a, b=None, v=None, per_image=False, alpha=1.0):
+        """a: [..., C]; -> alpha * [C] (or [B, C] per image)"""
         C = a.shape[-1]
         G = a.shape[0] if per_image else 1
         R = a.numel() // (C * G)
@@ -135,7 +135,7 @@ class _Ops(object):
         out = self.new(G, C)
         _lib.check(self.lib.effdet_train_col_reduce(self.st(), mode, a.data_ptr(), None if b is None else b.data_ptr(),
                                                     None if v is None else v.data_ptr(), G, R, C, out.data_ptr(),
-                                                    ws.data_ptr(), ws.numel()), 'effdet_train_col_reduce')
+                                                    ws.data_ptr(), ws.numel(), alpha), 'effdet_train_col_reduce')
         return out if per_image else out[0]
 
     def spatial(self, op, x, aux=None):
@@ -206,6 +206,35 @@ class TrainEngine(object):
     # =============================================================================================
     # conv (+BN) building blocks.  Every *_fwd returns (output, record); *_bwd(record, dy, grads) returns dx.
     # =============================================================================================
+    def _fold(self, W, bn, want_wf, want_wft, want_wt):
+        """effdet_train_fold_bn: (Wf, WfT, WT, scale, shift, rstd) of a conv weight [N, K] and its BatchNorm (running stats)"""
+        N, K = W.shape
+        ops = self.ops
+        Wf = ops.new(N, K) if want_wf else None
+        WfT = ops.new(K, N) if want_wft else None
+        WT = ops.new(K, N) if want_wt else None
+        vec = ops.new(3, N)
+        p = lambda t: None if t is None else t.data_ptr()
+        _lib.check(self.lib.effdet_train_fold_bn(ops.st(), W.data_ptr(), N, K, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                                 bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.eps),
+                                                 p(Wf), p(WfT), p(WT), vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr()),
+                   'effdet_train_fold_bn')
+        return Wf, WfT, WT, vec[0], vec[1], vec[2]
+
+    def _convbn_grads(self, rec, dwext, transposed, grads):
+        """effdet_train_convbn_grads: d weight (parameter layout), d gamma, d beta from the raw sums of the backward GEMM"""
+        N, K = rec['W'].shape
+        ops = self.ops
+        dW = ops.new(N, K)
+        dgb = ops.new(2, N)
+        _lib.check(self.lib.effdet_train_convbn_grads(ops.st(), dwext.data_ptr(), N, K, int(transposed), rec['W'].data_ptr(),
+                                                      rec['scale'].data_ptr(), rec['rstd'].data_ptr(), rec['mean'].data_ptr(),
+                                                      dW.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr()), 'effdet_train_convbn_grads')
+        wn, gn, bn_ = rec['names']
+        grads[wn] = dW.view(rec['wshape'])
+        grads[gn] = dgb[0]
+        grads[bn_] = dgb[1]
+
     def _pw_bneval_fwd(self, x, conv, bn, names):
         """1x1 conv (no bias) + BN with running statistics, folded: z = x (scale*W)^T + shift."""
         if bn.training:
@@ -213,74 +242,74 @@ class TrainEngine(object):
                                       'mode as pretrain.py:168-176 does (model.backbone.apply(set_bn_eval))')
         N = conv.weight.shape[0]
         W = conv.weight.detach().reshape(N, -1)
-        g, b, mean, rstd, scale, shift = _bn_vectors(bn)
-        Wf = (W * scale[:, None]).contiguous()
+        Wf, WfT, _, scale, shift, rstd = self._fold(W, bn, True, True, False)
         B, H, Wd, K = x.shape
-        z = self.ops.gemm_nt(x, Wf, shift.contiguous()).view(B, H, Wd, N)
-        return z, dict(x=x, W=W, Wf=Wf, mean=mean, rstd=rstd, scale=scale, names=names, wshape=conv.weight.shape)
+        z = self.ops.gemm_nt(x, Wf, shift).view(B, H, Wd, N)
+        return z, dict(x=x, W=W, Wf=Wf, WfT=WfT, mean=bn.running_mean, rstd=rstd, scale=scale, names=names, wshape=conv.weight.shape)
 
     def _pw_bneval_bwd(self, rec, dz, grads, need_dx=True):
         N, K = rec['Wf'].shape
-        dWraw, dsum = self.ops.gemm_tn(dz, rec['x'], N, K)
-        wn, gn, bn_ = rec['names']
-        grads[wn] = (rec['scale'][:, None] * dWraw).reshape(rec['wshape'])
-        grads[gn] = rec['rstd'] * ((rec['W'] * dWraw).sum(1) - rec['mean'] * dsum)
-        grads[bn_] = dsum.clone()
+        dWraw, _ = self.ops.gemm_tn(dz, rec['x'], N, K)
+        self._convbn_grads(rec, dWraw._base, False, grads)
         if not need_dx:
             return None
         B, H, Wd, _ = dz.shape
-        return self.ops.gemm_nt(dz, rec['Wf'].t().contiguous()).view(B, H, Wd, K)
+        return self.ops.gemm_nt(dz, rec['WfT']).view(B, H, Wd, K)
 
     def _dw_bneval_fwd(self, x, conv, bn, k, s, names):
         if bn.training:
             raise NotImplementedError('backbone BatchNorm in batch-statistics mode is not built (see pretrain.py:168-176)')
         C = conv.weight.shape[0]
-        taps = conv.weight.detach().permute(2, 3, 0, 1).reshape(k * k, C).contiguous()
-        g, b, mean, rstd, scale, shift = _bn_vectors(bn)
-        z = self.ops.dw_fwd(x, taps, scale.contiguous(), shift.contiguous(), k, s)
-        return z, dict(x=x, taps=taps, mean=mean, rstd=rstd, scale=scale, k=k, s=s, names=names, wshape=conv.weight.shape)
+        W = conv.weight.detach().reshape(C, k * k)
+        _, taps_s, taps, scale, shift, rstd = self._fold(W, bn, False, True, True)
+        z = self.ops.dw_fwd(x, taps, scale, shift, k, s)
+        return z, dict(x=x, W=W, taps_s=taps_s, mean=bn.running_mean, rstd=rstd, scale=scale, k=k, s=s, names=names,
+                       wshape=conv.weight.shape)
 
     def _dw_bneval_bwd(self, rec, dz, grads):
         k, s = rec['k'], rec['s']
-        dx, dtaps, dsum = self.ops.dw_bwd(dz, rec['x'], (rec['taps'] * rec['scale'][None, :]).contiguous(), k, s)
-        wn, gn, bn_ = rec['names']
-        C = dtaps.shape[1]
-        grads[wn] = (dtaps * rec['scale'][None, :]).reshape(k, k, C, 1).permute(2, 3, 0, 1).reshape(rec['wshape'])
-        grads[gn] = rec['rstd'] * ((rec['taps'] * dtaps).sum(0) - rec['mean'] * dsum)
-        grads[bn_] = dsum.clone()
+        dx, dtaps, _ = self.ops.dw_bwd(dz, rec['x'], rec['taps_s'], k, s)
+        self._convbn_grads(rec, dtaps._base, True, grads)
         return dx
 
     def _bn_fwd(self, c, bn, prefix):
         """BatchNorm2d on a raw conv output c [..., C] following bn.training (batch vs running statistics)."""
         C = c.shape[-1]
         M = c.numel() // C
-        g, b = bn.weight.detach(), bn.bias.detach()
+        ops = self.ops
         if bn.training:
-            mean = self.ops.col_reduce(0, c) / M
-            var = self.ops.col_reduce(2, c, v=mean) / M
-            with torch.no_grad():
-                mom = bn.momentum if bn.momentum is not None else 0.1
-                bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-                bn.running_var.mul_(1 - mom).add_(var * (M / max(M - 1, 1)), alpha=mom)
-                bn.num_batches_tracked += 1
+            mean = ops.col_reduce(0, c, alpha=1.0 / M)
+            var = ops.col_reduce(2, c, v=mean, alpha=1.0 / M)
         else:
-            mean, var = bn.running_mean.detach().clone(), bn.running_var.detach().clone()
-        rstd = torch.rsqrt(var + bn.eps)
-        scale = g * rstd
-        shift = b - mean * scale
-        y = self.ops.ew(3, c, v=(scale.contiguous(), shift.contiguous(), None, None))
-        return y, dict(c=c, mean=mean.contiguous(), rstd=rstd, scale=scale.contiguous(), train=bn.training, M=M, prefix=prefix)
+            mean, var = bn.running_mean, bn.running_var
+        vec = ops.new(3, C)
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        _lib.check(self.lib.effdet_train_bn_finalize(ops.st(), mean.data_ptr(), var.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                                     bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                                     bn.num_batches_tracked.data_ptr(), C, int(bn.training), float(mom),
+                                                     float(M / max(M - 1, 1)), float(bn.eps), vec[0].data_ptr(), vec[1].data_ptr(),
+                                                     vec[2].data_ptr()), 'effdet_train_bn_finalize')
+        scale, shift, rstd = vec[0], vec[1], vec[2]
+        y = ops.ew(3, c, v=(scale, shift, None, None))
+        if not bn.training:
+            mean = mean.clone()                 # the record must not alias a buffer a later load_state_dict may overwrite
+        return y, dict(c=c, mean=mean, rstd=rstd, scale=scale, train=bn.training, M=M, prefix=prefix)
 
     def _bn_bwd(self, rec, dy, grads):
         c, mean, rstd = rec['c'], rec['mean'], rec['rstd']
-        s1 = self.ops.col_reduce(0, dy)
-        s2c = self.ops.col_reduce(3, dy, c, v=mean)
-        self._acc(grads, rec['prefix'] + 'weight', s2c * rstd)
-        self._acc(grads, rec['prefix'] + 'bias', s1)
+        ops = self.ops
+        C = c.shape[-1]
+        s1 = ops.col_reduce(0, dy)
+        s2c = ops.col_reduce(3, dy, c, v=mean)
+        out = ops.new(4, C)
+        _lib.check(self.lib.effdet_train_bn_bwd_prep(ops.st(), s1.data_ptr(), s2c.data_ptr(), rstd.data_ptr(), C, 1.0 / rec['M'],
+                                                     out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr()),
+                   'effdet_train_bn_bwd_prep')
+        self._acc(grads, rec['prefix'] + 'weight', out[0])
+        self._acc(grads, rec['prefix'] + 'bias', out[1])
         if rec['train']:
-            M = rec['M']
-            return self.ops.ew(6, dy, c, v=(rec['scale'], (s1 / M).contiguous(), mean, (rstd * rstd * s2c / M).contiguous()))
-        return self.ops.ew(3, dy, v=(rec['scale'], None, None, None))
+            return ops.ew(6, dy, c, v=(rec['scale'], out[2], mean, out[3]))
+        return ops.ew(3, dy, v=(rec['scale'], None, None, None))
 
     @staticmethod
     def _acc(grads, name, g):
