@@ -36,7 +36,7 @@ inline RowMap make_rowmap(long long rpi, long long img_stride, long long ld, lon
 // ------------------------------------------------------------------------------------------------------------
 struct GemmNtArgs {
     const float* A; RowMap am; const float* W; const float* bias; float* C; RowMap cm;
-    long long M; int K, N, accumulate;
+    long long M; int K, N, accumulate, vec_out;
 };
 
 template <bool VEC>
@@ -87,6 +87,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int n = n0 + 16 * t + 4 * g;
+        if (p.vec_out) {                                     // N % 4 == 0 and 16-byte aligned rows: one store per lane and tile
+            if (n < p.N) {
+                f32x4 v = acc[t];
+                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                if (p.accumulate) v += *reinterpret_cast<const f32x4*>(crow + n);
+                *reinterpret_cast<f32x4*>(crow + n) = v;
+            }
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (n + r < p.N) {
@@ -670,6 +679,8 @@ extern "C" int effdet_train_gemm_nt(void* stream, const float* A, long long a_rp
     if (gx > 0x7fffffffLL) return EFFDET_EINVAL;
     const bool vec = K % 4 == 0 && p.am.ld % 4 == 0 && p.am.img_stride % 4 == 0 &&
                      reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(W) % 16 == 0;
+    p.vec_out = N % 4 == 0 && p.cm.ld % 4 == 0 && p.cm.img_stride % 4 == 0 && reinterpret_cast<uintptr_t>(C) % 16 == 0 &&
+                (bias == nullptr || reinterpret_cast<uintptr_t>(bias) % 16 == 0);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)gx, (unsigned)((N + 63) / 64));
     if (vec) hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), 0, st, p);
