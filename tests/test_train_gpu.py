@@ -464,3 +464,15 @@ def test_pretrain_step_hipgraph_matches_eager():
         assert torch.equal(runs[0][1][n], runs[1][1][n]), n
     for n in runs[0][2]:
         assert torch.equal(runs[0][2][n], runs[1][2][n]), n
+
+
+def test_pretrain_ddp_two_ranks_share_gpu():
+    """two data-parallel ranks (gloo, sharing this GPU): replicas stay bit-identical, graph path == eager path (tools/ddp_check.py)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EFFDET_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29571', os.path.join(root, 'tools', 'ddp_check.py')], env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0 and 'DDP_CHECK_OK world=2' in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
