@@ -476,3 +476,61 @@ def test_pretrain_ddp_two_ranks_share_gpu():
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
                         '--master-port', '29571', os.path.join(root, 'tools', 'ddp_check.py')], env=env, capture_output=True, text=True, timeout=420)
     assert r.returncode == 0 and 'DDP_CHECK_OK world=2' in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_gradients_d2_odd_channel_counts():
+    """tf_efficientdet_d2 (b2 backbone: 48 / 88 / 120 / 208 / 352 channels, BiFPN width 112, 5 cells): channel counts that are
+    not multiples of 16 or 64 exercise every tail path of the GEMM / reduction kernels.  BN in eval mode everywhere (--freeze_bn),
+    so the small 128 px maps do not dominate the error."""
+    from _models import seeded_model
+    from ood_object_detection_amd.effdet.loss import DetectionLoss
+    size, B, C = 128, 2, 12
+    model, cfg, nodes, sd = seeded_model('tf_efficientdet_d2', size, C, seed=31)
+    x = torch.from_numpy(seeded_array(31, 'input', (B, 3, size, size)))
+    cls_t, box_t, npos = _targets(cfg, size, B, C, 9)
+    (ref_total, _, _), ref_g, cls_ref, box_ref, _ = _oracle_step(sd, cfg, nodes, x, cls_t, box_t, npos, C, batch_stats=False)
+    model = model.to(DEV).float().train()
+    model.apply(lambda m: m.eval() if isinstance(m, torch.nn.BatchNorm2d) else None)
+    cfg.alpha, cfg.box_loss_weight = 0.15, 50.0
+    cls_o, box_o = model(x.to(DEV))
+    for a, r in zip(list(cls_o) + list(box_o), list(cls_ref) + list(box_ref)):
+        _close(a, r, 1e-3, 'd2 head output (training forward)')
+    total, _, _ = DetectionLoss(cfg)(cls_o, box_o, [t.to(DEV) for t in cls_t], [t.to(DEV) for t in box_t], npos.to(DEV))
+    total.backward()
+    gmax = max(float(r.abs().max()) for r in ref_g.values() if r is not None)
+    worst = ('', 0.0)
+    n = 0
+    for name, p in model.named_parameters():
+        r = ref_g.get(name)
+        if r is None:
+            continue
+        assert p.grad is not None, name
+        err = float((p.grad.cpu() - r).abs().max()) / max(float(r.abs().max()), 1e-5 * gmax)
+        if name.endswith('edge_weights'):
+            err *= 0.2
+        worst = max(worst, (name, err), key=lambda t: t[1])
+        n += 1
+    assert n > 600 and worst[1] <= 2e-3, (n, worst)
+
+
+def test_det_bench_train_backward_reaches_weights():
+    """DetBenchTrain (effdet/bench.py:106-145) in training mode: labels from boxes, loss, and `loss.backward()` fills the
+    gradients of backbone, BiFPN and heads"""
+    from ood_object_detection_amd.effdet.bench import DetBenchTrain
+    model, cfg, nodes, sd, x = _train_setup(128, 2, 20, seed=23)
+    bench = DetBenchTrain(model.to(DEV).float()).to(DEV)
+    bench.train()
+    bench.model.backbone.apply(lambda m: m.eval() if isinstance(m, torch.nn.BatchNorm2d) else None)
+    target = {'bbox': [torch.tensor([[10., 12., 70., 90.], [40., 30., 120., 100.]], device=DEV), torch.tensor([[5., 5., 60., 50.]], device=DEV)],
+              'cls': [torch.tensor([3, 7], device=DEV), torch.tensor([1], device=DEV)]}
+    out = bench(x.to(DEV), target)
+    assert set(out) >= {'loss', 'class_loss', 'box_loss'} and 'detections' not in out
+    out['loss'].backward()
+    for name in ('backbone.conv_stem.weight', 'backbone.blocks.3.1.se.conv_reduce.weight', 'fpn.cell.1.fnode.4.combine.edge_weights',
+                 'class_net.predict.conv_pw.bias', 'class_net.bn_rep.2.4.bn.weight', 'box_net.bn_rep.2.0.bn.weight'):
+        g = dict(bench.model.named_parameters())[name].grad
+        assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0, name
+    bench.eval()
+    with torch.no_grad():
+        out = bench(x.to(DEV), target)
+    assert 'detections' in out
