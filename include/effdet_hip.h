@@ -13,7 +13,8 @@
  *   - `stream` is a hipStream_t; all work is enqueued on it; no call synchronises (graph-capturable);
  *   - activations are NHWC, channels a multiple of 8; `dtype` 0 = float32 (parity mode),
  *     1 = bfloat16 (throughput mode, fp32 accumulate); weights of the MFMA GEMMs use the same dtype,
- *     every per-channel vector (scale/shift/bias/depthwise taps/SE weights) is float32;
+ *     every per-channel vector (scale/shift/bias/depthwise taps/SE weights) is float32; the effdet_train_* and
+ *     effdet_eval_* entry points are float32 only (channels a multiple of 4);
  *   - return value: 0 on success, -22 (EINVAL) for a rejected argument, -5 (EIO) if the launch failed;
  *   - thread-safe per stream, no global mutable state.
  */
