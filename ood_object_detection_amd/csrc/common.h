@@ -43,6 +43,28 @@ template <typename T> DEV float exp_t(float x) {
     if constexpr (sizeof(T) == 2) return fast_exp(x); else return expf(x);
 }
 
+// Folded BN + SiLU of the four accumulator values of a lane.  In bf16 throughput mode the non-transcendental part runs on
+// packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two values per lane and instruction); the
+// arithmetic - and therefore every bit of the result - is the same as four fast_silu(acc * sc + sh) calls.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <typename T> DEV f32x4 bn_silu4(const f32x4 acc, const f32x4 sc, const f32x4 sh) {
+    if constexpr (sizeof(T) == 2) {
+        const f32x2 x0 = f32x2{acc[0], acc[1]} * f32x2{sc[0], sc[1]} + f32x2{sh[0], sh[1]};
+        const f32x2 x1 = f32x2{acc[2], acc[3]} * f32x2{sc[2], sc[3]} + f32x2{sh[2], sh[3]};
+        const f32x2 t0 = x0 * -1.4426950408889634f, t1 = x1 * -1.4426950408889634f;
+        const f32x2 d0 = f32x2{__builtin_amdgcn_exp2f(t0[0]), __builtin_amdgcn_exp2f(t0[1])} + 1.0f;
+        const f32x2 d1 = f32x2{__builtin_amdgcn_exp2f(t1[0]), __builtin_amdgcn_exp2f(t1[1])} + 1.0f;
+        const f32x2 y0 = x0 * f32x2{__builtin_amdgcn_rcpf(d0[0]), __builtin_amdgcn_rcpf(d0[1])};
+        const f32x2 y1 = x1 * f32x2{__builtin_amdgcn_rcpf(d1[0]), __builtin_amdgcn_rcpf(d1[1])};
+        return f32x4{y0[0], y0[1], y1[0], y1[1]};
+    } else {
+        f32x4 y;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] = silu_f(acc[r] * sc[r] + sh[r]);
+        return y;
+    }
+}
+
 template <typename T> struct VecTraits;
 // 16-byte chunk = 4 floats or 8 bf16
 template <> struct VecTraits<float> { static constexpr int EPC = 4; };    // elements per 16-B chunk

@@ -271,9 +271,7 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
             for (int j = 0; j < SM_NJ; ++j) {
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(cpar + 16 * j + 4 * fpiece);
                 const f32x4 sh = *reinterpret_cast<const f32x4*>(cpar + SM_MC + 16 * j + 4 * fpiece);
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = silu_t<T>(acc[j][r] * sc[r] + sh[r]) * m;
+                const f32x4 v = bn_silu4<T>(acc[j], sc, sh) * m;
                 store4<T>(E + hp * EROW + 16 * j + 4 * fpiece, v[0], v[1], v[2], v[3]);
             }
         }
@@ -329,8 +327,9 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
                     for (int u = 0; u < UT; ++u) {
                         if (u == 1 && !second) break;
                         float o[4];
+                        const f32x4 ov = bn_silu4<T>(acc[u], s2v, t2v);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = to_f<T>(from_f<T>(silu_t<T>(acc[u][r] * s2v[r] + t2v[r])));   // SE averages what the next layer reads
+                        for (int r = 0; r < 4; ++r) o[r] = to_f<T>(from_f<T>(ov[r]));   // SE averages what the next layer reads
                         if (ok[u]) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) pl[r] += o[r];
@@ -548,10 +547,10 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void mbconv_deep_kernel(Mb
                     ei = (iy_lo - iy_top + r) * p.we + (hp - r * W) + p.pad_l;
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    store4<T>(E + ei * EROW + 16 * j + 4 * fpiece,
-                              silu_t<T>(acc[u][j][0] * sc[j][0] + sh[j][0]), silu_t<T>(acc[u][j][1] * sc[j][1] + sh[j][1]),
-                              silu_t<T>(acc[u][j][2] * sc[j][2] + sh[j][2]), silu_t<T>(acc[u][j][3] * sc[j][3] + sh[j][3]));
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = bn_silu4<T>(acc[u][j], sc[j], sh[j]);
+                    store4<T>(E + ei * EROW + 16 * j + 4 * fpiece, v[0], v[1], v[2], v[3]);
+                }
             }
         }
     }
@@ -609,8 +608,9 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void mbconv_deep_kernel(Mb
 #pragma unroll
                 for (int pr = 0; pr < NPAIR; ++pr) mma_chunk(afr[pr], ld_frag<T>(base + toff[pr]), acc);
                 float o[4];
+                const f32x4 ov = bn_silu4<T>(acc, s2v, t2v);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = to_f<T>(from_f<T>(silu_t<T>(acc[r] * s2v[r] + t2v[r])));
+                for (int r = 0; r < 4; ++r) o[r] = to_f<T>(from_f<T>(ov[r]));
                 if (qv && ch_ok) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pl[r] += o[r];

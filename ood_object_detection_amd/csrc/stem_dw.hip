@@ -190,9 +190,7 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(SdArgs p) {
             if (hp < SD_HP && ch < C) {
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(par + 9 * C + ch);
                 const f32x4 sh = *reinterpret_cast<const f32x4*>(par + 10 * C + ch);
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = silu_t<T>(acc[r] * sc[r] + sh[r]) * inside_m;   // a mask, not a branch per element
+                const f32x4 v = bn_silu4<T>(acc, sc, sh) * inside_m;                                // a mask, not a branch per element
                 if constexpr (sizeof(T) == 2) {
                     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                     *reinterpret_cast<bf16x4*>(E + hp * erow + ch) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
