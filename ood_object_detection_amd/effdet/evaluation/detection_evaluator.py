@@ -110,10 +110,22 @@ class ObjectDetectionEvaluator(object):
         gt_b, gt_c = self._pending_gt.pop(image_id, (torch.zeros(0, 4), torch.zeros(0, dtype=torch.int64)))
         self.add_batch(det, torch.tensor([n], dtype=torch.int32), gt_b[None], gt_c[None])
 
+    def _flush_pending(self):
+        """ground truth of images that never received detections still counts (the reference counts it when it is added,
+        object_detection_evaluation.py:87-139)"""
+        for image_id in list(self._pending_gt.keys()):
+            gt_b, gt_c = self._pending_gt.pop(image_id)
+            self._seen_det.add(image_id)
+            self.add_batch(torch.zeros(1, 1, 6), torch.zeros(1, dtype=torch.int32), gt_b[None], gt_c[None])
+
     def _compute(self):
         C, dev = self._num_classes, self.device
+        self._flush_pending()
         ap = torch.full((C,), float('nan'), dtype=torch.float64, device=dev)
         n = sum(t.numel() for t in self._scores)
+        if n > 65536:
+            raise RuntimeError('%d detections accumulated; effdet_eval_ap handles 65536 between clear() calls (the training loop '
+                               'clears every iteration, pretrain.py:223)' % n)
         if n:
             scores, classes, tp = torch.cat(self._scores).contiguous(), torch.cat(self._classes).contiguous(), torch.cat(self._tp).contiguous()
             nb = self.lib.effdet_eval_ap_workspace_bytes(n)

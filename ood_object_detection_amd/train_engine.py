@@ -33,6 +33,7 @@ class _Ops(object):
         self.lib = _lib.load()
         self.dev = device
         self._ws = None
+        self._retired = []
 
     def st(self):
         return torch.cuda.current_stream(self.dev).cuda_stream
@@ -45,6 +46,8 @@ class _Ops(object):
         if n < 0:
             raise RuntimeError('workspace query rejected its arguments')
         if self._ws is None or self._ws.numel() < n:
+            if self._ws is not None:
+                self._retired.append(self._ws)          # a captured hipGraph may still point at it: never hand it back
             self._ws = self.new(max(n, 1 << 20))
         return self._ws
 

@@ -651,3 +651,21 @@ def test_detection_evaluator_golden(golden, tag):
     ev.clear()
     m = ev.evaluate(names)
     assert np.isnan(m['Precision/mAP@0.5IOU'])
+    # ground truth of an image that never gets detections still counts in the recall denominator
+    from oracle import evaluation as oe
+    ev.clear()
+    ims = []
+    for i, im in enumerate(images):
+        ev.add_single_ground_truth_image_info(i, {'bbox': im['gt_boxes'], 'cls': im['gt_classes']})
+        if i % 2 == 0:
+            ev.add_single_detected_image_info(i, {'bbox': im['det_boxes'], 'scores': im['det_scores'], 'cls': im['det_classes']})
+            ims.append(dict(det_boxes=im['det_boxes'], det_scores=im['det_scores'], det_classes=im['det_classes'] - 1,
+                            gt_boxes=im['gt_boxes'], gt_classes=im['gt_classes'] - 1))
+        else:
+            ims.append(dict(det_boxes=np.zeros((0, 4), np.float32), det_scores=np.zeros(0, np.float32), det_classes=np.zeros(0, np.int64),
+                            gt_boxes=im['gt_boxes'], gt_classes=im['gt_classes'] - 1))
+    with np.errstate(all='ignore'):
+        r = oe.evaluate(ims, C)
+    m = ev.evaluate(names)
+    assert (np.isnan(r['mean_ap']) and np.isnan(m['Precision/mAP@0.5IOU'])) or abs(m['Precision/mAP@0.5IOU'] - r['mean_ap']) < 1e-12
+    assert np.allclose([m['AP@0.5IOU/c%d' % i] for i in range(C)], r['per_class_ap'], rtol=0, atol=1e-12, equal_nan=True)
