@@ -151,3 +151,36 @@ def test_pil_coefficient_tables_match_oracle(sizes):
     ob, ok = opre.pil_bilinear_coeffs(a, b)
     pb, pk = _pil_bilinear_tables(a, b)
     assert np.array_equal(ob, pb) and np.array_equal(ok, pk)
+
+
+def test_training_dispatch_and_no_cpu_fallback():
+    """EfficientDet.forward picks the differentiable path like the reference does implicitly (module in training mode + grad
+    mode + trainable parameters, pretrain.py:226-236) and that path, too, refuses to run on the CPU"""
+    import torch
+    from ood_object_detection_amd.effdet.factory import create_model
+    m = create_model('tf_efficientdet_d0', num_classes=5, image_size=(128, 128))
+    assert m.training and m.wants_autograd()
+    with torch.no_grad():
+        assert not m.wants_autograd()
+    m.eval()
+    assert not m.wants_autograd()
+    m.autograd = True
+    assert m.wants_autograd()
+    m.autograd = None
+    m.train()
+    for p in m.parameters():
+        p.requires_grad_(False)
+    assert not m.wants_autograd()
+    for p in m.parameters():
+        p.requires_grad_(True)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 128, 128), mode='bb')            # CPU tensors / CPU model: no fallback
+
+
+def test_pretrain_step_needs_gpu():
+    import torch
+    from ood_object_detection_amd.effdet.factory import create_model
+    from ood_object_detection_amd.pretrain import PretrainStep
+    m = create_model('tf_efficientdet_d0', num_classes=5, image_size=(128, 128))
+    with pytest.raises(RuntimeError):
+        PretrainStep(m)                                        # FlatAdam: float32 parameters on one GPU
