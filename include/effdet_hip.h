@@ -237,10 +237,10 @@ int effdet_weighted_median(void* stream, const float* embds, const float* confs,
 
 /* C[M,N] (+)= A[M,K] W[N,K]^T + bias[N] (bias may be NULL).  1x1-conv forward (replaces the nn.Conv2d(1x1) calls of
  * timm's blocks and effdet/efficientdet.py:42-83 in training), and its input gradient dX = dY W when W is passed
- * transposed. */
+ * transposed.  C2 (optional, addressed like C) receives silu(C): the pre-activation and the activation in one pass. */
 int effdet_train_gemm_nt(void* stream, const float* A, long long a_rpi, long long a_img_stride, long long a_ld,
                          const float* W, const float* bias, float* C, long long c_rpi, long long c_img_stride,
-                         long long c_ld, long long M, int K, int N, int accumulate);
+                         long long c_ld, long long M, int K, int N, int accumulate, float* C2);
 /* out[N][K+1] = dY[M,N]^T [X[M,K] | 1]: the 1x1-conv weight gradient in columns 0..K-1 and sum_m dY[m,n] (bias / BN
  * shift gradient) in column K (autograd of conv2d 1x1). */
 long long effdet_train_gemm_tn_workspace_floats(long long M, int N, int K);
@@ -262,12 +262,13 @@ int effdet_train_dwconv_bwd_dw(void* stream, const float* dY, const float* X, fl
  *  7 (a*s0)/s3 + (b*s1)/s3 [+ (c*s2)/s3]  (FpnCombine 'fastattn', effdet/efficientdet.py:240-242)   8 a*s0
  *  9 a*s0 + b*s1 [+ c*s2]
  * sdev (optional): device float[4] that replaces s0..s3 at run time, so that a captured hipGraph of the training step
- * sees the current BiFPN edge weights. */
+ * sees the current BiFPN edge weights.  out2 (optional): silu(out), written in the same pass. */
 int effdet_train_ew(void* stream, int op, float* out, const float* a, const float* b, const float* c,
                     const float* v0, const float* v1, const float* v2, const float* v3,
-                    float s0, float s1, float s2, float s3, long long n, int C, long long hw, const float* sdev);
+                    float s0, float s1, float s2, float s3, long long n, int C, long long hw, const float* sdev, float* out2);
 /* Per-channel reductions over the rows of dense [G][R][C] tensors -> out [G][C]:
- * mode 0 sum a; 1 sum a*b; 2 sum (a - v[c])^2; 3 sum a*(b - v[c]); every result is multiplied by alpha (1/M gives means). */
+ * mode 0 sum a; 1 sum a*b; 2 sum (a - v[c])^2; 3 sum a*(b - v[c]); 4: modes 0 and 3 in one pass, out [G][2][C];
+ * every result is multiplied by alpha (1/M gives means). */
 long long effdet_train_col_reduce_workspace_floats(int G, long long R, int C);
 int effdet_train_col_reduce(void* stream, int mode, const float* a, const float* b, const float* v,
                             int G, long long R, int C, float* out, float* workspace, long long workspace_floats, float alpha);

@@ -82,7 +82,7 @@ SIGNATURES = {
     'effdet_label_anchors': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_float, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_ll]),
     'effdet_train_gemm_nt': (c_int, [c_void_p, c_void_p, c_ll, c_ll, c_ll, c_void_p, c_void_p, c_void_p, c_ll, c_ll, c_ll,
-                                     c_ll, c_int, c_int, c_int]),
+                                     c_ll, c_int, c_int, c_int, c_void_p]),
     'effdet_train_gemm_tn_workspace_floats': (c_ll, [c_ll, c_int, c_int]),
     'effdet_train_gemm_tn': (c_int, [c_void_p, c_void_p, c_ll, c_ll, c_ll, c_void_p, c_ll, c_ll, c_ll, c_ll, c_int, c_int,
                                      c_void_p, c_void_p, c_ll]),
@@ -92,7 +92,7 @@ SIGNATURES = {
     'effdet_train_dwconv_bwd_dw': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                            c_void_p, c_ll]),
     'effdet_train_ew': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                c_float, c_float, c_float, c_float, c_ll, c_int, c_ll, c_void_p]),
+                                c_float, c_float, c_float, c_float, c_ll, c_int, c_ll, c_void_p, c_void_p]),
     'effdet_train_col_reduce_workspace_floats': (c_ll, [c_int, c_ll, c_int]),
     'effdet_train_col_reduce': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_ll, c_int, c_void_p, c_void_p, c_ll, c_float]),
     'effdet_train_spatial': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),

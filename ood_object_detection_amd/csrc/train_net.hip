@@ -37,6 +37,7 @@ inline RowMap make_rowmap(long long rpi, long long img_stride, long long ld, lon
 struct GemmNtArgs {
     const float* A; RowMap am; const float* W; const float* bias; float* C; RowMap cm;
     long long M; int K, N, accumulate, vec_out;
+    float* C2;                                 // optional second output with the row map of C: silu(C)
 };
 
 template <bool VEC>
@@ -83,7 +84,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
         for (int t = 0; t < 4; ++t) mma_chunk(a[t], b, acc[t]);
     }
     if (!mv) return;
-    float* crow = p.C + row_off(p.cm, m0 + r16);
+    const long long coff = row_off(p.cm, m0 + r16);
+    float* crow = p.C + coff;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int n = n0 + 16 * t + 4 * g;
@@ -93,6 +95,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
                 if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
                 if (p.accumulate) v += *reinterpret_cast<const f32x4*>(crow + n);
                 *reinterpret_cast<f32x4*>(crow + n) = v;
+                if (p.C2) {
+                    f32x4 q;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) q[r] = silu_f(v[r]);
+                    *reinterpret_cast<f32x4*>(p.C2 + coff + n) = q;
+                }
             }
             continue;
         }
@@ -103,6 +111,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
                 if (p.bias) v += p.bias[n + r];
                 if (p.accumulate) v += crow[n + r];
                 crow[n + r] = v;
+                if (p.C2) p.C2[coff + n + r] = silu_f(v);
             }
         }
     }
@@ -116,9 +125,15 @@ struct GemmTnArgs {
     long long M, rows_per_slice; int N, K, S;
 };
 
+// 32 rows of dY [32 n] and X [64 k] per step are staged in LDS with 16-byte global loads (rows padded to 48 / 80 floats:
+// the two 16-lane groups of a half-wave land on disjoint banks), then every wave feeds 8 of those rows to the matrix cores.
+template <bool VY, bool VX>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
+    constexpr int RT = 32, SY = 48, SX = 80;
+    __shared__ float sY[RT * SY];
+    __shared__ float sX[RT * SX];
     __shared__ float sm[4][32 * 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 64;
     const long long mb = (long long)blockIdx.z * p.rows_per_slice;
@@ -130,27 +145,55 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int Kx = p.K + 1;
-    for (long long mm = mb + wave * 4; mm < me; mm += 16) {
-        const long long m = mm + g;
-        const bool valid = m < me;
-        const float* yrow = p.dY + (valid ? row_off(p.ym, m) : 0);
-        const float* xrow = p.X + (valid ? row_off(p.xm, m) : 0);
-        float a[2], b[4];
+    const int yr = tid >> 3, yc = (tid & 7) * 4;             // dY piece of this thread: row yr, columns yc..yc+3
+    const int xr = tid >> 4, xc = (tid & 15) * 4;            // X pieces: rows xr and xr + 16, columns xc..xc+3
+    for (long long m0 = mb; m0 < me; m0 += RT) {
+        f32x4 vy = f32x4{0.f, 0.f, 0.f, 0.f}, vx[2];
+        {
+            const long long m = m0 + yr;
+            if (m < me) {
+                const float* row = p.dY + row_off(p.ym, m);
+                const int n = n0 + yc;
+                if (VY && n + 3 < p.N) vy = *reinterpret_cast<const f32x4*>(row + n);
+                else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int n = n0 + 16 * i + c16;
-            a[i] = (valid && n < p.N) ? yrow[n] : 0.f;
+                    for (int e = 0; e < 4; ++e) vy[e] = n + e < p.N ? row[n + e] : 0.f;
+                }
+            }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int kk = k0 + 16 * j + c16;
-            b[j] = !valid ? 0.f : (kk < p.K ? xrow[kk] : (kk == p.K ? 1.f : 0.f));
+        for (int h = 0; h < 2; ++h) {
+            vx[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const long long m = m0 + xr + 16 * h;
+            if (m < me) {
+                const float* row = p.X + row_off(p.xm, m);
+                const int kk = k0 + xc;
+                if (VX && kk + 3 < p.K) vx[h] = *reinterpret_cast<const f32x4*>(row + kk);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vx[h][e] = kk + e < p.K ? row[kk + e] : (kk + e == p.K ? 1.f : 0.f);
+                }
+            }
         }
+        __syncthreads();                                      // the previous step's operands have been consumed
+        *reinterpret_cast<f32x4*>(sY + yr * SY + yc) = vy;
+        *reinterpret_cast<f32x4*>(sX + xr * SX + xc) = vx[0];
+        *reinterpret_cast<f32x4*>(sX + (xr + 16) * SX + xc) = vx[1];
+        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int st = 0; st < 2; ++st) {
+            const int r = 8 * wave + 4 * st + g;
+            float a[2], b[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 2; ++i) a[i] = sY[r * SY + 16 * i + c16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = sX[r * SX + 16 * j + c16];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
     }
     // D[row = n local (4g + r)][col = k local (c16)]
 #pragma unroll
@@ -327,6 +370,7 @@ struct EwArgs {
     const float* v0; const float* v1; const float* v2; const float* v3;
     float s0, s1, s2, s3; long long n; int C; long long hwC;
     const float* sdev;                         // optional device float[4] overriding s0..s3 (graph-capturable steps)
+    float* out2;                               // optional second output: silu(out)
 };
 
 DEV float silu_grad(float z) { const float s = sigmoid_f(z); return s * (1.0f + z * (1.0f - s)); }
@@ -390,6 +434,12 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs p) {
         break; }
     }
     *reinterpret_cast<f32x4*>(p.out + i) = o;
+    if (p.out2) {
+        f32x4 q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = silu_f(o[j]);
+        *reinterpret_cast<f32x4*>(p.out2 + i) = q;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -399,9 +449,10 @@ struct ColArgs {
     int mode; const float* a; const float* b; const float* v; float* partial;
     long long R, rows_per_slice; int C, S;
 };
-// modes: 0 sum a; 1 sum a*b; 2 sum (a - v[c])^2; 3 sum a*(b - v[c])
+// modes: 0 sum a; 1 sum a*b; 2 sum (a - v[c])^2; 3 sum a*(b - v[c]); 4: both 0 and 3 in one pass (out [G][2][C])
 __global__ __launch_bounds__(256) void col_reduce_kernel(ColArgs p) {
     __shared__ float sm[4][64];
+    __shared__ float sm2[4][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + cl;
     const int gi = blockIdx.z, s = blockIdx.x;
@@ -409,7 +460,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(ColArgs p) {
     const long long rb = (long long)s * p.rows_per_slice;
     long long re = rb + p.rows_per_slice;
     if (re > p.R) re = p.R;
-    float acc = 0.f;
+    float acc = 0.f, acc2 = 0.f;
     if (cv) {
         const float vc = (p.mode >= 2) ? p.v[c] : 0.f;
         const long long base = (long long)gi * p.R * p.C + c;
@@ -418,13 +469,19 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(ColArgs p) {
             if (p.mode == 0) acc += a;
             else if (p.mode == 1) acc += a * p.b[base + r * p.C];
             else if (p.mode == 2) { const float d = a - vc; acc += d * d; }
-            else acc += a * (p.b[base + r * p.C] - vc);
+            else if (p.mode == 3) acc += a * (p.b[base + r * p.C] - vc);
+            else { acc += a; acc2 += a * (p.b[base + r * p.C] - vc); }
         }
     }
     sm[rl][cl] = acc;
+    sm2[rl][cl] = acc2;
     __syncthreads();
-    if (rl == 0 && cv)
-        p.partial[((long long)gi * p.S + s) * p.C + c] = ((sm[0][cl] + sm[1][cl]) + sm[2][cl]) + sm[3][cl];
+    if (rl == 0 && cv) {
+        const int W = p.mode == 4 ? 2 : 1;
+        float* dst = p.partial + ((long long)gi * p.S + s) * W * p.C + c;
+        dst[0] = ((sm[0][cl] + sm[1][cl]) + sm[2][cl]) + sm[3][cl];
+        if (W == 2) dst[p.C] = ((sm2[0][cl] + sm2[1][cl]) + sm2[2][cl]) + sm2[3][cl];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -668,11 +725,11 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(BnBwdArgs p) {
 // ================================================================================================================
 extern "C" int effdet_train_gemm_nt(void* stream, const float* A, long long a_rpi, long long a_img_stride, long long a_ld,
                                     const float* W, const float* bias, float* C, long long c_rpi, long long c_img_stride,
-                                    long long c_ld, long long M, int K, int N, int accumulate) {
+                                    long long c_ld, long long M, int K, int N, int accumulate, float* C2) {
     EFFDET_ENTER();
     if (!A || !W || !C || M <= 0 || K <= 0 || N <= 0) return EFFDET_EINVAL;
     GemmNtArgs p;
-    p.A = A; p.W = W; p.bias = bias; p.C = C; p.M = M; p.K = K; p.N = N; p.accumulate = accumulate;
+    p.A = A; p.W = W; p.bias = bias; p.C = C; p.M = M; p.K = K; p.N = N; p.accumulate = accumulate; p.C2 = C2;
     p.am = make_rowmap(a_rpi, a_img_stride, a_ld, M, K);
     p.cm = make_rowmap(c_rpi, c_img_stride, c_ld, M, N);
     const long long gx = (M + 63) / 64;
@@ -680,7 +737,8 @@ extern "C" int effdet_train_gemm_nt(void* stream, const float* A, long long a_rp
     const bool vec = K % 4 == 0 && p.am.ld % 4 == 0 && p.am.img_stride % 4 == 0 &&
                      reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(W) % 16 == 0;
     p.vec_out = N % 4 == 0 && p.cm.ld % 4 == 0 && p.cm.img_stride % 4 == 0 && reinterpret_cast<uintptr_t>(C) % 16 == 0 &&
-                (bias == nullptr || reinterpret_cast<uintptr_t>(bias) % 16 == 0);
+                (bias == nullptr || reinterpret_cast<uintptr_t>(bias) % 16 == 0) &&
+                (C2 == nullptr || reinterpret_cast<uintptr_t>(C2) % 16 == 0);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)gx, (unsigned)((N + 63) / 64));
     if (vec) hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), 0, st, p);
@@ -717,11 +775,16 @@ extern "C" int effdet_train_gemm_tn(void* stream, const float* dY, long long y_r
     p.ym = make_rowmap(y_rpi, y_img_stride, y_ld, M, N);
     p.xm = make_rowmap(x_rpi, x_img_stride, x_ld, M, K);
     long long rps = (M + S - 1) / S;
-    rps = (rps + 15) / 16 * 16;
+    rps = (rps + 31) / 32 * 32;
     p.rows_per_slice = rps;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((N + 31) / 32), (unsigned)((K + 1 + 63) / 64), (unsigned)S);
-    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, st, p);
+    const bool vy = p.ym.ld % 4 == 0 && p.ym.img_stride % 4 == 0 && reinterpret_cast<uintptr_t>(dY) % 16 == 0;
+    const bool vx = p.xm.ld % 4 == 0 && p.xm.img_stride % 4 == 0 && reinterpret_cast<uintptr_t>(X) % 16 == 0;
+    if (vy && vx) hipLaunchKernelGGL((gemm_tn_kernel<true, true>), grid, dim3(256), 0, st, p);
+    else if (vx) hipLaunchKernelGGL((gemm_tn_kernel<false, true>), grid, dim3(256), 0, st, p);
+    else if (vy) hipLaunchKernelGGL((gemm_tn_kernel<true, false>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_tn_kernel<false, false>), grid, dim3(256), 0, st, p);
     int rc = effdet_check_launch();
     if (rc) return rc;
     return launch_reduce_mid(st, workspace, 1, S, (long long)N * (K + 1), out, 0);
@@ -797,7 +860,7 @@ extern "C" int effdet_train_dwconv_bwd_dw(void* stream, const float* dY, const f
 
 extern "C" int effdet_train_ew(void* stream, int op, float* out, const float* a, const float* b, const float* c,
                                const float* v0, const float* v1, const float* v2, const float* v3,
-                               float s0, float s1, float s2, float s3, long long n, int C, long long hw, const float* sdev) {
+                               float s0, float s1, float s2, float s3, long long n, int C, long long hw, const float* sdev, float* out2) {
     EFFDET_ENTER();
     if (!out || !a || n <= 0 || n % 4 || C <= 0 || C % 4 || op < 0 || op > 9) return EFFDET_EINVAL;
     const bool need_b = op == 1 || op == 2 || op == 6 || op == 7 || op == 9;
@@ -807,7 +870,7 @@ extern "C" int effdet_train_ew(void* stream, int op, float* out, const float* a,
     if (op == 6 && (!v2 || !v3)) return EFFDET_EINVAL;
     if ((op == 4 || op == 5) && hw <= 0) return EFFDET_EINVAL;
     if (op == 7 && s3 == 0.f && !sdev) return EFFDET_EINVAL;
-    EwArgs p{op, out, a, b, c, v0, v1, v2, v3, s0, s1, s2, s3, n, C, (hw > 0 ? hw : 1) * C, sdev};
+    EwArgs p{op, out, a, b, c, v0, v1, v2, v3, s0, s1, s2, s3, n, C, (hw > 0 ? hw : 1) * C, sdev, out2};
     const long long blocks = (n / 4 + 255) / 256;
     if (blocks > 0x7fffffffLL) return EFFDET_EINVAL;
     hipLaunchKernelGGL(ew_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
@@ -829,24 +892,25 @@ static int col_slices(int G, long long R, int C, long long* rps) {
 extern "C" long long effdet_train_col_reduce_workspace_floats(int G, long long R, int C) {
     if (G <= 0 || R <= 0 || C <= 0) return EFFDET_EINVAL;
     long long rps;
-    return (long long)col_slices(G, R, C, &rps) * G * C;
+    return (long long)col_slices(G, R, C, &rps) * G * C * 2;          // mode 4 keeps two sums per slice
 }
 
 extern "C" int effdet_train_col_reduce(void* stream, int mode, const float* a, const float* b, const float* v,
                                        int G, long long R, int C, float* out, float* workspace, long long workspace_floats, float alpha) {
     EFFDET_ENTER();
-    if (!a || !out || !workspace || G <= 0 || G > 65535 || R <= 0 || C <= 0 || mode < 0 || mode > 3) return EFFDET_EINVAL;
-    if ((mode == 1 || mode == 3) && !b) return EFFDET_EINVAL;
+    if (!a || !out || !workspace || G <= 0 || G > 65535 || R <= 0 || C <= 0 || mode < 0 || mode > 4) return EFFDET_EINVAL;
+    if ((mode == 1 || mode >= 3) && !b) return EFFDET_EINVAL;
     if (mode >= 2 && !v) return EFFDET_EINVAL;
     long long rps;
     const int S = col_slices(G, R, C, &rps);
-    if (workspace_floats < (long long)S * G * C) return EFFDET_EINVAL;
+    const int Wd = mode == 4 ? 2 : 1;
+    if (workspace_floats < (long long)S * G * C * Wd) return EFFDET_EINVAL;
     ColArgs p{mode, a, b, v, workspace, R, rps, C, S};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)S, (unsigned)((C + 63) / 64), (unsigned)G), dim3(256), 0, st, p);
     int rc = effdet_check_launch();
     if (rc) return rc;
-    return launch_reduce_mid(st, workspace, G, S, C, out, 0, alpha);
+    return launch_reduce_mid(st, workspace, G, S, (long long)C * Wd, out, 0, alpha);
 }
 
 extern "C" int effdet_train_spatial(void* stream, int op, const float* in, const float* aux, float* out,

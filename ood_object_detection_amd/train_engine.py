@@ -52,8 +52,8 @@ class _Ops(object):
         return self._ws
 
     # ---- GEMMs ----------------------------------------------------------------------------------
-    def gemm_nt(self, A, W, bias=None, M=None, a_map=None, out=None, c_map=None):
-        """A [M,K] (dense, or a (ptr, rpi, img_stride, ld) map) x W[N,K]^T + bias -> out [M,N]."""
+    def gemm_nt(self, A, W, bias=None, M=None, a_map=None, out=None, c_map=None, silu_out=False):
+        """A [M,K] (dense, or a (ptr, rpi, img_stride, ld) map) x W[N,K]^T + bias -> out [M,N] (and silu(out) when asked)."""
         N, K = W.shape
         if a_map is None:
             M = A.numel() // K
@@ -65,10 +65,11 @@ class _Ops(object):
             cp, cm = out.data_ptr(), (0, 0, 0)
         else:
             cp, cm = c_map[0], c_map[1:]
+        out2 = self.new(M, N) if silu_out else None
         _lib.check(self.lib.effdet_train_gemm_nt(self.st(), ap, am[0], am[1], am[2], W.data_ptr(),
-                                                 None if bias is None else bias.data_ptr(), cp, cm[0], cm[1], cm[2], M, K, N, 0),
-                   'effdet_train_gemm_nt')
-        return out
+                                                 None if bias is None else bias.data_ptr(), cp, cm[0], cm[1], cm[2], M, K, N, 0,
+                                                 None if out2 is None else out2.data_ptr()), 'effdet_train_gemm_nt')
+        return (out, out2) if silu_out else out
 
     def gemm_tn(self, dY, X, N, K, M=None, y_map=None, x_map=None):
         """-> (dW [N,K], dsum [N]) = dY^T [X | 1]"""
@@ -110,14 +111,16 @@ class _Ops(object):
         return dx, out[:k * k], out[k * k]
 
     # ---- element-wise ---------------------------------------------------------------------------
-    def ew(self, op, a, b=None, c=None, v=(None, None, None, None), s=(0.0, 0.0, 0.0, 0.0), hw=0, sdev=None):
-        """sdev: device float[4] replacing the scalars s (no host read-back: the step stays graph-capturable)"""
+    def ew(self, op, a, b=None, c=None, v=(None, None, None, None), s=(0.0, 0.0, 0.0, 0.0), hw=0, sdev=None, silu_out=False):
+        """sdev: device float[4] replacing the scalars s (no host read-back: the step stays graph-capturable);
+        silu_out: also return silu(result), produced in the same pass"""
         out = torch.empty_like(a)
+        out2 = torch.empty_like(a) if silu_out else None
         C = a.shape[-1]
         p = lambda t: None if t is None else t.data_ptr()
         _lib.check(self.lib.effdet_train_ew(self.st(), op, out.data_ptr(), a.data_ptr(), p(b), p(c), p(v[0]), p(v[1]), p(v[2]), p(v[3]),
-                                            s[0], s[1], s[2], s[3], a.numel(), C, hw, p(sdev)), 'effdet_train_ew(%d)' % op)
-        return out
+                                            s[0], s[1], s[2], s[3], a.numel(), C, hw, p(sdev), p(out2)), 'effdet_train_ew(%d)' % op)
+        return (out, out2) if silu_out else out
 
     def silu(self, z):
         return self.ew(0, z)
@@ -135,7 +138,7 @@ class _Ops(object):
         R = a.numel() // (C * G)
         n = self.lib.effdet_train_col_reduce_workspace_floats(G, R, C)
         ws = self.ws(n)
-        out = self.new(G, C)
+        out = self.new(G, 2, C) if mode == 4 else self.new(G, C)
         _lib.check(self.lib.effdet_train_col_reduce(self.st(), mode, a.data_ptr(), None if b is None else b.data_ptr(),
                                                     None if v is None else v.data_ptr(), G, R, C, out.data_ptr(),
                                                     ws.data_ptr(), ws.numel(), alpha), 'effdet_train_col_reduce')
@@ -238,8 +241,8 @@ class TrainEngine(object):
         grads[gn] = dgb[0]
         grads[bn_] = dgb[1]
 
-    def _pw_bneval_fwd(self, x, conv, bn, names):
-        """1x1 conv (no bias) + BN with running statistics, folded: z = x (scale*W)^T + shift."""
+    def _pw_bneval_fwd(self, x, conv, bn, names, silu_out=False):
+        """1x1 conv (no bias) + BN with running statistics, folded: z = x (scale*W)^T + shift (and a = silu(z) when asked)."""
         if bn.training:
             raise NotImplementedError('backbone BatchNorm in batch-statistics mode is not built: put the backbone BN in eval '
                                       'mode as pretrain.py:168-176 does (model.backbone.apply(set_bn_eval))')
@@ -247,8 +250,11 @@ class TrainEngine(object):
         W = conv.weight.detach().reshape(N, -1)
         Wf, WfT, _, scale, shift, rstd = self._fold(W, bn, True, True, False)
         B, H, Wd, K = x.shape
-        z = self.ops.gemm_nt(x, Wf, shift).view(B, H, Wd, N)
-        return z, dict(x=x, W=W, Wf=Wf, WfT=WfT, mean=bn.running_mean, rstd=rstd, scale=scale, names=names, wshape=conv.weight.shape)
+        rec = dict(x=x, W=W, Wf=Wf, WfT=WfT, mean=bn.running_mean, rstd=rstd, scale=scale, names=names, wshape=conv.weight.shape)
+        if silu_out:
+            z, a = self.ops.gemm_nt(x, Wf, shift, silu_out=True)
+            return (z.view(B, H, Wd, N), a.view(B, H, Wd, N)), rec
+        return self.ops.gemm_nt(x, Wf, shift).view(B, H, Wd, N), rec
 
     def _pw_bneval_bwd(self, rec, dz, grads, need_dx=True):
         N, K = rec['Wf'].shape
@@ -275,8 +281,9 @@ class TrainEngine(object):
         self._convbn_grads(rec, dtaps._base, True, grads)
         return dx
 
-    def _bn_fwd(self, c, bn, prefix):
-        """BatchNorm2d on a raw conv output c [..., C] following bn.training (batch vs running statistics)."""
+    def _bn_fwd(self, c, bn, prefix, silu_out=False):
+        """BatchNorm2d on a raw conv output c [..., C] following bn.training (batch vs running statistics);
+        silu_out: returns ((y, silu(y)), record)."""
         C = c.shape[-1]
         M = c.numel() // C
         ops = self.ops
@@ -293,7 +300,7 @@ class TrainEngine(object):
                                                      float(M / max(M - 1, 1)), float(bn.eps), vec[0].data_ptr(), vec[1].data_ptr(),
                                                      vec[2].data_ptr()), 'effdet_train_bn_finalize')
         scale, shift, rstd = vec[0], vec[1], vec[2]
-        y = ops.ew(3, c, v=(scale, shift, None, None))
+        y = ops.ew(3, c, v=(scale, shift, None, None), silu_out=silu_out)
         if not bn.training:
             mean = mean.clone()                 # the record must not alias a buffer a later load_state_dict may overwrite
         return y, dict(c=c, mean=mean, rstd=rstd, scale=scale, train=bn.training, M=M, prefix=prefix)
@@ -302,8 +309,8 @@ class TrainEngine(object):
         c, mean, rstd = rec['c'], rec['mean'], rec['rstd']
         ops = self.ops
         C = c.shape[-1]
-        s1 = ops.col_reduce(0, dy)
-        s2c = ops.col_reduce(3, dy, c, v=mean)
+        both = ops.col_reduce(4, dy, c, v=mean)                # [2, C]: sum(dy), sum(dy * (c - mean)) in one pass over dy
+        s1, s2c = both[0], both[1]
         out = ops.new(4, C)
         _lib.check(self.lib.effdet_train_bn_bwd_prep(ops.st(), s1.data_ptr(), s2c.data_ptr(), rstd.data_ptr(), C, 1.0 / rec['M'],
                                                      out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr()),
@@ -423,10 +430,9 @@ class TrainEngine(object):
         sc = _StemConv()
         w = bb.conv_stem.weight.detach().permute(0, 2, 3, 1).reshape(stem_c, 27)
         sc.weight = torch.cat([w, w.new_zeros(stem_c, 5)], 1)
-        z0, rec = self._pw_bneval_fwd(col, sc, bb.bn1, ('conv_stem.weight', 'bn1.weight', 'bn1.bias'))
+        (z0, cur), rec = self._pw_bneval_fwd(col, sc, bb.bn1, ('conv_stem.weight', 'bn1.weight', 'bn1.bias'), silu_out=True)
         rec['wshape'] = (stem_c, 32)
         saved['stem'] = (rec, z0)
-        cur = ops.silu(z0)
         feats = []
         for si, blocks in enumerate(stages):
             for bi, b in enumerate(blocks):
@@ -434,9 +440,9 @@ class TrainEngine(object):
                 p = 'blocks.%d.%d.' % (si, bi)
                 r = dict(b=b, p=p, x=cur)
                 if b['type'] == 'ir':
-                    z1, r['pw'] = self._pw_bneval_fwd(cur, m.conv_pw, m.bn1, (p + 'conv_pw.weight', p + 'bn1.weight', p + 'bn1.bias'))
+                    (z1, a1), r['pw'] = self._pw_bneval_fwd(cur, m.conv_pw, m.bn1, (p + 'conv_pw.weight', p + 'bn1.weight', p + 'bn1.bias'),
+                                                            silu_out=True)
                     r['z1'] = z1
-                    a1 = ops.silu(z1)
                     z2, r['dw'] = self._dw_bneval_fwd(a1, m.conv_dw, m.bn2, b['k'], b['s'],
                                                       (p + 'conv_dw.weight', p + 'bn2.weight', p + 'bn2.bias'))
                     proj, bnp, pn = m.conv_pwl, m.bn3, (p + 'conv_pwl.weight', p + 'bn3.weight', p + 'bn3.bias')
@@ -568,18 +574,17 @@ class TrainEngine(object):
                     wv = torch.relu(ew_param.detach())                            # efficientdet.py:238-242
                     den = wv.sum() + 0.0001
                     sdev = torch.cat([wv, wv.new_zeros(3 - n_in), den.reshape(1)]).contiguous()
-                    fused = ops.ew(7, ins[0], ins[1], third, sdev=sdev)
+                    fused, act = ops.ew(7, ins[0], ins[1], third, sdev=sdev, silu_out=True)
                 elif method == 'attn':
                     wv = torch.softmax(ew_param.detach(), 0)
                     den = wv.new_ones(())
                     sdev = torch.cat([wv, wv.new_zeros(3 - n_in), den.reshape(1)]).contiguous()
-                    fused = ops.ew(9, ins[0], ins[1], third, sdev=sdev)
+                    fused, act = ops.ew(9, ins[0], ins[1], third, sdev=sdev, silu_out=True)
                 else:
                     wv = torch.ones(n_in, dtype=torch.float32, device=self.dev)
                     den = wv.new_ones(())
                     sdev = torch.cat([wv, wv.new_zeros(3 - n_in), den.reshape(1)]).contiguous()
-                    fused = ops.ew(9, ins[0], ins[1], third, sdev=sdev)
-                act = ops.silu(fused)
+                    fused, act = ops.ew(9, ins[0], ins[1], third, sdev=sdev, silu_out=True)
                 sc = fn.after_combine.conv
                 d, rdw = self._dw_fwd(act, sc.conv_dw, p + 'after_combine.conv.conv_dw.')
                 c, rpw = self._pw_fwd(d, sc.conv_pw, p + 'after_combine.conv.conv_pw.')
@@ -622,8 +627,7 @@ class TrainEngine(object):
                     conv = head.conv_rep[r]
                     d, rdw = self._dw_fwd(t, conv.conv_dw, '%sconv_rep.%d.conv_dw.' % (name, r))
                     c, rpw = self._pw_fwd(d, conv.conv_pw, '%sconv_rep.%d.conv_pw.' % (name, r))
-                    y, rbn = self._bn_fwd(c, head.bn_rep[r][l].bn, '%sbn_rep.%d.%d.bn.' % (name, r, l))
-                    t = ops.silu(y)
+                    (y, t), rbn = self._bn_fwd(c, head.bn_rep[r][l].bn, '%sbn_rep.%d.%d.bn.' % (name, r, l), silu_out=True)
                     lrec['reps'].append((rdw, rpw, rbn, y))
                 d, rdw = self._dw_fwd(t, head.predict.conv_dw, name + 'predict.conv_dw.')
                 cmap = (out_t.data_ptr() + offs[l] * NO * 4, h * w, P * NO, NO)

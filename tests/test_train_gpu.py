@@ -133,6 +133,10 @@ def test_col_reduce_modes():
     _close(ops.col_reduce(2, ad, v=vd), ((A2 - v.double()) ** 2).sum(0), 1e-5, 'centred sumsq')
     _close(ops.col_reduce(3, ad, bd, v=vd), (A2 * (B2 - v.double())).sum(0), 1e-5, 'centred dot')
     _close(ops.col_reduce(1, ad, bd, per_image=True), (a.double() * b.double()).sum(1), 1e-5, 'per-image dot')
+    both = ops.col_reduce(4, ad, bd, v=vd)
+    _close(both[0], A2.sum(0), 1e-5, 'fused sum')
+    _close(both[1], (A2 * (B2 - v.double())).sum(0), 1e-5, 'fused centred dot')
+    _close(ops.col_reduce(0, ad, alpha=0.5), 0.5 * A2.sum(0), 1e-5, 'alpha')
     # bitwise reproducible
     assert torch.equal(ops.col_reduce(1, ad, bd), ops.col_reduce(1, ad, bd))
 
