@@ -241,8 +241,8 @@ int effdet_weighted_median(void* stream, const float* embds, const float* confs,
 int effdet_train_gemm_nt(void* stream, const float* A, long long a_rpi, long long a_img_stride, long long a_ld,
                          const float* W, const float* bias, float* C, long long c_rpi, long long c_img_stride,
                          long long c_ld, long long M, int K, int N, int accumulate, float* C2);
-/* out[N][K+1] = dY[M,N]^T [X[M,K] | 1]: the 1x1-conv weight gradient in columns 0..K-1 and sum_m dY[m,n] (bias / BN
- * shift gradient) in column K (autograd of conv2d 1x1). */
+/* dY[M,N]^T [X[M,K] | 1] in one pass: out = the 1x1-conv weight gradient as a dense [N][K] matrix followed by the N sums
+ * sum_m dY[m,n] (bias / BN shift gradient); out holds N*K + N floats (autograd of conv2d 1x1). */
 long long effdet_train_gemm_tn_workspace_floats(long long M, int N, int K);
 int effdet_train_gemm_tn(void* stream, const float* dY, long long y_rpi, long long y_img_stride, long long y_ld,
                          const float* X, long long x_rpi, long long x_img_stride, long long x_ld,
@@ -286,8 +286,8 @@ int effdet_train_se_bwd(void* stream, const float* pool_sum, int hw, const float
 
 /* Parameter-sized helpers of conv + BatchNorm on running statistics (one launch each instead of a dozen tensor ops):
  * fold: scale = gamma / sqrt(var + eps), shift = beta - mean * scale, rstd; Wf [N][K] = W * scale[n], WfT [K][N] = Wf^T,
- * WT [K][N] = W^T (each matrix optional).  grads: from dWext = effdet_train_gemm_tn's [N][K+1] (or the depthwise
- * [(K+1)][N] layout when transposed != 0): dW [N][K] = scale * dWraw, d gamma = rstd * (sum_k W * dWraw - mean * dsum),
+ * WT [K][N] = W^T (each matrix optional).  grads: from dWext = effdet_train_gemm_tn's output ([N][K] then N sums; or the
+ * depthwise [(K+1)][N] layout when transposed != 0): dW [N][K] = scale * dWraw, d gamma = rstd * (sum_k W * dWraw - mean * dsum),
  * d beta = dsum. */
 int effdet_train_fold_bn(void* stream, const float* W, int N, int K, const float* gamma, const float* beta,
                          const float* mean, const float* var, float eps,

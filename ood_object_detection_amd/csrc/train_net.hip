@@ -242,6 +242,37 @@ __global__ __launch_bounds__(256) void reduce_mid_kernel(ReduceMidArgs p) {
     }
 }
 
+// second stage of the weight-gradient GEMM: partial [S][N][K+1] -> dense dW [N][K] followed by dsum [N] (same fixed
+// summation order as reduce_mid_kernel)
+struct ReduceSplitArgs { const float* in; float* out; int N, K, S; };
+__global__ __launch_bounds__(256) void reduce_split_kernel(ReduceSplitArgs p) {
+    __shared__ float sm[16][17];
+    const int li = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const long long L = (long long)p.N * (p.K + 1);
+    const long long l = (long long)blockIdx.x * 16 + li;
+    float s = 0.f;
+    if (l < L) {
+        const float* src = p.in + l;
+        int i = sl;
+        for (; i + 48 < p.S; i += 64) {
+            const float a0 = src[(long long)i * L], a1 = src[(long long)(i + 16) * L];
+            const float a2 = src[(long long)(i + 32) * L], a3 = src[(long long)(i + 48) * L];
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; i < p.S; i += 16) s += src[(long long)i * L];
+    }
+    sm[sl][li] = s;
+    __syncthreads();
+    if (sl == 0 && l < L) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += sm[j][li];
+        const long long n = l / (p.K + 1);
+        const int kk = (int)(l - n * (p.K + 1));
+        if (kk < p.K) p.out[n * p.K + kk] = t; else p.out[(long long)p.N * p.K + n] = t;
+    }
+}
+
 int launch_reduce_mid(hipStream_t st, const float* in, int G, int S, long long L, float* out, int accumulate, float alpha = 1.0f) {
     ReduceMidArgs a{in, out, L, G, S, accumulate, alpha};
     const long long blocks = (L + 15) / 16;
@@ -660,14 +691,14 @@ struct FinArgs {
     float* dW; float* dgamma; float* dbeta;
 };
 // z = scale * conv(x; W) + shift, dWraw = dz^T x, dsum = sum dz  ->  dW = scale * dWraw,
-// d gamma = rstd * (sum_k W * dWraw - mean * dsum), d beta = dsum.   dWext: [N][K+1] (or [(K+1)][N] when transposed).
+// d gamma = rstd * (sum_k W * dWraw - mean * dsum), d beta = dsum.   dWext: [N][K] then [N] sums (or [(K+1)][N] when transposed).
 __global__ __launch_bounds__(256) void convbn_grads_kernel(FinArgs p) {
     __shared__ float sm[4];
     const int n = blockIdx.x;
     const float sc = p.scale[n];
     float acc = 0.f;
     for (int k = threadIdx.x; k < p.K; k += 256) {
-        const float v = p.transposed ? p.dWext[(long long)k * p.N + n] : p.dWext[(long long)n * (p.K + 1) + k];
+        const float v = p.transposed ? p.dWext[(long long)k * p.N + n] : p.dWext[(long long)n * p.K + k];
         p.dW[(long long)n * p.K + k] = sc * v;
         acc += p.W[(long long)n * p.K + k] * v;
     }
@@ -676,7 +707,7 @@ __global__ __launch_bounds__(256) void convbn_grads_kernel(FinArgs p) {
     __syncthreads();
     if (threadIdx.x == 0) {
         const float tot = ((sm[0] + sm[1]) + sm[2]) + sm[3];
-        const float dsum = p.transposed ? p.dWext[(long long)p.K * p.N + n] : p.dWext[(long long)n * (p.K + 1) + p.K];
+        const float dsum = p.dWext[(long long)p.K * p.N + n];      // both layouts keep the N sums behind the N*K gradients
         p.dgamma[n] = p.rstd[n] * (tot - p.mean[n] * dsum);
         p.dbeta[n] = dsum;
     }
@@ -787,7 +818,11 @@ extern "C" int effdet_train_gemm_tn(void* stream, const float* dY, long long y_r
     else hipLaunchKernelGGL((gemm_tn_kernel<false, false>), grid, dim3(256), 0, st, p);
     int rc = effdet_check_launch();
     if (rc) return rc;
-    return launch_reduce_mid(st, workspace, 1, S, (long long)N * (K + 1), out, 0);
+    ReduceSplitArgs r{workspace, out, N, K, S};
+    const long long rb = ((long long)N * (K + 1) + 15) / 16;
+    if (rb > 0x7fffffffLL) return EFFDET_EINVAL;
+    hipLaunchKernelGGL(reduce_split_kernel, dim3((unsigned)rb), dim3(256), 0, st, r);
+    return effdet_check_launch();
 }
 
 extern "C" int effdet_train_reduce_mid(void* stream, const float* in, int G, int S, long long L, float* out, int accumulate) {

@@ -156,9 +156,18 @@ class PretrainStep(object):
             e1.synchronize()
             self.last_allreduce_ms = e0.elapsed_time(e1)
 
+    def _engine_flags(self):
+        eng = self.model._train_engine
+        if eng is not None:
+            eng.direct_grad = True          # FlatAdam owns every .grad (views of one flat buffer): add into them directly
+
     def __call__(self, x, target, time_allreduce=False, evaluator=None):
         model, opt = self.model, self.opt
         self._calls += 1
+        if model._train_engine is None:
+            from .train_engine import TrainEngine
+            model._train_engine = TrainEngine(model)
+        self._engine_flags()
         if self.graph and evaluator is None and self._calls > self._graph_warmup:
             cls_t, box_t, npos = self.targets(target)
             if self._cap is None:
