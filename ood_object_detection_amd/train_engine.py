@@ -679,6 +679,8 @@ class TrainEngine(object):
             dd = self._pw_bwd(nrec['pw'], dc, grads)
             dact = self._dw_bwd(nrec['dw'], dd, grads)
             dfused = ops.silu_bwd(nrec['fused'], dact)
+            if getattr(self, 'keep_debug', False):
+                nrec['_dfused'], nrec['_dact'] = dfused, dact
             n = nrec['n_in']
             wt, den = nrec['w'], nrec['den']                                  # device tensors [n], []
             if nrec['method'] in ('fastattn', 'attn'):
@@ -701,6 +703,7 @@ class TrainEngine(object):
             if dy is None:
                 continue
             add_to(src, self._resample_bwd(rec, dy, grads))
+        self._debug_dt = dt if getattr(self, 'keep_debug', False) else None
         return dt[:nbb], grads
 
 
