@@ -406,6 +406,20 @@ def _run(model, x, mode):
     eng = model.engine_for(B, size)
     if mode == 'bb':
         return eng.run_backbone(x)
+
+    def heads(activs_in, want_cls, want_box):
+        """class / box outputs; with a MetaHead as class_net (infer.py:191) the class outputs are the MetaHead's forward on
+        the pyramid, exactly as the reference's `self.class_net(x)` call (efficientdet.py:905-933)"""
+        if want_cls and eng._cls_plan is None:
+            _, box_o = eng.run_heads(activs_in, False, want_box) if want_box or activs_in is not None else (None, None)
+            pyr = [v.contiguous() for v in eng.pyramid_views()] if activs_in is None else list(activs_in)
+            model.ood_energy = model.ood_max_logit = None
+            return model.class_net(pyr), box_o
+        cls_o, box_o = eng.run_heads(activs_in, want_cls, want_box)
+        if want_cls:
+            model.ood_energy, model.ood_max_logit = eng.ood_energy, eng.ood_max_logit
+        return cls_o, box_o
+
     if mode in ('full_net', 'fpn', 'supp_bb'):
         feats = eng.run_backbone(x)
         activs = eng.run_fpn(None)
@@ -413,22 +427,16 @@ def _run(model, x, mode):
             return feats, activs
         if mode == 'supp_bb':
             return activs
-        cls_o, box_o = eng.run_heads(None, True, True)
-        model.ood_energy, model.ood_max_logit = eng.ood_energy, eng.ood_max_logit
-        return cls_o, box_o
+        return heads(None, True, True)
     if mode == 'only_fpn':
         return eng.run_fpn(x)
     if mode in ('fpn_and_head', 'not_cls'):
         activs = eng.run_fpn(x)
         if mode == 'not_cls':
-            return activs, eng.run_heads(None, False, True)[1]
-        cls_o, box_o = eng.run_heads(None, True, True)
-        model.ood_energy, model.ood_max_logit = eng.ood_energy, eng.ood_max_logit
-        return cls_o, box_o
+            return activs, heads(None, False, True)[1]
+        return heads(None, True, True)
     # 'head'
-    cls_o, box_o = eng.run_heads(x, True, True)
-    model.ood_energy, model.ood_max_logit = eng.ood_energy, eng.ood_max_logit
-    return cls_o, box_o
+    return heads(x, True, True)
 
 from .meta_head import MetaHead  # noqa: E402,F401  (reference: effdet/efficientdet.py:569)
 from .aux_nets import AnchorNet, ProjectionNet  # noqa: E402,F401  (reference: effdet/efficientdet.py:697,765)

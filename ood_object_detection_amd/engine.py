@@ -579,7 +579,9 @@ class Engine(object):
                                            outs, [P * NO] * L, '%s.predict' % name, ood=oodd))
             return plan
 
-        self._cls_plan = plan_for(model.class_net, 'class_net', self.cls_all, C, True)
+        # infer.py:186-191 replaces `model.class_net` by a MetaHead (functional head, own launches in effdet/meta_head.py):
+        # backbone / BiFPN / box head then still run from this plan, the class outputs come from the MetaHead's forward
+        self._cls_plan = plan_for(model.class_net, 'class_net', self.cls_all, C, True) if hasattr(model.class_net, 'conv_rep') else None
         self._box_plan = plan_for(model.box_net, 'box_net', self.box_all, 4, False)
 
     def head_views(self, t, K):
@@ -598,6 +600,8 @@ class Engine(object):
                 self.pyr[:, off:off + h * w, :].copy_(src.permute(0, 2, 3, 1).reshape(self.B, h * w, self.F))
         cls_o = box_o = None
         if want_cls:
+            if self._cls_plan is None:
+                raise RuntimeError('model.class_net is not a HeadNet (MetaHead?): its outputs come from the head\'s own forward')
             self._run(self._cls_plan)
             cls_o = self.head_views(self.cls_all, self.C)
         if want_box:

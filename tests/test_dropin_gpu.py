@@ -84,3 +84,111 @@ def test_pretrain_loop_as_written():
         sys.path.remove(os.path.join(root, 'ood_object_detection_amd'))
         for k in [k for k in sys.modules if k == 'effdet' or k.startswith('effdet.')]:
             del sys.modules[k]
+
+
+def test_infer_validation_iteration_as_written():
+    """infer.py's model set-up (:173-206) and the forward-only part of an iteration (:341-351, :561-563, :681, :689-700):
+    MetaHead swapped in from the class_net parameters, num_classes = 1, strict state-dict round trips, modes supp_bb / bb /
+    not_cls / supp_cls / qry_cls with fast weights, _post_process + generate_detections + evaluator."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'ood_object_detection_amd'))
+    try:
+        for k in [k for k in sys.modules if k == 'effdet' or k.startswith('effdet.')]:
+            del sys.modules[k]
+        from effdet.anchors import Anchors, generate_detections
+        from effdet.bench import _post_process
+        from effdet.config import get_efficientdet_config
+        from effdet.efficientdet import EfficientDet, MetaHead, ProjectionNet
+        from effdet.evaluation.detection_evaluator import ObjectDetectionEvaluator
+        from effdet.loss import DetectionLoss
+
+        torch.manual_seed(0)
+        h = get_efficientdet_config('tf_efficientdet_d0')
+        h.image_size = (256, 256)          # 12 276 anchors x 1 class > max_detection_points (torch.topk needs k <= N*C, too)
+        h.num_classes = 4
+        model = EfficientDet(h, pretrained_backbone=False)
+        state_dict = {k: v.clone() for k, v in model.state_dict().items()}
+        model.load_state_dict(state_dict, strict=True)                                                # infer.py:185
+        class_net_init_params = {n: v.data.detach().clone() for n, v in model.named_parameters() if 'class_net' in n}
+        model.class_net = MetaHead(model.config, pretrain_init=class_net_init_params)                 # :191
+        model.config.num_classes = 1                                                                  # :192
+        model_config = model.config
+        proj_net = ProjectionNet(model_config, 64)                                                    # :196
+        model.load_state_dict({k: v.clone() for k, v in model.state_dict().items()}, strict=True)    # :199
+        proj_net.load_state_dict(proj_net.state_dict(), strict=True)
+        model.to('cuda').eval()
+        anchors = Anchors.from_config(model_config).to('cuda')                                        # :206
+        loss_fn = DetectionLoss(model_config)                                                         # :212
+        assert loss_fn is not None
+        g = torch.Generator().manual_seed(2)
+        supp_imgs = torch.randn(3, 3, 256, 256, generator=g).to('cuda')
+        qry_imgs = torch.randn(2, 3, 256, 256, generator=g).to('cuda')
+        with torch.no_grad():
+            supp_activs = model(supp_imgs, mode='supp_bb')                                            # :343
+            qry_feats = model(qry_imgs, mode='bb')                                                    # :346
+            qry_activs, qry_box_out = model(qry_feats, mode='not_cls')                                # :349
+            qry_activs = [a.clone() for a in qry_activs]
+            anch_confs, obj_embds = model(supp_activs, fast_weights=None, mode='supp_cls')            # :563
+            assert len(anch_confs) == model_config.num_levels and anch_confs[0].shape[:2] == (3, 9)
+            assert obj_embds[0].shape[1] == model_config.fpn_channels
+            fast_weights = [par - 0.01 * torch.ones_like(par) if 'predict_p' in n else par
+                            for n, par in model.class_net.named_parameters()]                        # :660-678 (first-order stand-in)
+            qry_class_out = model(qry_activs, fast_weights=fast_weights, mode='qry_cls')              # :681
+            base_out = model(qry_activs, fast_weights=None, mode='qry_cls')
+            assert not torch.equal(qry_class_out[0], base_out[0])                                     # the fast weights are used
+            class_out_post, box_out_post, indices, classes = _post_process(
+                qry_class_out, qry_box_out, num_levels=model_config.num_levels, num_classes=model_config.num_classes,
+                max_detection_points=model_config.max_detection_points)                               # :690
+            evaluator = ObjectDetectionEvaluator([{'id': 1, 'name': 'obj'}], evaluate_corlocs=True)
+            gt = [np.array([[10., 12., 70., 90.]], np.float32), np.array([[5., 5., 60., 50.], [40., 30., 120., 100.]], np.float32)]
+            for b_ix in range(2):
+                detections = generate_detections(class_out_post[b_ix], box_out_post[b_ix], anchors.boxes, indices[b_ix], classes[b_ix],
+                                                 None, 256, max_det_per_image=30, soft_nms=False).cpu().numpy()   # :694
+                assert detections.shape[1] == 6 and detections.shape[0] <= 30
+                evaluator.add_single_ground_truth_image_info(b_ix, {'bbox': gt[b_ix], 'cls': np.ones(len(gt[b_ix]), np.int64)})
+                bboxes_yxyx = np.concatenate([detections[:, 1:2], detections[:, 0:1], detections[:, 3:4], detections[:, 2:3]], axis=1)
+                evaluator.add_single_detected_image_info(b_ix, {'bbox': bboxes_yxyx, 'scores': detections[:, 4], 'cls': detections[:, 5]})
+            map_metrics = evaluator.evaluate(['obj'])                                                 # :700
+        assert 'Precision/mAP@0.5IOU' in map_metrics and 'AP@0.5IOU/obj' in map_metrics
+    finally:
+        sys.path.remove(os.path.join(root, 'ood_object_detection_amd'))
+        for k in [k for k in sys.modules if k == 'effdet' or k.startswith('effdet.')]:
+            del sys.modules[k]
+
+
+def test_integration_md_ctypes_stubs_run():
+    """the ctypes bindings printed in INTEGRATION.md (section B) are executed verbatim and compared with the package's own
+    callables: documentation that cannot rot"""
+    import re
+    from ood_object_detection_amd import _lib as L
+    from ood_object_detection_amd.effdet import bench as pb, soft_nms as ps
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, 'INTEGRATION.md')).read()
+    sec = text[text.index('## B.'):text.index('### anchors.py:95')]
+    blocks = re.findall(r'```python\n(.*?)```', sec, flags=re.S)
+    assert len(blocks) >= 3
+    L.load()
+    ns = {}
+    for b in blocks:
+        exec(b.replace("ctypes.CDLL('libeffdet_hip.so')", "ctypes.CDLL(%r)" % L.LIB_PATH), ns)
+    dev = 'cuda:0'
+    g = torch.Generator().manual_seed(5)
+    # _post_process
+    B, C, A = 2, 7, 9
+    sizes = [16, 8, 4, 2, 1]
+    cls = [torch.randn(B, A * C, s, s, generator=g).to(dev) for s in sizes]
+    box = [torch.randn(B, A * 4, s, s, generator=g).to(dev) for s in sizes]
+    got = ns['_post_process'](cls, box, 5, C, 200)
+    ref = pb._post_process(cls, box, 5, C, 200)
+    for a, r in zip(got, ref):
+        assert torch.equal(a, r)
+    # batched_soft_nms
+    n = 300
+    xy = torch.rand(n, 2, generator=g) * 100
+    boxes = torch.cat([xy, xy + 5 + torch.rand(n, 2, generator=g) * 40], 1).to(dev)
+    scores = torch.rand(n, generator=g).to(dev)
+    idxs = torch.randint(0, 4, (n,), generator=g).to(dev)
+    k1, s1 = ns['batched_soft_nms'](boxes, scores, idxs, True, 0.5, 0.3, 0.001)
+    k2, s2 = ps.batched_soft_nms(boxes, scores, idxs, method_gaussian=True, sigma=0.5, iou_threshold=0.3, score_threshold=0.001)
+    m = min(len(k1), len(k2))
+    assert m > 0 and torch.equal(k1[:m], k2[:m]) and torch.allclose(s1[:m], s2[:m], atol=1e-6)
