@@ -201,3 +201,30 @@ def test_effdet_importable_under_the_reference_name():
             "print('ALIAS_OK')\n") % os.path.join(root, 'ood_object_detection_amd')
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd='/tmp', timeout=300)
     assert r.returncode == 0 and 'ALIAS_OK' in r.stdout, r.stderr[-2000:]
+
+
+def test_create_model_checkpoint_round_trip(tmp_path):
+    """factory.create_model(..., checkpoint_path=, checkpoint_ema=) (effdet/factory.py:39-54, timm load_checkpoint): bare state
+    dicts, {'state_dict': ...} / {'state_dict_ema': ...} wrappers, DataParallel 'module.' prefixes; a different class count
+    resets only class_net.predict.conv_pw (efficientdet.py:854-886); strict loading rejects a wrong layout"""
+    import torch
+    from ood_object_detection_amd.effdet.factory import create_model
+    torch.manual_seed(3)
+    src = create_model('tf_efficientdet_d0', num_classes=7, image_size=(128, 128))
+    sd = {k: v.clone() for k, v in src.state_dict().items()}
+    p1, p2, p3 = str(tmp_path / 'bare.pth'), str(tmp_path / 'wrapped.pth'), str(tmp_path / 'ema.pth')
+    torch.save(sd, p1)
+    torch.save({'state_dict': {'module.' + k: v for k, v in sd.items()}, 'epoch': 3}, p2)
+    torch.save({'state_dict': {k: torch.zeros_like(v) for k, v in sd.items()}, 'state_dict_ema': sd}, p3)
+    for path, ema in ((p1, False), (p2, False), (p3, True)):
+        bench = create_model('tf_efficientdet_d0', bench_task='predict', num_classes=7, checkpoint_path=path, checkpoint_ema=ema,
+                             image_size=(128, 128))
+        got = bench.model.state_dict()
+        assert set(got) == set(sd)
+        assert all(torch.equal(got[k], sd[k]) for k in sd)
+    m_def = create_model('tf_efficientdet_d0', image_size=(128, 128))     # the fork's default: FLAGS.pretrain_classes = 400 (model_config.py:30)
+    assert m_def.class_net.predict.conv_pw.weight.shape[0] == 9 * 400
+    with pytest.raises(RuntimeError):
+        create_model('tf_efficientdet_d0', num_classes=5, checkpoint_path=p1, image_size=(128, 128))   # 7-class checkpoint, 5-class head
+    with pytest.raises(KeyError):
+        create_model('tf_efficientdet_dx')
