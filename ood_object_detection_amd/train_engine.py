@@ -173,15 +173,6 @@ class _Ops(object):
         return out
 
 
-def _bn_vectors(bn):
-    """(gamma, beta, mean, rstd, scale, shift) of a BatchNorm in eval mode."""
-    g, b = bn.weight.detach(), bn.bias.detach()
-    mean = bn.running_mean.detach()
-    rstd = torch.rsqrt(bn.running_var.detach() + bn.eps)
-    scale = g * rstd
-    return g, b, mean, rstd, scale, b - mean * scale
-
-
 class TrainEngine(object):
     """Stage functions `bb_forward/backward`, `fh_forward/backward` over one model (its parameters are read live, so an
     optimizer step needs no re-preparation)."""

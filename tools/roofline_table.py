@@ -72,7 +72,6 @@ def layers(model, image, classes, es):
                     L.append(('%s.lateral.%d' % (p, off), spx * chs[off] * F, (spx * (chs[off] + F) + chs[off] * F) * es, p + '.lat%d' % off, spx * F * es))
                 src_lvl = off if off < cfg.num_levels else int(round(math.log2(nodes[off - cfg.num_levels]['reduction'] / red0)))
                 in_px += hw[src_lvl][0] * hw[src_lvl][1]
-            n_in = len(node['inputs_offsets'])
             # unfused: resample + fuse (n_in reads of the level + 1 write), act, dw (r+w), pw+BN (r+w)
             L.append((p + '.combine+act', 0, (in_px + px) * F * es, p, px * F * es))
             L.append((p + '.conv_dw', 9 * px * F, 2 * px * F * es, p, px * F * es))
