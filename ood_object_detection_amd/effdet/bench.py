@@ -132,6 +132,12 @@ class DetBenchPredict(nn.Module):
         return reps
 
     def forward(self, x, img_info: Optional[Dict[str, torch.Tensor]] = None):
+        # detections are not differentiable (top-k, NMS): the network always runs on the fused inference engine here, also
+        # when the wrapped model was left in training mode or the caller did not enter torch.no_grad()
+        with torch.no_grad():
+            return self._forward(x, img_info)
+
+    def _forward(self, x, img_info):
         if tuple(x.shape[2:]) != tuple(self.anchors.image_size):
             # the anchors follow the actual input size (the reference needs config.image_size == input size)
             self.anchors = Anchors(self.config.min_level, self.config.max_level, self.config.num_scales,

@@ -440,3 +440,40 @@ def test_pipelined_predict_identical_to_sequential():
         det, cnt, ood = outs[t]
         assert torch.equal(cnt, cnt_r) and torch.equal(det, det_r) and torch.equal(ood['energy'], en_r)
     assert int(refs[0][1].sum()) > 0
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_one_class_head_ood_degenerates_to_the_logit(dtype):
+    """with C = 1 (infer.py:192) energy = -z and max-logit = z exactly; detections still come out"""
+    from ood_object_detection_amd.effdet.bench import DetBenchPredict
+    model, cfg, nodes, sd = seeded_model('tf_efficientdet_d0', 256, 1, seed=13, cls_bias=0.0)
+    model = model.to(DEV).to(dtype)
+    x = torch.from_numpy(seeded_array(13, 'input', (2, 3, 256, 256))).to(DEV).to(dtype)
+    with torch.no_grad():
+        cls_o, box_o = model(x)
+        z = torch.cat([c.permute(0, 2, 3, 1).reshape(2, -1) for c in cls_o], 1).float()
+        assert z.shape == tuple(model.ood_max_logit.shape)
+        # the scores are float32 values of the accumulator; the stored logits are rounded to the model dtype
+        assert torch.equal(model.ood_max_logit.to(dtype).float(), z)
+        assert torch.allclose(model.ood_energy, -model.ood_max_logit, rtol=0, atol=2e-6)
+        det = DetBenchPredict(model).to(DEV)(x)
+    assert det.shape == (2, 100, 6) and bool(torch.isfinite(det).all())
+    assert set(det[..., 5].unique().tolist()) <= {0.0, 1.0}
+
+
+def test_det_bench_predict_ignores_training_mode_and_grad_mode():
+    """a bf16 model left in training mode, called without torch.no_grad(): DetBenchPredict still runs the inference engine
+    (the differentiable path is float32 only and would raise) and gives the same detections as the eval / no_grad call"""
+    from ood_object_detection_amd.effdet.bench import DetBenchPredict
+    model, cfg, nodes, sd = seeded_model('tf_efficientdet_d0', 128, 20, seed=11, cls_bias=0.0)
+    model = model.to(DEV).to(torch.bfloat16)
+    x = torch.from_numpy(seeded_array(11, 'input', (2, 3, 128, 128))).to(DEV).to(torch.bfloat16)
+    bench = DetBenchPredict(model, streams=1).to(DEV)
+    with torch.no_grad():
+        ref = bench(x).clone()
+    model.train()
+    assert model.wants_autograd()
+    det = bench(x)
+    assert not det.requires_grad and torch.equal(det, ref)
+    with pytest.raises(RuntimeError):
+        model(x)                      # the differentiable path itself refuses bfloat16
