@@ -242,8 +242,10 @@ class TrainEngine(object):
     def _pw_bneval_fwd(self, x, conv, bn, names, silu_out=False):
         """1x1 conv (no bias) + BN with running statistics, folded: z = x (scale*W)^T + shift (and a = silu(z) when asked)."""
         if bn.training:
-            raise NotImplementedError('backbone BatchNorm in batch-statistics mode is not built: put the backbone BN in eval '
-                                      'mode as pretrain.py:168-176 does (model.backbone.apply(set_bn_eval))')
+            raise NotImplementedError('backbone BatchNorm in batch-statistics mode is not built.  For training put the backbone BN in '
+                                      'eval mode as pretrain.py:168-176 does (model.backbone.apply(set_bn_eval)); for inference call '
+                                      'model.eval() or run under torch.no_grad() (a module in training mode with grad enabled takes '
+                                      'the differentiable path)')
         N = conv.weight.shape[0]
         W = conv.weight.detach().reshape(N, -1)
         Wf, WfT, _, scale, shift, rstd = self._fold(W, bn, True, True, False)
