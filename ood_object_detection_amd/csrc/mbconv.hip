@@ -320,8 +320,11 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
                         const u32x4 fr = {ddq == 0 ? bits : 0u, ddq == 1 ? bits : 0u, ddq == 2 ? bits : 0u, ddq == 3 ? bits : 0u};
                         Frag<T> af; af.v = __builtin_bit_cast(bf16x8, fr);
                         const int to = tap_off(pr);
-                        mma_chunk(af, ld_frag<T>(base[0] + to), acc[0]);
-                        if (second) mma_chunk(af, ld_frag<T>(base[1] + to), acc[1]);
+                        // both pixel tiles unconditionally (an absent second tile reads pixel 0's operands and is dropped at the
+                        // store): no exec-mask branch between the two LDS loads, so they are in flight together
+                        const Frag<T> b0 = ld_frag<T>(base[0] + to), b1 = ld_frag<T>(base[1] + to);
+                        mma_chunk(af, b0, acc[0]);
+                        mma_chunk(af, b1, acc[1]);
                     }
 #pragma unroll
                     for (int u = 0; u < UT; ++u) {
