@@ -228,3 +228,26 @@ def test_create_model_checkpoint_round_trip(tmp_path):
         create_model('tf_efficientdet_d0', num_classes=5, checkpoint_path=p1, image_size=(128, 128))   # 7-class checkpoint, 5-class head
     with pytest.raises(KeyError):
         create_model('tf_efficientdet_dx')
+
+
+def test_roofline_table_matches_survey_figures():
+    """tools/roofline_table.py: d0 / 640 / C=90 is 3.89 GMAC = 7.79 GFLOP per image (the survey's layer table and
+    the paper's 2.5 B at 512 px), N = 76 725 anchors; the fused launch list moves ~155 MB per image"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('roofline_table', os.path.join(root, 'tools', 'roofline_table.py'))
+    rt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rt)
+    L, geo = rt.layers('tf_efficientdet_d0', 640, 90, 2)
+    macs = sum(l[1] for l in L)
+    assert geo['N'] == 76725 and geo['P'] == 8525
+    assert abs(macs / 1e9 - 3.894) < 0.005
+    L512, _ = rt.layers('tf_efficientdet_d0', 512, 90, 2)
+    assert abs(sum(l[1] for l in L512) / 1e9 - 2.49) < 0.01
+    groups = {}
+    for name, m, nb, g, ob in L:
+        groups.setdefault(g, [0, []])
+        groups[g][0] += nb
+        groups[g][1].append(ob)
+    fused = sum(nb - 2 * sum(obs[:-1]) for nb, obs in groups.values())
+    assert 140e6 < fused < 170e6
