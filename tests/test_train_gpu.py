@@ -30,7 +30,8 @@ def _close(got, ref, rtol, what=''):
     assert err <= lim, '%s: L-inf %.3e > %.3e (max|ref| %.3e)' % (what, err, lim, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize('M,K,N', [(1000, 64, 64), (777, 32, 96), (300, 810, 64), (260, 64, 810), (130, 40, 36), (4096, 16, 8)])
+@pytest.mark.parametrize('M,K,N', [(1000, 64, 64), (777, 32, 96), (300, 810, 64), (260, 64, 810), (130, 40, 36), (4096, 16, 8),
+                                   (131072 + 37, 16, 96), (140000, 24, 10)])      # >= 128 k rows: two row groups per wave
 def test_gemm_nt(M, K, N):
     ops = _ops()
     A, W, b = _rnd(1, 'A', (M, K)), _rnd(1, 'W', (N, K)), _rnd(1, 'b', (N,))
