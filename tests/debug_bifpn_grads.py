@@ -1,5 +1,5 @@
 """Debug aid: per-tensor / per-node gradient comparison of the BiFPN + heads backward (HIP TrainEngine vs autograd through the
-oracle), incl. max-pool near-tie statistics.  usage: python tools/debug_bifpn_grads.py [bifpn_fa|bifpn_attn|bifpn_sum]"""
+oracle), incl. max-pool near-tie statistics.  usage: python tests/debug_bifpn_grads.py [bifpn_fa|bifpn_attn|bifpn_sum]"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
