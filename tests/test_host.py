@@ -251,3 +251,20 @@ def test_roofline_table_matches_survey_figures():
         groups[g][1].append(ob)
     fused = sum(nb - 2 * sum(obs[:-1]) for nb, obs in groups.values())
     assert 140e6 < fused < 170e6
+
+
+def test_only_checkers_import_the_oracle():
+    """oracle/ is test infrastructure: nothing in the product package or in tools/ may import it (bench.py may, in its
+    cpu_baseline leg only)"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = re.compile(r'^\s*(from\s+oracle\b|import\s+oracle\b)', re.M)
+    offenders = []
+    for sub in ('ood_object_detection_amd', 'tools'):
+        for dirpath, _, files in os.walk(os.path.join(root, sub)):
+            for f in files:
+                if f.endswith('.py') and pat.search(open(os.path.join(dirpath, f)).read()):
+                    offenders.append(os.path.join(dirpath, f))
+    assert not offenders, offenders
+    bench_src = open(os.path.join(root, 'bench.py')).read()
+    body = bench_src[bench_src.index('def cpu_baseline'):bench_src.index('def main')]
+    assert len(pat.findall(bench_src)) == len(pat.findall(body)) > 0        # every oracle import of bench.py sits in cpu_baseline
