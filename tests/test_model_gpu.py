@@ -490,3 +490,24 @@ def test_d5_is_refused_with_a_reason():
     with pytest.raises(NotImplementedError):
         with torch.no_grad():
             m(torch.zeros(1, 3, 256, 256, device=DEV))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_non_square_input(dtype):
+    """H != W (128 x 256): every kernel carries both extents; head outputs against the oracle, detections come out"""
+    from ood_object_detection_amd.effdet.bench import DetBenchPredict
+    model, cfg, nodes, sd = seeded_model('tf_efficientdet_d0', 128, 12, seed=17, cls_bias=0.0)
+    x = torch.from_numpy(seeded_array(17, 'input', (2, 3, 128, 256)))
+    with torch.no_grad():
+        cls_r, box_r = om.efficientdet_forward(sd, cfg, x, nodes)
+    m = model.to(DEV).to(dtype)
+    with torch.no_grad():
+        cls_o, box_o = m(x.to(DEV).to(dtype))
+        for a, r in zip(list(cls_o) + list(box_o), list(cls_r) + list(box_r)):
+            assert a.shape == r.shape
+            if dtype == torch.float32:
+                assert _linf(a, r) <= 1e-4 * max(1.0, float(r.abs().max()))
+            else:
+                assert bool(torch.isfinite(a.float()).all())
+        det = DetBenchPredict(m).to(DEV)(x.to(DEV).to(dtype))
+    assert det.shape == (2, 100, 6) and float(det[..., 2].max()) > 128.0      # boxes reach into the wide half
