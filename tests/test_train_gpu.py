@@ -590,3 +590,44 @@ def test_gradients_other_fusion_methods(fpn_name):
     rows.sort(reverse=True)
     assert rows[0][0] <= 2e-3, (gmax, rows[:6])
     assert n_edge == (24 if fpn_name == 'bifpn_attn' else 0)
+
+
+def test_gradients_non_square_input():
+    """128 x 256 images: the training operators carry H and W separately (TF-SAME padding, pooling, upsampling, row maps)"""
+    from _models import seeded_model
+    from ood_object_detection_amd.effdet.loss import DetectionLoss
+    B, C, H, W = 2, 12, 128, 256
+    model, cfg, nodes, sd = seeded_model('tf_efficientdet_d0', 128, C, seed=43)
+    x = torch.from_numpy(seeded_array(43, 'input_ns', (B, 3, H, W)))
+    rs = np.random.RandomState(12)
+    cls_t, box_t = [], []
+    for l in range(cfg.num_levels):
+        h, w = H // (2 ** (cfg.min_level + l)), W // (2 ** (cfg.min_level + l))
+        cls_t.append(torch.from_numpy(rs.choice([-2, -1, -1, -1, -1, 0, 3, C - 1], size=(B, h, w, 9)).astype(np.int64)))
+        t = rs.normal(0, 0.2, (B, h, w, 36)).astype(np.float32)
+        t[rs.uniform(size=t.shape) < 0.7] = 0.0
+        box_t.append(torch.from_numpy(t))
+    npos = torch.tensor([7.0, 4.0])
+    (ref_total, _, _), ref_g, cls_ref, box_ref, _ = _oracle_step(sd, cfg, nodes, x, cls_t, box_t, npos, C, batch_stats=False)
+    model = model.to(DEV).float().train()
+    model.apply(lambda m: m.eval() if isinstance(m, torch.nn.BatchNorm2d) else None)
+    cfg.alpha, cfg.box_loss_weight = 0.15, 50.0
+    cls_o, box_o = model(x.to(DEV))
+    for a, r in zip(list(cls_o) + list(box_o), list(cls_ref) + list(box_ref)):
+        _close(a, r, 1e-3, 'non-square head output')
+    total, _, _ = DetectionLoss(cfg)(cls_o, box_o, [t.to(DEV) for t in cls_t], [t.to(DEV) for t in box_t], npos.to(DEV))
+    assert abs(total.item() - float(ref_total)) <= 1e-4 * abs(float(ref_total))
+    total.backward()
+    gmax = max(float(r.abs().max()) for r in ref_g.values() if r is not None)
+    rows = []
+    for name, p in model.named_parameters():
+        r = ref_g.get(name)
+        if r is None:
+            continue
+        floor = 1e-5 * gmax
+        if name.endswith('edge_weights'):
+            floor = 1e-3 * gmax       # nw_k (S_j - S_k) / den: the dot products S are of the order of the largest gradients
+        err = float((p.grad.cpu() - r).abs().max()) / max(float(r.abs().max()), floor)
+        rows.append((err, name))
+    rows.sort(reverse=True)
+    assert rows[0][0] <= 2e-3, rows[:5]
