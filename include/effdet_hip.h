@@ -196,6 +196,14 @@ int effdet_nms_soft(void* stream, const float* boxes, const float* scores, const
                     float iou_threshold, float score_threshold, int max_det,
                     const float* img_scale, float* det, int* det_count, int* keep_src);
 
+/* The same soft-NMS for any k (the stand-alone soft_nms / batched_soft_nms API of effdet/soft_nms.py:42-169 has no size
+ * limit and returns every pick): working scores in `score_scratch` [B,k] floats, max_det <= k. effdet_nms_soft itself
+ * keeps the candidates in registers (k <= 8192, max_det <= k). */
+int effdet_nms_soft_large(void* stream, const float* boxes, const float* scores, const int* classes, const int* src,
+                          const int* count, const float* maxcoord, int B, int k, int method_gaussian, float sigma,
+                          float iou_threshold, float score_threshold, int max_det,
+                          const float* img_scale, float* det, int* det_count, int* keep_src, float* score_scratch);
+
 /* OOD scores of the kept detections: energy/maxlogit [B,n_anchors] -> [B,max_det] (0 where padded). */
 int effdet_gather_ood(void* stream, const int* keep_src, const long long* indices, const float* energy,
                       const float* maxlogit, long long n_anchors, int B, int k, int max_det,

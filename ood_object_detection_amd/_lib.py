@@ -75,6 +75,8 @@ SIGNATURES = {
                                 c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'effdet_nms_soft': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                 c_int, c_float, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'effdet_nms_soft_large': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                      c_int, c_float, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'effdet_detection_loss_workspace_floats': (c_ll, [c_int, c_ll, c_int]),
     'effdet_detection_loss': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_ll, c_int,
                                       c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_ll]),

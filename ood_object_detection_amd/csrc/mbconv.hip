@@ -13,7 +13,14 @@
 //     depthwise taps out of LDS, BN2 + SiLU, 16-byte NHWC stores, pool partials.
 // HBM traffic per tile = input halo + output tile (+ weights from L2).
 #include "common.h"
+// Phase-ablation switch of tools/ablate_gpu.sh: exists only in the separate -DEFFDET_ABLATE build
+// (libeffdet_hip_ablate.so, `make ablate`); the product library has no run-time work-skipping switch.
+#ifdef EFFDET_ABLATE
 #include <cstdlib>
+#define MB_DBG(p) ((p).dbg)
+#else
+#define MB_DBG(p) 0
+#endif
 
 namespace {
 
@@ -31,7 +38,7 @@ struct MbArgs {
     int e_bytes;                                // size of the expanded tile (also hosts the pool scratch)
     FastDiv fd_ppr, fd_iw, fd_tx;               // / (16-byte pieces per input row), / IW, / tiles_x
     int tw_shift;                               // TW = 1 << tw_shift
-    int dbg;                                    // ablation switch (EFFDET_DEBUG_SKIP), 0 in production
+    int dbg;                                    // phase-ablation mask; only read in the -DEFFDET_ABLATE build
 };
 
 constexpr int MC = 64;                          // expanded channels per pass
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
         const char* xp[HK];
 #pragma unroll
         for (int kc = 0; kc < HK; ++kc) xp[kc] = xa[kc];
-        for (int ms = wave; ms < ((p.dbg & 1) ? 0 : n_msub); ms += SM_T / 64) {
+        for (int ms = wave; ms < ((MB_DBG(p) & 1) ? 0 : n_msub); ms += SM_T / 64) {
             f32x4 acc[SM_NJ];
 #pragma unroll
             for (int j = 0; j < SM_NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
         if constexpr (MF) {
             // ---- depthwise on the matrix cores: wave (dj, dhalf) owns channel tile dj and every NH-th pixel tile
             float plr[4] = {0.f, 0.f, 0.f, 0.f};
-            if (wave < NH * SM_NJ && !(p.dbg & 2)) {
+            if (wave < NH * SM_NJ && !(MB_DBG(p) & 2)) {
                 // the lane's single non-zero dword of each diagonal operand; expanded to the 16-byte fragment at use
                 unsigned abits[NPAIR];
 #pragma unroll
@@ -368,7 +375,7 @@ __global__ __launch_bounds__(SM_T, 4) void mbconv_front_kernel(MbArgs p) {
             // ---- float32: depthwise on the vector ALU out of LDS, a thread owns 8 channels of one output pixel at a time
             F8 pool = f8_zero();
             const int cg = tid % SM_CG, pg0 = tid / SM_CG;
-            if (pg0 < SM_PG && !(p.dbg & 2)) {
+            if (pg0 < SM_PG && !(MB_DBG(p) & 2)) {
                 for (int px = pg0; px < p.TH * p.TW; px += SM_PG) {
                     const int ty = px >> p.tw_shift, tx = px & (p.TW - 1);
                     const int oy = oy0 + ty, ox = ox0 + tx;
@@ -508,7 +515,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void mbconv_deep_kernel(Mb
     // ---- expand the band: two 16-pixel sub-tiles per step share every W fragment read
     const char* Xb = reinterpret_cast<const char*>(p.X) + ((long long)b * p.H * W + (long long)iy_lo * W) * cbytes;
     const int n_pair = (npx + 31) / 32;
-    for (int mp = wave; mp < ((p.dbg & 1) ? 0 : n_pair); mp += NTH / 64) {
+    for (int mp = wave; mp < ((MB_DBG(p) & 1) ? 0 : n_pair); mp += NTH / 64) {
         f32x4 acc[2][4];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
@@ -578,7 +585,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void mbconv_deep_kernel(Mb
         float* pl_x = reinterpret_cast<float*>(lds) + (NPAR * MC);  // [NH-1][64] pool sums handed to the first wave of a tile
         float plr[4] = {0.f, 0.f, 0.f, 0.f};
         const bool ch_ok = 16 * j + 4 * fpiece < cn;
-        if (16 * j < cn && !(p.dbg & 2)) {
+        if (16 * j < cn && !(MB_DBG(p) & 2)) {
             constexpr int NTAP = KS * KS, NPAIR = (NTAP + 1) / 2;
             const int hi = fpiece >> 1;
             const bool active = (fpiece & 1) == (frow >> 3);
@@ -654,7 +661,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void mbconv_deep_kernel(Mb
     const int cgn = cn / 8;
     F8 pool = f8_zero();
     const int cg = tid & 7;
-    if (cg < cgn && !(p.dbg & 2)) {
+    if (cg < cgn && !(MB_DBG(p) & 2)) {
         const F8 s2 = load8<float>(cpar + cg * 8), t2 = load8<float>(cpar + MC + cg * 8);
         const int gpr = (p.Wo + PPT - 1) / PPT;
         for (int pg = tid >> 3; pg < (oy_e - oy_b) * gpr; pg += NTH / 8) {
@@ -853,8 +860,11 @@ static int mbconv_common(void* stream, int dtype, const void* X, const float* in
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.mid = mid; a.k = k; a.stride = stride;
     a.Ho = same_out(H, stride); a.Wo = same_out(W, stride);
     a.pad_t = same_pad_before(H, k, stride); a.pad_l = same_pad_before(W, k, stride);
-    static const int dbg = getenv("EFFDET_DEBUG_SKIP") ? atoi(getenv("EFFDET_DEBUG_SKIP")) : 0;
-    a.dbg = dbg;
+#ifdef EFFDET_ABLATE
+    a.dbg = getenv("EFFDET_DEBUG_SKIP") ? atoi(getenv("EFFDET_DEBUG_SKIP")) : 0;
+#else
+    a.dbg = 0;
+#endif
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return dtype == 0 ? launch_mb<float>(st, a) : launch_mb<bf16_t>(st, a);
 }

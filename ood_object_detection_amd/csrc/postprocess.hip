@@ -695,6 +695,80 @@ __global__ __launch_bounds__(1024) void nms_soft_kernel(NmsArgs p) {
     if (tid == 0) p.det_count[b] = count;
 }
 
+// The same algorithm for any n (the stand-alone soft_nms API, effdet/soft_nms.py:42-112, has no size limit): the working
+// scores live in a caller-provided scratch row, boxes are re-read from global memory (L2) each round.
+__global__ __launch_bounds__(1024) void nms_soft_global_kernel(NmsArgs p, float* sc_ws) {
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ unsigned long long wbest[16];
+    __shared__ float top[5];
+    __shared__ unsigned long long best_s;
+    const int n = p.count[b];
+    const float off1 = p.maxcoord[b] + 1.0f;
+    float* sc = sc_ws + (long long)b * p.k;
+    const float* bx = p.boxes + (long long)b * p.k * 4;
+    const int* cls = p.classes + (long long)b * p.k;
+    for (int i = tid; i < p.max_det * 6; i += 1024) p.det[(long long)b * p.max_det * 6 + i] = 0.f;
+    for (int i = tid; i < p.max_det; i += 1024) p.keep_src[(long long)b * p.max_det + i] = -1;
+    for (int i = tid; i < n; i += 1024) sc[i] = p.scores[(long long)b * p.k + i];
+    __syncthreads();
+    int count = 0;
+    for (; count < p.max_det; ++count) {
+        unsigned long long best = 0ull;
+        for (int i = tid; i < n; i += 1024) {
+            const float s = sc[i];
+            if (s >= 0.f) {
+                const unsigned long long k1 = (((unsigned long long)__float_as_uint(s) << 32) |
+                                               (unsigned long long)(0xFFFFFFFFu - (unsigned int)i)) + (1ull << 32);
+                best = k1 > best ? k1 : best;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(best, o, 64);
+            best = other > best ? other : best;
+        }
+        if (lane == 0) wbest[wave] = best;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long m = 0ull;
+            for (int w = 0; w < 16; ++w) m = wbest[w] > m ? wbest[w] : m;
+            best_s = m;
+            if (m != 0ull) {
+                const int ti = (int)(0xFFFFFFFFu - (unsigned int)(m & 0xFFFFFFFFull));
+                const float offs = (float)cls[ti] * off1;
+                top[0] = bx[ti * 4] + offs; top[1] = bx[ti * 4 + 1] + offs; top[2] = bx[ti * 4 + 2] + offs; top[3] = bx[ti * 4 + 3] + offs;
+                top[4] = sc[ti];
+                write_det(p, b, count, ti, sc[ti]);
+            }
+        }
+        __syncthreads();
+        const unsigned long long bsel = best_s;
+        if (bsel == 0ull) break;
+        const int ti = (int)(0xFFFFFFFFu - (unsigned int)(bsel & 0xFFFFFFFFull));
+        const float tx1 = top[0], ty1 = top[1], tx2 = top[2], ty2 = top[3];
+        const float tarea = (tx2 - tx1) * (ty2 - ty1);
+        for (int i = tid; i < n; i += 1024) {
+            const float s = sc[i];
+            if (s >= 0.f) {
+                const float offs = (float)cls[i] * off1;
+                const float x1 = bx[i * 4] + offs, y1 = bx[i * 4 + 1] + offs, x2 = bx[i * 4 + 2] + offs, y2 = bx[i * 4 + 3] + offs;
+                const float area2 = (x2 - x1) * (y2 - y1);
+                const float w = fmaxf(fminf(tx2, x2) - fmaxf(tx1, x1), 0.f);
+                const float h = fmaxf(fminf(ty2, y2) - fmaxf(ty1, y1), 0.f);
+                const float inter = w * h;
+                const float iou = inter > 0.f ? inter / (tarea + area2 - inter) : 0.f;
+                float decay;
+                if (p.gaussian) decay = expf(-(iou * iou) / p.sigma);
+                else decay = iou > p.soft_iou_thr ? 1.0f - iou : 1.0f;
+                const float ns = s * decay;
+                sc[i] = ((ns > p.score_thr) && (i != ti)) ? ns : -1.f;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) p.det_count[b] = count;
+}
+
 __global__ void gather_ood_kernel(const int* keep_src, const long long* indices, const float* energy,
                                   const float* maxlogit, long long n_anchors, int k, int max_det, int B,
                                   float* out_energy, float* out_maxlogit) {
@@ -888,8 +962,8 @@ extern "C" int effdet_decode_threshold_gather(void* stream, int dtype, const voi
 
 static int nms_common(NmsArgs& a, int B, bool soft, void* stream) {
     if (!a.boxes || !a.scores || !a.classes || !a.src || !a.count || !a.maxcoord || !a.det || !a.det_count || !a.keep_src) return EFFDET_EINVAL;
-    if (B <= 0 || a.k <= 0 || a.max_det <= 0 || a.max_det > NMS_MAX_DET) return EFFDET_EINVAL;
-    if (soft && a.k > 1024 * SOFT_Q) return EFFDET_EINVAL;
+    if (B <= 0 || a.k <= 0 || a.max_det <= 0 || (!soft && a.max_det > NMS_MAX_DET)) return EFFDET_EINVAL;     // the hard kernel keeps its picks in LDS
+    if (soft && (a.k > 1024 * SOFT_Q || a.max_det > a.k)) return EFFDET_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (soft) hipLaunchKernelGGL(nms_soft_kernel, dim3(B), dim3(1024), 0, st, a);
     else hipLaunchKernelGGL(nms_hard_kernel, dim3(B), dim3(256), 0, st, a);
@@ -913,6 +987,20 @@ extern "C" int effdet_nms_soft(void* stream, const float* boxes, const float* sc
     NmsArgs a{boxes, scores, classes, src, count, maxcoord, k, (double)iou_threshold, max_det, img_scale, det, det_count, keep_src,
               method_gaussian ? 1 : 0, sigma, iou_threshold, score_threshold};
     return nms_common(a, B, true, stream);
+}
+
+extern "C" int effdet_nms_soft_large(void* stream, const float* boxes, const float* scores, const int* classes, const int* src,
+                                     const int* count, const float* maxcoord, int B, int k,
+                                     int method_gaussian, float sigma, float iou_threshold, float score_threshold, int max_det,
+                                     const float* img_scale, float* det, int* det_count, int* keep_src, float* score_scratch) {
+    EFFDET_ENTER();
+    if (!(sigma > 0.f) || !score_scratch) return EFFDET_EINVAL;
+    if (!boxes || !scores || !classes || !src || !count || !maxcoord || !det || !det_count || !keep_src) return EFFDET_EINVAL;
+    if (B <= 0 || k <= 0 || max_det <= 0 || max_det > k) return EFFDET_EINVAL;
+    NmsArgs a{boxes, scores, classes, src, count, maxcoord, k, (double)iou_threshold, max_det, img_scale, det, det_count, keep_src,
+              method_gaussian ? 1 : 0, sigma, iou_threshold, score_threshold};
+    hipLaunchKernelGGL(nms_soft_global_kernel, dim3(B), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), a, score_scratch);
+    return effdet_check_launch();
 }
 
 extern "C" int effdet_gather_ood(void* stream, const int* keep_src, const long long* indices, const float* energy,

@@ -67,6 +67,28 @@ def _packed(outs, num_levels, width):
     return torch.cat([outs[l].permute(0, 2, 3, 1).reshape(B, -1, width) for l in range(num_levels)], 1).contiguous()
 
 
+import contextlib
+import threading
+
+_fork = threading.local()
+
+
+@contextlib.contextmanager
+def forked_stream(stream):
+    """`with forked_stream(s):` = `with torch.cuda.stream(s):` that also records that the code inside runs on a side stream
+    forked from the caller's.  DetBenchPredict uses it for its concurrent sub-batches; callers that run a DetBenchPredict on
+    their own side stream inside a hipGraph capture should use it too.  Why: forking again from a stream that is itself a
+    fork of the capturing stream segfaults in hipStreamEndCapture on ROCm 7.2 (round-1 record gpurun_out/b2.log: the box
+    head forked onto a third stream inside a captured half-batch) - a crash `except` cannot catch - so DetBenchPredict
+    refuses to fork at depth > 0 while the stream is capturing."""
+    _fork.depth = getattr(_fork, 'depth', 0) + 1
+    try:
+        with torch.cuda.stream(stream):
+            yield
+    finally:
+        _fork.depth -= 1
+
+
 class DetBenchPredict(nn.Module):
     """`streams` (extension, default: automatic): with two streams the batch is processed as two concurrent
     half-batches - images are independent, so results are identical - and the narrow, latency-bound launches of
@@ -91,9 +113,8 @@ class DetBenchPredict(nn.Module):
 
     def _one(self, model, x, img_scale, img_size):
         """One (sub-)batch: model -> top-k -> decode -> NMS -> OOD gather.  The top-k runs without the box gather and
-        decode reads the box regressions from the box head's packed output through the top-k indices.  (Running the box
-        head beside the top-k on a third stream works eagerly but crashes hipStreamEndCapture - nested forks - so the
-        two stay in launch order; the half-batches already overlap each other.)"""
+        decode reads the box regressions from the box head's packed output through the top-k indices.  Class head, box
+        head and top-k stay in launch order on one stream (see `forked_stream` for why nothing forks from here)."""
         lib = _lib.load()
         class_out, box_out = model(x)
         cls_topk, _, indices, classes = _post_process(
@@ -116,7 +137,7 @@ class DetBenchPredict(nn.Module):
         import copy
         B, size = x.shape[0], (x.shape[2], x.shape[3])
         N = self.anchors.boxes.shape[0]
-        key = (B, size, n, x.device, self.model._wver[0], self.num_classes)
+        key = (B, size, n, x.device, self.model.weights_token(), self.num_classes)
         if self._replicas is not None and self._replicas[0] == key and all(rep._engine is eng for rep, _, eng in self._replicas[1]):
             return self._replicas[1]
         e = torch.empty(B, N, dtype=torch.float32, device=x.device)
@@ -154,6 +175,10 @@ class DetBenchPredict(nn.Module):
             self.last_ood = {'energy': energy, 'max_logit': maxlogit, 'anchor_energy': self.model.ood_energy,
                              'anchor_max_logit': self.model.ood_max_logit}
             return det
+        if getattr(_fork, 'depth', 0) > 0 and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('DetBenchPredict(streams=%d) would fork sub-batch streams from a stream that is itself a fork inside '
+                               'a hipGraph capture; nested forks crash hipStreamEndCapture on ROCm 7.2. Capture from the origin '
+                               'stream, or construct DetBenchPredict(model, streams=1) for use on side streams.' % n)
         reps = self._split_setup(x, n)
         Bh = B // n
         cur = torch.cuda.current_stream(x.device)
@@ -161,7 +186,7 @@ class DetBenchPredict(nn.Module):
         for i, (rep, stream, _) in enumerate(reps):
             sl = slice(i * Bh, (i + 1) * Bh)
             stream.wait_stream(cur)
-            with torch.cuda.stream(stream):
+            with forked_stream(stream):
                 outs.append(self._one(rep, x[sl], None if img_scale is None else img_scale[sl],
                                       None if img_size is None else img_size[sl]))
         for _, stream, _ in reps:

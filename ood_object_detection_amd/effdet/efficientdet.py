@@ -279,12 +279,15 @@ class EfficientDet(nn.Module):
         self._engine = None
         self._train_engine = None
         self.autograd = None        # None: differentiable forward iff self.training and grad mode and trainable params; True/False forces
-        self._wver = [0]            # bumped whenever parameters may have changed; shared by shallow copies of the model
+        # [0]: bumped whenever parameters may have changed (load_state_dict, .to(), reset_head, invalidate(), PretrainStep);
+        # [1]: cached (module ids, parameter + buffer tensors) behind weights_token().  Shared by shallow copies of the model.
+        self._wver = [0, None]
         self.ood_energy = None
         self.ood_max_logit = None
         # normalisation applied when a raw uint8 batch is passed to forward (effdet/data/loader.py:114-128)
         self.input_mean = (0.485, 0.456, 0.406)
         self.input_std = (0.229, 0.224, 0.225)
+        self.supp_level_offset = 2  # FLAGS.supp_level_offset of the reference (infer.py:94, pretrain.py:63), read by mode='supp_cls'
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
 
     # ---- engine management -----------------------------------------------------------------
@@ -306,6 +309,29 @@ class EfficientDet(nn.Module):
         d['_train_engine'] = None
         return d
 
+    def train(self, mode=True):
+        # a train() <-> eval() transition usually brackets parameter updates: packed / BN-folded weights are rebuilt after it
+        if bool(mode) != self.training:
+            self._engine = None
+            self._wver[0] += 1
+        return super().train(mode)
+
+    def weights_token(self):
+        """Cheap fingerprint of the parameters the packed engine was built from: the explicit version, the identity of the
+        sub-modules the scripts replace (infer.py:191 swaps class_net, reset_head swaps predict.conv_pw) and the sum of the
+        autograd version counters of every parameter and buffer - any in-place update through the tensor itself
+        (`optimizer.step()`, `p.add_()`, `p.copy_()`, BatchNorm running statistics) changes it.  Writes through `p.data`
+        bypass version counters: call `invalidate()` after those."""
+        pred = getattr(self.class_net, 'predict', None)
+        mods = (id(self.backbone), id(self.fpn), id(self.class_net), id(self.box_net), id(getattr(pred, 'conv_pw', None)))
+        c = self._wver[1]
+        if c is None or c[0] != mods or c[2] != self._wver[0]:
+            c = self._wver[1] = (mods, list(self.parameters()) + list(self.buffers()), self._wver[0])
+        v = 0
+        for t in c[1]:
+            v += t._version
+        return (self._wver[0], mods, v)
+
     def prepare(self, batch_size, image_size=None, ood_out=None):
         """Fold BN, repack weights to the kernel layouts and build the launch plan."""
         from ..engine import Engine
@@ -315,7 +341,7 @@ class EfficientDet(nn.Module):
 
     def engine_for(self, batch_size, image_size):
         e = self._engine
-        if e is None or e.B != batch_size or e.image_size != tuple(image_size) or not e.matches(self) or e.wver != self._wver[0]:
+        if e is None or e.B != batch_size or e.image_size != tuple(image_size) or not e.matches(self) or e.wtoken != self.weights_token():
             e = self.prepare(batch_size, image_size)
         return e
 
@@ -355,9 +381,12 @@ class EfficientDet(nn.Module):
             from .meta_head import MetaHead
             if not isinstance(self.class_net, MetaHead):
                 raise RuntimeError("mode %r needs `model.class_net = MetaHead(...)` as in infer.py:191" % mode)
-            if mode == 'supp_cls':        # efficientdet.py:896-897 (level_offset = FLAGS.supp_level_offset, default 0)
+            if mode == 'supp_cls':        # efficientdet.py:896-897: level_offset = FLAGS.supp_level_offset (default 2 in both
+                # scripts, infer.py:94 / pretrain.py:63 - the support pass skips the two finest levels and its outputs line up
+                # with the 3-level `proj_anchors` of dataloader.py:66); here: `model.supp_level_offset` or the config field
+                off = getattr(self.config, 'supp_level_offset', None)
                 return self.class_net(x, fast_weights=fast_weights, ret_activs=True,
-                                      level_offset=getattr(self.config, 'supp_level_offset', 0), heads='both')
+                                      level_offset=self.supp_level_offset if off is None else off, heads='both')
             return self.class_net(x, fast_weights=fast_weights, ret_activs=ret_activs, heads='None')
         if mode not in _MODES:
             raise ValueError('unknown mode %r' % (mode,))

@@ -35,7 +35,7 @@ class Engine(object):
     def __init__(self, model, B, image_size, ood_out=None):
         cfg = model.config
         self._ood_out = ood_out
-        self.wver = getattr(model, '_wver', [0])[0]          # weights version the packed copies were made from
+        self.wtoken = model.weights_token()                  # fingerprint of the parameters the packed copies are made from
         p0 = model.backbone.conv_stem.weight
         if p0.device.type != 'cuda':
             raise RuntimeError('the EfficientDet HIP path needs the model on a GPU (cuda:N); there is no CPU fallback')

@@ -177,7 +177,7 @@ class TrainEngine(object):
     """Stage functions `bb_forward/backward`, `fh_forward/backward` over one model (its parameters are read live, so an
     optimizer step needs no re-preparation)."""
 
-    def __init__(self, model):
+    def __init__(self, model, head_chains=False):
         p0 = model.backbone.conv_stem.weight
         if p0.device.type != 'cuda':
             raise RuntimeError('the training path needs the model on a GPU (cuda:N); there is no CPU fallback')
@@ -195,10 +195,10 @@ class TrainEngine(object):
         self._ones = {}
         self._main_ops = self.ops
         self._chain_ops, self._chain_streams = [], []        # one workspace + stream per (head, level) chain
-        import os
-        # opt-in: run the 2 x L independent head towers on parallel streams.  Measured (d0 / 640 / 8 images): no gain - eager
-        # launches are CPU-bound, and the captured graph does not run the branches faster (38.8 vs 37.0 steps/s) - so off.
-        self.head_chains = os.environ.get('EFFDET_HEAD_CHAINS', '0') == '1'
+        # opt-in constructor argument: run the 2 x L independent head towers on parallel streams.  Measured (d0 / 640 / 8
+        # images): no gain - eager launches are CPU-bound, and the captured graph does not run the branches faster
+        # (38.8 vs 37.0 steps/s) - so off by default.
+        self.head_chains = bool(head_chains)
         self.direct_grad = False        # True: parameter gradients are added into existing `.grad`s by one multi-tensor launch
 
     def _const(self, C, v):

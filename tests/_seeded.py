@@ -79,3 +79,40 @@ def eval_case(seed, n_img, C, n_det):
         images.append(dict(gt_boxes=gt, gt_classes=np.asarray(gc, np.int64), det_boxes=np.stack(det).astype(np.float32),
                            det_scores=sc, det_classes=np.asarray(dc, np.int64)))
     return images
+
+
+def meta_nets_case(g):
+    """Rebuild the seeded weights / inputs of tests/golden/meta_nets.npz (tools/make_golden.py::gen_meta_nets): the
+    fixture stores the reference's outputs only, the inputs are regenerated from (seed, key, shape)."""
+    seed, B, Fc, A, L, R = [int(v) for v in g['mh_meta'][:6]]
+    sizes = [int(v) for v in g['mh_meta'][6:]]
+    init = {}
+    for l in range(R):
+        init['class_net.conv_rep.%d.conv_dw.weight' % l] = seeded_tensor(seed, 'class_net.conv_rep.%d.conv_dw.weight' % l, (Fc, 1, 3, 3))
+        init['class_net.conv_rep.%d.conv_pw.weight' % l] = seeded_tensor(seed, 'class_net.conv_rep.%d.conv_pw.weight' % l, (Fc, Fc, 1, 1))
+        init['class_net.conv_rep.%d.conv_pw.bias' % l] = seeded_tensor(seed, 'class_net.conv_rep.%d.conv_pw.bias' % l, (Fc,))
+        for lev in range(L):
+            for wb in ('weight', 'bias'):
+                k = 'class_net.bn_rep.%d.%d.bn.%s' % (l, lev, wb)
+                init[k] = seeded_tensor(seed, k, (Fc,))
+    init['class_net.predict.conv_dw.weight'] = seeded_tensor(seed, 'class_net.predict.conv_dw.weight', (Fc, 1, 3, 3))
+    sc = (1.0 / Fc) ** 0.5
+    extra = dict(predict_pw=seeded_tensor(seed, 'meta.predict_pw', (A, Fc, 1, 1)) * sc,
+                 predict_pb=seeded_tensor(seed, 'meta.predict_pb', (A,)),
+                 predict_pw_sep=seeded_tensor(seed, 'meta.predict_pw_sep', (A, Fc, 1, 1)) * sc,
+                 predict_pb_sep=seeded_tensor(seed, 'meta.predict_pb_sep', (A,)))
+    x = [torch.from_numpy(seeded_array(seed, 'lvl%d' % i, (B, Fc, s, s))) for i, s in enumerate(sizes)]
+    xa = [torch.from_numpy(seeded_array(seed + 1, 'an%d' % i, (2, Fc, s, s))) for i, s in enumerate(sizes)]
+    xp = torch.from_numpy(seeded_array(seed + 2, 'px', (5, 37, Fc + 42)))
+    return dict(seed=seed, B=B, F=Fc, A=A, L=L, R=R, sizes=sizes, init=init, extra=extra, x=x, x_anchor=xa, x_proj=xp)
+
+
+def meta_lists(init, extra, L, R):
+    """the reference's parameter lists (efficientdet.py:594-632): conv_dw, conv_pw, conv_pb, predict, bn_w, bn_b (level-major)"""
+    dw = [init['class_net.conv_rep.%d.conv_dw.weight' % l] for l in range(R)]
+    pw = [init['class_net.conv_rep.%d.conv_pw.weight' % l] for l in range(R)]
+    pb = [init['class_net.conv_rep.%d.conv_pw.bias' % l] for l in range(R)]
+    pred = [init['class_net.predict.conv_dw.weight'], extra['predict_pw'], extra['predict_pb']]
+    bw = [init['class_net.bn_rep.%d.%d.bn.weight' % (r, lev)] for lev in range(L) for r in range(R)]
+    bb = [init['class_net.bn_rep.%d.%d.bn.bias' % (r, lev)] for lev in range(L) for r in range(R)]
+    return dw, pw, pb, pred, bw, bb

@@ -11,7 +11,7 @@ FLAGS.pretrain_classes = 400
 FLAGS.alpha = 0.15
 FLAGS.gamma = 0.0
 FLAGS.bbox_coeff = 50.0
-FLAGS.supp_level_offset = 0
+FLAGS.supp_level_offset = 2         # infer.py:94, pretrain.py:63
 FLAGS.multi_gpu = False
 
 

@@ -85,7 +85,50 @@ def test_reset_head_and_param_count():
     assert m.class_net.predict.conv_pw.weight.shape == (810, 64, 1, 1)
     assert abs(float(m.class_net.predict.conv_pw.bias[0]) + np.log(99.0)) < 1e-6
     n = sum(p.numel() for p in m.parameters())
-    assert 3.8e6 < n < 3.95e6                           # d0 ~ 3.9 M parameters
+    assert n == 3880067                                 # the published effdet table for tf_efficientdet_d0 (90 classes)
+
+
+@pytest.mark.parametrize('name,count,feat_chs', [('tf_efficientdet_d0', 3880067, [40, 112, 320]), ('tf_efficientdet_d1', 6625898, [40, 112, 320]),
+                                                 ('tf_efficientdet_d2', 8097039, [48, 120, 352]), ('tf_efficientdet_d3', 12032296, [48, 136, 384]),
+                                                 ('tf_efficientdet_d4', 20723675, [56, 160, 448])])
+def test_param_counts_equal_the_published_table(name, count, feat_chs):
+    """architecture pin for the (absent) timm backbone: the exact parameter counts rwightman/efficientdet-pytorch publishes
+    for 90 classes, and the channels of the three backbone feature maps the BiFPN consumes"""
+    from ood_object_detection_amd.effdet.factory import create_model
+    m = create_model(name, num_classes=90)
+    assert sum(p.numel() for p in m.parameters()) == count
+    assert [f['num_chs'] for f in m.fpn.in_feature_info[:3]] == feat_chs
+    assert [f['reduction'] for f in m.fpn.in_feature_info[:3]] == [8, 16, 32]
+
+
+def test_meta_nets_match_reference_layout(golden):
+    """MetaHead parameter names / order, ProjectionNet encoding tables + layer shapes, AnchorNet state-dict layout against the
+    reference classes (fixture meta_nets.npz), and the scripts' default supp_level_offset = 2 (infer.py:94, pretrain.py:63)"""
+    from _seeded import meta_nets_case
+    from ood_object_detection_amd.effdet.config import get_efficientdet_config
+    from ood_object_detection_amd.effdet.efficientdet import AnchorNet, EfficientDet, MetaHead, ProjectionNet
+    g = golden('meta_nets')
+    c = meta_nets_case(g)
+    cfg = get_efficientdet_config('tf_efficientdet_d0')
+    mh = MetaHead(cfg, pretrain_init=c['init'])
+    assert [n for n, _ in mh.named_parameters()] == [str(n) for n in g['mh_param_names']]
+    fw = mh.conv_dw_rep + mh.conv_pw_rep + mh.conv_pb_rep + mh.predict + mh.bn_rep_w + mh.bn_rep_b
+    assert len(fw) == int(g['mh_n_fast'])
+    for depth in (2, 3, 4):
+        pn = ProjectionNet(cfg, 128, proj_depth=depth)
+        lin = [m for m in pn.projection if isinstance(m, torch.nn.Linear)]
+        assert [m.weight.shape[0] for m in lin] + [lin[0].weight.shape[1]] == [int(v) for v in g['pn%d_dims' % depth]]
+    for k in ('anch_enc', 'cell_enc', 'lev_enc'):
+        assert np.array_equal(getattr(pn, k).numpy(), g['pn_' + k])
+    pn = ProjectionNet(cfg, 128, dot_mult=3.0, dot_add=3.0)
+    assert [float(pn.dot_mult), float(pn.dot_add)] == [float(v) for v in g['pn_dot']]
+    for layers in (3, 1):
+        sd = AnchorNet(cfg, num_anch_layers=layers).state_dict()
+        mine = {k: list(v.shape) for k, v in sd.items() if not k.endswith('num_batches_tracked')}
+        ref = {str(k): json.loads(str(s)) for k, s in zip(g['an%d_keys' % layers], g['an%d_shapes' % layers])}
+        assert mine == ref and list(mine.keys()) == list(ref.keys())
+    cfg.num_classes = 3
+    assert EfficientDet(cfg, pretrained_backbone=False).supp_level_offset == int(g['supp_level_offset_default']) == 2
 
 
 def test_backbone_arch_tables():

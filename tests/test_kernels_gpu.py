@@ -373,14 +373,32 @@ def test_soft_nms_golden(golden, tag):
     boxes, scores, classes = (torch.from_numpy(g[tag + s]).to(DEV) for s in ('_boxes', '_scores', '_classes'))
     for fn, args, key in ((soft_nms, dict(method_gaussian=True), '_g'), (soft_nms, dict(method_gaussian=False), '_l')):
         i, s = fn(boxes, scores, sigma=0.5, iou_threshold=0.3, score_threshold=0.001, **args)
-        n = min(len(g[tag + key + '_idx']), i.numel())
-        assert i.numel() == min(len(g[tag + key + '_idx']), 512)
-        assert np.array_equal(i.cpu().numpy()[:n], g[tag + key + '_idx'][:n])
-        assert np.abs(s.cpu().numpy()[:n] - g[tag + key + '_scores'][:n]).max() <= 1e-6
+        assert i.numel() == len(g[tag + key + '_idx'])                 # every pick, like soft_nms.py:88-112
+        assert np.array_equal(i.cpu().numpy(), g[tag + key + '_idx'])
+        assert np.abs(s.cpu().numpy() - g[tag + key + '_scores']).max() <= 1e-6
     i, s = batched_soft_nms(boxes, scores, classes, method_gaussian=True, iou_threshold=0.3, score_threshold=0.001)
-    n = i.numel()
-    assert np.array_equal(i.cpu().numpy(), g[tag + '_bg_idx'][:n])
-    assert np.abs(s.cpu().numpy() - g[tag + '_bg_scores'][:n]).max() <= 1e-6
+    assert i.numel() == len(g[tag + '_bg_idx'])
+    assert np.array_equal(i.cpu().numpy(), g[tag + '_bg_idx'])
+    assert np.abs(s.cpu().numpy() - g[tag + '_bg_scores']).max() <= 1e-6
+
+
+@pytest.mark.parametrize('n', [1500, 9000])
+def test_soft_nms_standalone_returns_every_pick_at_any_size(n):
+    """the stand-alone API has no pick budget and no size limit (reference: soft_nms.py:88-112): n = 1500 (> the old 512-pick cap,
+    register kernel) and n = 9000 (> 8192: the scratch-row kernel) against the oracle, run to exhaustion"""
+    from ood_object_detection_amd.effdet.soft_nms import batched_soft_nms
+    rs = np.random.RandomState(n)
+    c = rs.uniform(0, 400, (n, 2)); wh = rs.uniform(8, 80, (n, 2))
+    boxes = torch.from_numpy(np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32))
+    scores = torch.from_numpy(rs.permutation(n).astype(np.float32) / n * 0.98 + 0.011)        # distinct
+    classes = torch.from_numpy(rs.randint(0, 5, n).astype(np.int64))
+    ri, rsc = op.batched_soft_nms(boxes, scores, classes, True, 0.5, 0.3, 0.001)
+    i, s = batched_soft_nms(boxes.to(DEV), scores.to(DEV), classes.to(DEV), method_gaussian=True, sigma=0.5, iou_threshold=0.3, score_threshold=0.001)
+    assert i.numel() == ri.numel() and ri.numel() > 512
+    # rescored values differ by exp ulps; a swap of two picks needs two decayed scores within ~1e-7 of each other
+    same = (i.cpu() == ri)
+    assert float(same.float().mean()) >= 0.999
+    assert float((s.cpu()[same] - rsc[same]).abs().max()) <= 1e-6
 
 
 def test_nms_many_candidates_vs_oracle():

@@ -321,7 +321,7 @@ def test_meta_head_modes_through_model():
             assert float((a.float().cpu() - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max()))
         mh.add_head(); mh.to(DEV)
         co, ao, act = model(activs, mode='supp_cls')
-        assert len(co) == len(ao) == len(act) == 5
+        assert len(co) == len(ao) == len(act) == 3         # supp_level_offset = 2 (infer.py:94)
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
@@ -511,3 +511,175 @@ def test_non_square_input(dtype):
                 assert bool(torch.isfinite(a.float()).all())
         det = DetBenchPredict(m).to(DEV)(x.to(DEV).to(dtype))
     assert det.shape == (2, 100, 6) and float(det[..., 2].max()) > 128.0      # boxes reach into the wide half
+
+
+# ---- MetaHead / AnchorNet / ProjectionNet against the reference's own classes (fixture meta_nets.npz, generated by
+#      tools/make_golden.py from effdet/efficientdet.py:569-830 run on the CPU)
+def _close_ref(a, r, tol=2e-4):
+    r = torch.from_numpy(np.asarray(r))
+    a = a.float().cpu()
+    return tuple(a.shape) == tuple(r.shape) and float((a - r).abs().max()) <= tol * max(1.0, float(r.abs().max()))
+
+
+def test_meta_head_matches_reference_fixture(golden):
+    from _seeded import meta_lists, meta_nets_case, seeded_tensor
+    from ood_object_detection_amd.effdet.config import get_efficientdet_config
+    from ood_object_detection_amd.effdet.meta_head import MetaHead
+    g = golden('meta_nets')
+    c = meta_nets_case(g)
+    cfg = get_efficientdet_config('tf_efficientdet_d0')
+    mh = MetaHead(cfg, pretrain_init=c['init'])
+    with torch.no_grad():
+        mh.predict_pw.copy_(c['extra']['predict_pw']); mh.predict_pb.copy_(c['extra']['predict_pb'])
+    mh = mh.to(DEV)
+    x = [t.to(DEV) for t in c['x']]
+    L = c['L']
+    with torch.no_grad():
+        o, a = mh(x, ret_activs=True)
+        for i in range(L):
+            assert _close_ref(o[i], g['mh_out%d' % i]) and _close_ref(a[i], g['mh_act%d' % i])
+        o2 = mh(x, level_offset=2)
+        assert len(o2) == L - 2 and all(_close_ref(o2[i], g['mh_off2_out%d' % i]) for i in range(L - 2))
+        fw = mh.conv_dw_rep + mh.conv_pw_rep + mh.conv_pb_rep + mh.predict + mh.bn_rep_w + mh.bn_rep_b
+        fw = [w.detach() + 0.05 * seeded_tensor(c['seed'], 'fw%d' % i, w.shape).to(DEV) for i, w in enumerate(fw)]
+        o3, a3 = mh(x, fast_weights=fw, ret_activs=True)
+        for i in range(L):
+            assert _close_ref(o3[i], g['mh_fw_out%d' % i]) and _close_ref(a3[i], g['mh_fw_act%d' % i])
+        mh.add_head()
+        mh.predict_pw_sep.data.copy_(c['extra']['predict_pw_sep']); mh.predict_pb_sep.data.copy_(c['extra']['predict_pb_sep'])
+        mh.to(DEV)
+        off = int(g['supp_level_offset_default'])
+        co, ao, act = mh(x, ret_activs=True, level_offset=off, heads='both')
+        assert len(co) == int(g['mh_both_levels']) == L - off
+        for i in range(L - off):
+            assert _close_ref(co[i], g['mh_both_cls%d' % i]) and _close_ref(ao[i], g['mh_both_anch%d' % i]) and _close_ref(act[i], g['mh_both_act%d' % i])
+
+
+def test_supp_cls_mode_uses_the_scripts_default_level_offset(golden):
+    """EfficientDet.forward(mode='supp_cls') under defaults returns num_levels - 2 outputs (FLAGS.supp_level_offset = 2,
+    infer.py:94 / pretrain.py:63) that line up with the 3-level proj_anchors of dataloader.py:66"""
+    import copy
+    model, mh = _meta_head(torch.float32)
+    model = copy.deepcopy(model).to(DEV)
+    x = torch.from_numpy(seeded_array(32, 'img', (2, 3, 128, 128))).to(DEV)
+    with torch.no_grad():
+        activs = model(x, mode='supp_bb')
+        mh.add_head(); mh.to(DEV)
+        model.class_net = mh
+        co, ao, act = model(activs, mode='supp_cls')
+        assert len(co) == len(ao) == len(act) == model.config.num_levels - 2 == 3
+        assert [t.shape[-1] for t in ao] == [a.shape[-1] for a in activs[2:]]
+        model.supp_level_offset = 0
+        assert len(model(activs, mode='supp_cls')[0]) == 5
+
+
+@pytest.mark.parametrize('layers', [3, 1])
+def test_anchor_net_matches_reference_fixture(golden, layers):
+    import json
+    from _seeded import meta_nets_case, seeded_tensor
+    from ood_object_detection_amd.effdet.aux_nets import AnchorNet
+    from ood_object_detection_amd.effdet.config import get_efficientdet_config
+    g = golden('meta_nets')
+    c = meta_nets_case(g)
+    cfg = get_efficientdet_config('tf_efficientdet_d0')
+    net = AnchorNet(cfg, num_anch_layers=layers).eval()
+    sd = net.state_dict()
+    new = {k: (v if k.endswith('num_batches_tracked') else seeded_tensor(c['seed'] + layers, k, v.shape)) for k, v in sd.items()}
+    net.load_state_dict(new, strict=True)
+    net = net.to(DEV)
+    with torch.no_grad():
+        out = net([t.to(DEV) for t in c['x_anchor']])
+    for i in range(c['L']):
+        assert _close_ref(out[i], g['an%d_out%d' % (layers, i)])
+
+
+def test_projection_net_matches_reference_fixture(golden):
+    from _seeded import meta_nets_case, seeded_tensor
+    from ood_object_detection_amd.effdet.aux_nets import ProjectionNet
+    from ood_object_detection_amd.effdet.config import get_efficientdet_config
+    g = golden('meta_nets')
+    c = meta_nets_case(g)
+    cfg = get_efficientdet_config('tf_efficientdet_d0')
+    for depth in (2, 3, 4):
+        net = ProjectionNet(cfg, 128, proj_depth=depth)
+        with torch.no_grad():
+            for i, m in enumerate([m for m in net.projection if isinstance(m, torch.nn.Linear)]):
+                m.weight.copy_(seeded_tensor(c['seed'] + depth, 'proj%d' % i, m.weight.shape) * (1.0 / m.in_features) ** 0.5)
+            y = net.to(DEV)(c['x_proj'].to(DEV))
+        assert _close_ref(y, g['pn%d_out' % depth], tol=2e-5)
+    for n in (1, 7, 200, 1024):
+        med, cs = net.weighted_median(torch.from_numpy(g['wm%d_e' % n]).to(DEV), torch.from_numpy(g['wm%d_c' % n]).to(DEV))
+        assert np.array_equal(med.cpu().numpy(), g['wm%d_med' % n])
+        assert abs(float(cs) - float(g['wm%d_sum' % n])) <= 1e-4 * max(1.0, float(g['wm%d_sum' % n]))
+
+
+def test_engine_follows_in_place_parameter_updates():
+    """after a stock optimizer step (no `invalidate()` call) an inference forward must run on the NEW weights: the
+    engine key carries a fingerprint of the parameters' version counters, and train() <-> eval() transitions drop the engine"""
+    import copy
+    model, cfg, nodes, sd = seeded_model('tf_efficientdet_d0', 128, 20, seed=11)
+    model = copy.deepcopy(model).to(DEV)
+    x = torch.from_numpy(seeded_array(11, 'input', (2, 3, 128, 128))).to(DEV)
+
+    def fwd(m):
+        with torch.no_grad():
+            c, b = m(x)
+            return [t.clone() for t in list(c) + list(b)]
+
+    def fresh():
+        f = copy.deepcopy(model)
+        f.invalidate()
+        return fwd(f)
+    y0 = fwd(model)
+    eng0 = model._engine
+    assert fwd(model)[0].data_ptr() != 0 and model._engine is eng0                  # unchanged weights: the engine is reused
+    with torch.no_grad():
+        for p in model.class_net.parameters():
+            p.add_(0.01)                                                             # in place, no invalidate()
+    y1 = fwd(model)
+    assert model._engine is not eng0
+    assert all(torch.equal(a, b) for a, b in zip(y1, fresh())) and not torch.equal(y0[0], y1[0])
+    # stock torch.optim.Adam + clip_grad_norm_ (INTEGRATION.md), then model.eval() forward
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    for p in model.parameters():
+        p.grad = torch.ones_like(p) * 0.1
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+    opt.step()
+    y2 = fwd(model)
+    assert all(torch.equal(a, b) for a, b in zip(y2, fresh())) and not torch.equal(y1[0], y2[0])
+    # BatchNorm running statistics written in place
+    with torch.no_grad():
+        model.fpn.cell[0].fnode[0].after_combine.conv.bn.running_var.mul_(1.5)
+    y3 = fwd(model)
+    assert all(torch.equal(a, b) for a, b in zip(y3, fresh())) and not torch.equal(y2[0], y3[0])
+    # train() / eval() transitions rebuild as well
+    e = model._engine
+    model.train(); model.eval()
+    fwd(model)
+    assert model._engine is not e
+
+
+def test_nested_fork_inside_capture_is_refused():
+    """The round-1 segfault (box head forked onto a third stream inside a captured half-batch -> hipStreamEndCapture crash)
+    is unreachable through the package: DetBenchPredict refuses to fork from a forked stream while capturing.  Forking from
+    the capture's origin stream (what bench.py --sub-batches 0 and PipelinedPredict do) still works."""
+    from ood_object_detection_amd.effdet.bench import DetBenchPredict, forked_stream
+    model, cfg, nodes, sd = seeded_model('tf_efficientdet_d0', 128, 20, seed=11, cls_bias=0.0)
+    model = model.to(DEV).to(torch.bfloat16)
+    x = torch.from_numpy(seeded_array(11, 'input', (4, 3, 128, 128))).to(DEV).to(torch.bfloat16)
+    bench = DetBenchPredict(model, streams=2).to(DEV)
+    with torch.no_grad():
+        ref = bench(x).clone()
+        side, inner = torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            out = bench(x)                                  # fork from the origin stream: fine
+            cur = torch.cuda.current_stream(DEV)
+            inner.wait_stream(cur)
+            with forked_stream(inner):
+                with pytest.raises(RuntimeError, match='nested forks'):
+                    bench(x)                                # fork from a fork while capturing: refused before any launch
+            cur.wait_stream(inner)
+        g.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(out, ref)

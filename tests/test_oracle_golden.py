@@ -220,3 +220,67 @@ def test_evaluation_oracle_matches_reference(golden, tag):
     assert abs(r['mean_ap'] - float(g[tag + '_map'])) < 1e-12 and abs(r['mean_corloc'] - float(g[tag + '_corloc'])) < 1e-12
     assert np.allclose(r['per_class_ap'], g[tag + '_ap'], rtol=0, atol=1e-12, equal_nan=True)
     assert np.allclose(r['per_class_corloc'], g[tag + '_cl'], rtol=0, atol=1e-12, equal_nan=True)
+
+
+# ---- MetaHead / AnchorNet / ProjectionNet: the oracle's restatements against the reference's own classes
+#      (fixture tools/make_golden.py::gen_meta_nets; efficientdet.py:569-830)
+def test_meta_head_oracle_matches_reference(golden):
+    from _seeded import meta_lists, meta_nets_case, seeded_tensor
+    g = golden('meta_nets')
+    c = meta_nets_case(g)
+    dw, pw, pb, pred, bw, bb = meta_lists(c['init'], c['extra'], c['L'], c['R'])
+    tol = lambda a, b: float((a - torch.from_numpy(b)).abs().max()) <= 2e-5 * max(1.0, float(np.abs(b).max()))
+    o, a = om.meta_head_forward(dw, pw, pb, bw, bb, pred, c['x'])
+    for i in range(c['L']):
+        assert tol(o[i], g['mh_out%d' % i]) and tol(a[i], g['mh_act%d' % i])
+    o2, _ = om.meta_head_forward(dw, pw, pb, bw, bb, pred, c['x'], level_offset=2)
+    assert len(o2) == c['L'] - 2 and all(tol(o2[i], g['mh_off2_out%d' % i]) for i in range(c['L'] - 2))
+    # fast weights: the reference's flat list order
+    fw = dw + pw + pb + pred + bw + bb
+    assert len(fw) == int(g['mh_n_fast'])
+    fw = [w + 0.05 * seeded_tensor(c['seed'], 'fw%d' % i, w.shape) for i, w in enumerate(fw)]
+    R, L = c['R'], c['L']
+    o3, a3 = om.meta_head_forward(fw[:R], fw[R:2 * R], fw[2 * R:3 * R], fw[3 * R + 3:3 * R + 3 + R * L], fw[3 * R + 3 + R * L:],
+                                  fw[3 * R:3 * R + 3], c['x'])
+    for i in range(L):
+        assert tol(o3[i], g['mh_fw_out%d' % i]) and tol(a3[i], g['mh_fw_act%d' % i])
+    # separate class head, heads='both' with the scripts' default supp_level_offset = 2 (infer.py:94)
+    off = int(g['supp_level_offset_default'])
+    assert int(g['mh_both_levels']) == L - off
+    o4, a4, c4 = om.meta_head_forward(dw, pw, pb, bw, bb, pred, c['x'], level_offset=off,
+                                      predict_class=[c['extra']['predict_pw_sep'], c['extra']['predict_pb_sep']])
+    for i in range(L - off):
+        assert tol(c4[i], g['mh_both_cls%d' % i]) and tol(o4[i], g['mh_both_anch%d' % i]) and tol(a4[i], g['mh_both_act%d' % i])
+
+
+@pytest.mark.parametrize('layers', [3, 1])
+def test_anchor_net_oracle_matches_reference(golden, layers):
+    from _seeded import meta_nets_case, seeded_tensor
+    g = golden('meta_nets')
+    c = meta_nets_case(g)
+    keys = [str(k) for k in g['an%d_keys' % layers]]
+    shapes = [json.loads(str(s)) for s in g['an%d_shapes' % layers]]
+    sd = {k: seeded_tensor(c['seed'] + layers, k, s) for k, s in zip(keys, shapes)}
+    out = om.anchor_net_forward(sd, c['x_anchor'], c['L'], eps=float(g['an%d_eps' % layers]) or 1e-3)
+    for i in range(c['L']):
+        r = g['an%d_out%d' % (layers, i)]
+        assert float((out[i] - torch.from_numpy(r)).abs().max()) <= 2e-5 * max(1.0, float(np.abs(r).max()))
+
+
+def test_projection_net_oracle_matches_reference(golden):
+    from _seeded import meta_nets_case, seeded_tensor
+    g = golden('meta_nets')
+    c = meta_nets_case(g)
+    for depth in (2, 3, 4):
+        dims = [int(v) for v in g['pn%d_dims' % depth]]
+        d_in, outs = dims[-1], dims[:-1]
+        ws, k = [], d_in
+        for i, n in enumerate(outs):
+            ws.append(seeded_tensor(c['seed'] + depth, 'proj%d' % i, (n, k)) * (1.0 / k) ** 0.5)
+            k = n
+        y = om.projection_forward(ws, c['x_proj'])
+        r = g['pn%d_out' % depth]
+        assert float((y - torch.from_numpy(r)).abs().max()) <= 2e-5 * max(1.0, float(np.abs(r).max()))
+    for n in (1, 7, 200, 1024):
+        med, cs = om.weighted_median(torch.from_numpy(g['wm%d_e' % n]), torch.from_numpy(g['wm%d_c' % n]))
+        assert np.array_equal(med.numpy(), g['wm%d_med' % n]) and abs(float(cs) - float(g['wm%d_sum' % n])) <= 1e-5 * max(1.0, float(cs))

@@ -20,6 +20,9 @@ Fixtures written
     config.npz                model_config.get_efficientdet_config + fpn_config.bifpn_config dumps
     bifpn_head.npz            EfficientDet(config) forward (reference BiFpn/HeadNet code on stub
                               conv layers and the oracle backbone): key/shape list + outputs
+    meta_nets.npz             the reference's own MetaHead / AnchorNet / ProjectionNet classes
+                              (efficientdet.py:569-830) on seeded weights and inputs: forwards, fast_weights,
+                              level_offset, separate head, weighted_median, encoding tables
 """
 import hashlib
 import json
@@ -258,6 +261,119 @@ def gen_bifpn_head():
     save('bifpn_head', **out)
 
 
+def gen_meta_nets():
+    """The reference's MetaHead / AnchorNet / ProjectionNet (effdet/efficientdet.py:569-830), instantiated on the CPU.
+    Their constructors read absl FLAGS (supplied by the stub namespace below) and move a few buffers with
+    `.to('cuda')` / `.cuda()`; in THIS script only, those two calls are mapped to the CPU so the classes can be built in
+    the GPU-less container.  Everything else - constructor, parameter order, forward - is the reference's code."""
+    from absl import flags
+    FL = flags.FLAGS
+    from effdet.config import get_efficientdet_config
+    import effdet.efficientdet as ref
+    _to, _cuda = torch.Tensor.to, torch.Tensor.cuda
+
+    def to_cpu(self, *a, **k):
+        a = tuple('cpu' if (isinstance(v, str) and v.startswith('cuda')) else v for v in a)
+        if isinstance(k.get('device'), str) and k['device'].startswith('cuda'):
+            k['device'] = 'cpu'
+        return _to(self, *a, **k)
+    torch.Tensor.to = to_cpu
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    out = {}
+    try:
+        cfg = get_efficientdet_config('tf_efficientdet_d0')
+        Fc, A, L, R = cfg.fpn_channels, 9, cfg.num_levels, cfg.box_class_repeats
+        sizes = [16, 8, 4, 2, 1]
+        B = 3
+        seed = 51
+        # ---- MetaHead: pretrain_init = a seeded class_net state dict (infer.py:186-191)
+        keys = {}
+        for l in range(R):
+            keys['class_net.conv_rep.%d.conv_dw.weight' % l] = (Fc, 1, 3, 3)
+            keys['class_net.conv_rep.%d.conv_pw.weight' % l] = (Fc, Fc, 1, 1)
+            keys['class_net.conv_rep.%d.conv_pw.bias' % l] = (Fc,)
+            for lev in range(L):
+                keys['class_net.bn_rep.%d.%d.bn.weight' % (l, lev)] = (Fc,)
+                keys['class_net.bn_rep.%d.%d.bn.bias' % (l, lev)] = (Fc,)
+        keys['class_net.predict.conv_dw.weight'] = (Fc, 1, 3, 3)
+        init = {k: seeded_tensor(seed, k, shp) for k, shp in keys.items()}
+        for sep in (False, True):
+            FL.separate_head = sep
+            mh = ref.MetaHead(cfg, pretrain_init=init)
+            with torch.no_grad():
+                mh.predict_pw.copy_(seeded_tensor(seed, 'meta.predict_pw', mh.predict_pw.shape) * (1.0 / Fc) ** 0.5)
+                mh.predict_pb.copy_(seeded_tensor(seed, 'meta.predict_pb', mh.predict_pb.shape))
+                if sep:
+                    mh.add_head()
+                    mh.predict_pw_sep.data.copy_(seeded_tensor(seed, 'meta.predict_pw_sep', mh.predict_pw_sep.shape) * (1.0 / Fc) ** 0.5)
+                    mh.predict_pb_sep.data.copy_(seeded_tensor(seed, 'meta.predict_pb_sep', mh.predict_pb_sep.shape))
+            x = [torch.from_numpy(seeded_array(seed, 'lvl%d' % i, (B, Fc, s, s))) for i, s in enumerate(sizes)]
+            with torch.no_grad():
+                if not sep:
+                    o, a = mh([t.clone() for t in x], ret_activs=True)
+                    for i in range(L):
+                        out['mh_out%d' % i], out['mh_act%d' % i] = o[i], a[i]
+                    o2 = mh([t.clone() for t in x], level_offset=2)
+                    assert len(o2) == L - 2
+                    for i in range(L - 2):
+                        out['mh_off2_out%d' % i] = o2[i]
+                    # fast weights in the reference's list order (efficientdet.py:645-652): a perturbed copy of the parameters
+                    fw = list(mh.conv_dw_rep) + list(mh.conv_pw_rep) + list(mh.conv_pb_rep) + list(mh.predict) + list(mh.bn_rep_w) + list(mh.bn_rep_b)
+                    fw = [w.detach() + 0.05 * seeded_tensor(seed, 'fw%d' % i, w.shape) for i, w in enumerate(fw)]
+                    o3, a3 = mh([t.clone() for t in x], fast_weights=fw, ret_activs=True)
+                    for i in range(L):
+                        out['mh_fw_out%d' % i], out['mh_fw_act%d' % i] = o3[i], a3[i]
+                    out['mh_n_fast'] = np.int64(len(fw))
+                    # the order of named parameters is part of the contract (optimizers / checkpoints of infer.py)
+                    out['mh_param_names'] = np.array([n for n, _ in mh.named_parameters()])
+                else:
+                    co, ao, act = mh([t.clone() for t in x], ret_activs=True, level_offset=FL.supp_level_offset, heads='both')
+                    out['mh_both_levels'] = np.int64(len(co))
+                    for i in range(len(co)):
+                        out['mh_both_cls%d' % i], out['mh_both_anch%d' % i], out['mh_both_act%d' % i] = co[i], ao[i], act[i]
+        out['mh_meta'] = np.array([seed, B, Fc, A, L, R] + sizes)
+        out['supp_level_offset_default'] = np.int64(2)            # infer.py:94 / pretrain.py:63
+        # ---- AnchorNet (FLAGS.num_anch_layers 3 and 1; eval-mode BN with seeded running statistics)
+        FL.supp_alpha, FL.learn_alpha, FL.inner_alpha, FL.detach_anch = False, False, 0.25, False
+        for layers in (3, 1):
+            FL.num_anch_layers = layers
+            net = ref.AnchorNet(cfg).eval()
+            sd = net.state_dict()
+            new = {k: (v if k.endswith('num_batches_tracked') else seeded_tensor(seed + layers, k, v.shape)) for k, v in sd.items()}
+            net.load_state_dict(new, strict=True)
+            x = [torch.from_numpy(seeded_array(seed + 1, 'an%d' % i, (2, Fc, s, s))) for i, s in enumerate(sizes)]
+            with torch.no_grad():
+                o = net([t.clone() for t in x])
+            out['an%d_keys' % layers] = np.array([k for k in sd.keys() if not k.endswith('num_batches_tracked')])
+            out['an%d_shapes' % layers] = np.array([json.dumps(list(sd[k].shape)) for k in sd.keys() if not k.endswith('num_batches_tracked')])
+            out['an%d_eps' % layers] = np.float64(net.bn_rep[0][0].bn.eps if layers > 1 else 0.0)
+            for i in range(L):
+                out['an%d_out%d' % (layers, i)] = o[i]
+        # ---- ProjectionNet: encoding tables, MLP for every proj_depth, weighted_median
+        FL.dot_mult, FL.dot_add, FL.median_grad = 3.0, 3.0, False
+        for depth in (2, 3, 4):
+            FL.proj_depth = depth
+            net = ref.ProjectionNet(cfg, 128)
+            lin = [m for m in net.projection if isinstance(m, torch.nn.Linear)]
+            with torch.no_grad():
+                for i, m in enumerate(lin):
+                    m.weight.copy_(seeded_tensor(seed + depth, 'proj%d' % i, m.weight.shape) * (1.0 / m.in_features) ** 0.5)
+                xin = torch.from_numpy(seeded_array(seed + 2, 'px', (5, 37, Fc + 42)))
+                out['pn%d_out' % depth] = net(xin)
+            out['pn%d_dims' % depth] = np.array([m.weight.shape[0] for m in lin] + [lin[0].weight.shape[1]])
+        out['pn_anch_enc'], out['pn_cell_enc'], out['pn_lev_enc'] = net.anch_enc, net.cell_enc, net.lev_enc
+        out['pn_dot'] = np.array([float(net.dot_mult), float(net.dot_add)])
+        g = torch.Generator().manual_seed(2)
+        for n in (1, 7, 200, 1024):
+            e = torch.randn(n, 24, generator=g)
+            c = torch.rand(n, generator=g)
+            med, cs = net.weighted_median(e, c)
+            out['wm%d_e' % n], out['wm%d_c' % n], out['wm%d_med' % n], out['wm%d_sum' % n] = e, c, med, cs
+    finally:
+        torch.Tensor.to, torch.Tensor.cuda = _to, _cuda
+    save('meta_nets', **out)
+
+
 def gen_evaluation():
     """mAP / CorLoc of the reference's ObjectDetectionEvaluator (effdet/evaluation/detection_evaluator.py:96-316) the way
     pretrain.py:246-252 drives it."""
@@ -283,6 +399,6 @@ def gen_evaluation():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['anchors', 'post_process', 'decode', 'soft_nms', 'generate_detections', 'loss',
-                             'labeler', 'config', 'bifpn_head', 'evaluation']
+                             'labeler', 'config', 'bifpn_head', 'evaluation', 'meta_nets']
     for w in which:
         globals()['gen_' + w]()
