@@ -123,6 +123,132 @@ def cpu_baseline(model_cpu_sd, cfg, image, num_classes, budget_s=20.0, gpu_check
     return out
 
 
+def detection_agreement(det_a, cnt_a, anc_a, det_b, cnt_b, anc_b):
+    """Agreement of two DetBenchPredict results ([B, max_det, 6] = x1, y1, x2, y2, score, class; valid rows per image in cnt;
+    anc = the anchor index every kept detection came from, `last_ood['anchor_index']`).  Two detections are THE SAME
+    detection when they come from the same anchor with the same class.  Returns the fraction of A's detections that B also
+    has and, over those pairs, the L-inf of box coordinates (pixels) and of scores - the detection-level counterpart of
+    BASELINE.json's 'box/score L-inf vs ref'.  Unmatched detections are near-ties of the discrete steps (top-k, NMS)."""
+    det_a, det_b, anc_a, anc_b = det_a.float().cpu(), det_b.float().cpu(), anc_a.cpu(), anc_b.cpu()
+    n_ref = n_match = 0
+    box_linf = score_linf = 0.0
+    for i in range(det_a.shape[0]):
+        na, nb = int(cnt_a[i]), int(cnt_b[i])
+        kb = {(int(anc_b[i, j]), int(det_b[i, j, 5])): j for j in range(nb)}
+        n_ref += na
+        for r in range(na):
+            j = kb.get((int(anc_a[i, r]), int(det_a[i, r, 5])))
+            if j is None:
+                continue
+            n_match += 1
+            box_linf = max(box_linf, float((det_b[i, j, :4] - det_a[i, r, :4]).abs().max()))
+            score_linf = max(score_linf, float(abs(det_b[i, j, 4] - det_a[i, r, 4])))
+    return {'matched_frac': round(n_match / max(1, n_ref), 4), 'boxes_linf_px': round(box_linf, 4), 'scores_linf': round(score_linf, 6),
+            'detections_ref': n_ref}
+
+
+def parity_bf16(model_f32_cpu, x_cpu, dev, soft_nms=False):
+    """bf16 (the benched mode) against the float32 HIP path, same weights, same images, whole DetBenchPredict: detection
+    agreement plus the L-inf of the head outputs and of the per-anchor OOD energy."""
+    import copy
+    from ood_object_detection_amd.effdet.bench import DetBenchPredict
+    out = {}
+    res = {}
+    for tag, dt in (('f32', torch.float32), ('bf16', torch.bfloat16)):
+        m = copy.deepcopy(model_f32_cpu).to(dev).to(dt)
+        m.config.soft_nms = bool(soft_nms)
+        b = DetBenchPredict(m, streams=1).to(dev)
+        with torch.no_grad():
+            det = b(x_cpu.to(dev).to(dt))
+        eng = m._engine
+        res[tag] = (det.float().cpu(), b.last_count.cpu(), eng.cls_all.float().cpu(), eng.box_all.float().cpu(), m.ood_energy.float().cpu(),
+                    b.last_ood['anchor_index'].cpu())
+        anchors = b.anchors.boxes.float().cpu()
+        del b, m
+    out.update(detection_agreement(res['f32'][0], res['f32'][1], res['f32'][5], res['bf16'][0], res['bf16'][1], res['bf16'][5]))
+    # the same comparison with the discrete steps taken out: for every detection the float32 path kept, what the bf16 head
+    # outputs give for that SAME (anchor, class) - score = sigmoid(logit), box = decode (effdet/anchors.py:51-85) - so every
+    # reference detection is covered whether or not top-k / NMS made the same choice
+    det32, cnt32, cls32, box32, _, anc32 = res['f32']
+    cls16, box16 = res['bf16'][2], res['bf16'][3]
+
+    def decode(rel, a):
+        ya, xa, ha, wa = (a[:, 0] + a[:, 2]) / 2, (a[:, 1] + a[:, 3]) / 2, a[:, 2] - a[:, 0], a[:, 3] - a[:, 1]
+        w, h = torch.exp(rel[:, 3]) * wa, torch.exp(rel[:, 2]) * ha
+        yc, xc = rel[:, 0] * ha + ya, rel[:, 1] * wa + xa
+        return torch.stack([xc - w / 2, yc - h / 2, xc + w / 2, yc + h / 2], 1)
+    sb = ss = 0.0
+    for i in range(det32.shape[0]):
+        n = int(cnt32[i])
+        if n == 0:
+            continue
+        a_idx, c_idx = anc32[i, :n], det32[i, :n, 5].long() - 1
+        ss = max(ss, float((torch.sigmoid(cls32[i, a_idx, c_idx]) - torch.sigmoid(cls16[i, a_idx, c_idx])).abs().max()))
+        sb = max(sb, float((decode(box32[i, a_idx], anchors[a_idx]) - decode(box16[i, a_idx], anchors[a_idx])).abs().max()))
+    out['same_candidates'] = {'boxes_linf_px': round(sb, 4), 'scores_linf': round(ss, 6)}
+    out['images'] = int(x_cpu.shape[0])
+    out['class_logits_linf'] = round(float((res['f32'][2] - res['bf16'][2]).abs().max()), 5)
+    out['box_outputs_linf'] = round(float((res['f32'][3] - res['bf16'][3]).abs().max()), 5)
+    out['ood_energy_linf'] = round(float((res['f32'][4] - res['bf16'][4]).abs().max()), 5)
+    out['class_logits_absmax'] = round(float(res['f32'][2].abs().max()), 4)
+    out['reference'] = 'float32 HIP path (itself checked against the CPU oracle: parity_vs_hip_f32)'
+    return out
+
+
+def timed_steps(model, x, dev, nfl, sub, steps, warmup, use_graph, barrier):
+    """W warm-up + K timed DetBenchPredict.forward steps with `nfl` batches in flight (own engine instance, input and stream
+    per slot, shared weights).  Returns (elapsed seconds, launch mode, first bench)."""
+    import copy
+    from ood_object_detection_amd.effdet.bench import DetBenchPredict
+    benches = [DetBenchPredict(model if i == 0 else copy.copy(model), streams=sub).to(dev) for i in range(nfl)]
+    xs = [x] + [x.clone() for _ in range(nfl - 1)]
+    streams = [torch.cuda.Stream(dev) for _ in range(nfl)]
+    with torch.no_grad():
+        for _ in range(max(1, min(warmup, 3))):
+            for b_, x_ in zip(benches, xs):
+                b_(x_)
+        torch.cuda.synchronize(dev)
+        launch, graphs = 'eager', None
+        if use_graph:
+            try:
+                graphs = []
+                for b_, x_, s_ in zip(benches, xs, streams):
+                    s_.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(s_):
+                        b_(x_)
+                    torch.cuda.current_stream(dev).wait_stream(s_)
+                    g_ = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_, stream=s_):
+                        b_(x_)
+                    graphs.append(g_)
+                for g_, s_ in zip(graphs, streams):
+                    with torch.cuda.stream(s_):
+                        g_.replay()
+                torch.cuda.synchronize(dev)
+                launch = 'hipgraph'
+            except Exception as e:          # launch-mode choice only: the same HIP kernels run either way
+                sys.stderr.write('graph capture unavailable (%s); launching eagerly\n' % (e,))
+                graphs = None
+                torch.cuda.synchronize(dev)
+
+        def step(i):
+            k = i % nfl
+            with torch.cuda.stream(streams[k]):
+                if graphs is not None:
+                    graphs[k].replay()
+                else:
+                    benches[k](xs[k])
+        for i in range(warmup):
+            step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    return elapsed, launch, benches[0]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -135,6 +261,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying one hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the in-flight-1 / float32 / parity_bf16 side measurements')
     ap.add_argument('--soft-nms', action='store_true')
     ap.add_argument('--profile-out', default='')
     ap.add_argument('--in-flight', type=int, default=3,
@@ -171,7 +298,6 @@ def main():
     sd_cpu = {k: v.clone().float() for k, v in model.state_dict().items()} if want_cpu else None
     model = model.to(dev).to(dtype)
     sub = args.sub_batches or None
-    bench = DetBenchPredict(model, streams=sub).to(dev)
     B = args.batch
     x = (torch.randn(B, 3, args.image, args.image, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + rank))).to(dtype)
 
@@ -185,53 +311,7 @@ def main():
     nfl = max(1, args.in_flight)
     # every in-flight slot has its own engine (activation buffers, launch plan) on shallow copies of the model (shared weights),
     # its own input batch and its own stream; each step still is one full DetBenchPredict.forward over B images
-    benches = [bench] + [DetBenchPredict(copy.copy(model), streams=sub).to(dev) for _ in range(nfl - 1)]
-    xs = [x] + [x.clone() for _ in range(nfl - 1)]
-    streams = [torch.cuda.Stream(dev) for _ in range(nfl)]
-    with torch.no_grad():
-        for _ in range(max(1, args.warmup)):
-            for b_, x_ in zip(benches, xs):
-                det = b_(x_)
-        torch.cuda.synchronize(dev)
-        launch = 'eager'
-        graphs = None
-        if not args.no_graph:
-            try:
-                graphs = []
-                for b_, x_, s_ in zip(benches, xs, streams):
-                    s_.wait_stream(torch.cuda.current_stream(dev))
-                    with torch.cuda.stream(s_):
-                        b_(x_)
-                    torch.cuda.current_stream(dev).wait_stream(s_)
-                    g_ = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g_, stream=s_):
-                        det = b_(x_)
-                    graphs.append(g_)
-                for g_, s_ in zip(graphs, streams):
-                    with torch.cuda.stream(s_):
-                        g_.replay()
-                torch.cuda.synchronize(dev)
-                launch = 'hipgraph'
-            except Exception as e:          # launch-mode choice only: the same HIP kernels run either way
-                sys.stderr.write('graph capture unavailable (%s); launching eagerly\n' % (e,))
-                graphs = None
-                torch.cuda.synchronize(dev)
-
-        def step(i):
-            k = i % nfl
-            with torch.cuda.stream(streams[k]):
-                if graphs is not None:
-                    graphs[k].replay()
-                else:
-                    benches[k](xs[k])
-        for i in range(args.warmup):
-            step(i)
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(i)
-        barrier()
-        elapsed = time.perf_counter() - t0
+    elapsed, launch, bench = timed_steps(model, x, dev, nfl, sub, args.steps, args.warmup, not args.no_graph, barrier)
 
     if dist is not None:
         t = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
@@ -328,6 +408,23 @@ def main():
                 fh.write('%-10s launches %4d  ms %8.3f  alg_GB %8.3f  GB/s %8.1f  TFLOP/s %7.2f\n' % (
                     k, f['launches'], f['ms'], f['bytes'] / 1e9, f['bytes'] / f['ms'] / 1e6, f['flops'] / f['ms'] / 1e9))
             fh.write('# network (sum of launches) ms %.3f ; timed step ms %.3f (adds top-k/decode/NMS/OOD gather)\n' % (net_ms, ms_per_step))
+    # ---- beside the headline (N = 1 only, outside the timed region): the same workload with ONE batch in flight, the float32
+    #      (reference-precision) path, and the accuracy of the benched bf16 mode at detection level
+    extra = {}
+    if world == 1 and not args.no_extras:
+        ks = max(5, min(args.steps, 10))
+        if nfl != 1:
+            e1, _, _ = timed_steps(copy.copy(model), x, dev, 1, sub, ks, 2, not args.no_graph, barrier)
+            extra['in_flight_1_images_per_sec'] = round(B * ks / e1, 1)
+        if args.dtype == 'bf16':
+            m32 = build_model(args.model, args.image, args.classes).to(dev)
+            m32.config.soft_nms = bool(args.soft_nms)
+            e32, _, _ = timed_steps(m32, x.float(), dev, nfl, sub, ks, 2, not args.no_graph, barrier)
+            extra['f32_images_per_sec'] = round(B * ks / e32, 1)
+            del m32
+            torch.cuda.empty_cache()
+            xp = torch.randn(4, 3, args.image, args.image, generator=torch.Generator().manual_seed(5))
+            extra['parity_bf16'] = parity_bf16(build_model(args.model, args.image, args.classes), xp, dev, soft_nms=args.soft_nms)
     cpu = None
     if want_cpu:
         def gpu_check(x1):
@@ -351,6 +448,8 @@ def main():
                    'detections_per_image_mean': round(float(counts.mean()), 1)},
         'roofline': roofline, 'cpu_baseline': cpu,
     }
+    out['config']['images_in_flight'] = nfl * B
+    out.update(extra)
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

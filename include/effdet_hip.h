@@ -204,10 +204,11 @@ int effdet_nms_soft_large(void* stream, const float* boxes, const float* scores,
                           float iou_threshold, float score_threshold, int max_det,
                           const float* img_scale, float* det, int* det_count, int* keep_src, float* score_scratch);
 
-/* OOD scores of the kept detections: energy/maxlogit [B,n_anchors] -> [B,max_det] (0 where padded). */
+/* OOD scores of the kept detections: energy/maxlogit [B,n_anchors] -> [B,max_det] (0 where padded); out_anchor
+ * (optional) receives the anchor index each kept detection came from (-1 where padded). */
 int effdet_gather_ood(void* stream, const int* keep_src, const long long* indices, const float* energy,
                       const float* maxlogit, long long n_anchors, int B, int k, int max_det,
-                      float* out_energy, float* out_maxlogit);
+                      float* out_energy, float* out_maxlogit, long long* out_anchor);
 
 /* ---- training-side operators -------------------------------------------------- */
 

@@ -113,7 +113,7 @@ SIGNATURES = {
                                          c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     'effdet_train_bn_bwd_prep': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'effdet_gather_ood': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_int, c_int, c_int,
-                                  c_void_p, c_void_p]),
+                                  c_void_p, c_void_p, c_void_p]),
 }
 
 

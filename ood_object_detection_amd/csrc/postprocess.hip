@@ -771,18 +771,20 @@ __global__ __launch_bounds__(1024) void nms_soft_global_kernel(NmsArgs p, float*
 
 __global__ void gather_ood_kernel(const int* keep_src, const long long* indices, const float* energy,
                                   const float* maxlogit, long long n_anchors, int k, int max_det, int B,
-                                  float* out_energy, float* out_maxlogit) {
+                                  float* out_energy, float* out_maxlogit, long long* out_anchor) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * max_det) return;
     const int b = i / max_det;
     const int s = keep_src[i];
     float e = 0.f, m = 0.f;
+    long long a = -1;
     if (s >= 0) {
-        const long long a = indices[(long long)b * k + s];
+        a = indices[(long long)b * k + s];
         e = energy[(long long)b * n_anchors + a];
         m = maxlogit[(long long)b * n_anchors + a];
     }
     out_energy[i] = e; out_maxlogit[i] = m;
+    if (out_anchor) out_anchor[i] = a;
 }
 
 // Sources that walk scalar elements (row maxima, gathered anchor rows) are latency bound per thread: give
@@ -1005,12 +1007,12 @@ extern "C" int effdet_nms_soft_large(void* stream, const float* boxes, const flo
 
 extern "C" int effdet_gather_ood(void* stream, const int* keep_src, const long long* indices, const float* energy,
                                  const float* maxlogit, long long n_anchors, int B, int k, int max_det,
-                                 float* out_energy, float* out_maxlogit) {
+                                 float* out_energy, float* out_maxlogit, long long* out_anchor) {
     EFFDET_ENTER();
     if (!keep_src || !indices || !energy || !maxlogit || !out_energy || !out_maxlogit || B <= 0 || k <= 0 || max_det <= 0) return EFFDET_EINVAL;
     const int total = B * max_det;
     hipLaunchKernelGGL(gather_ood_kernel, dim3((total + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       keep_src, indices, energy, maxlogit, n_anchors, k, max_det, B, out_energy, out_maxlogit);
+                       keep_src, indices, energy, maxlogit, n_anchors, k, max_det, B, out_energy, out_maxlogit, out_anchor);
     return effdet_check_launch();
 }
 

@@ -126,11 +126,13 @@ class DetBenchPredict(nn.Module):
             max_det_per_image=self.max_det_per_image, soft_nms=self.soft_nms, box_all=_packed(box_out, self.num_levels, 4))
         energy = torch.empty(B, self.max_det_per_image, dtype=torch.float32, device=x.device)
         maxlogit = torch.empty_like(energy)
+        anchor = torch.empty(B, self.max_det_per_image, dtype=torch.int64, device=x.device)
         st = torch.cuda.current_stream(x.device).cuda_stream
         _lib.check(lib.effdet_gather_ood(st, keep_src.data_ptr(), indices.data_ptr(), model.ood_energy.data_ptr(),
                                          model.ood_max_logit.data_ptr(), model.ood_energy.shape[1], B, k,
-                                         self.max_det_per_image, energy.data_ptr(), maxlogit.data_ptr()), 'effdet_gather_ood')
-        return det, count, energy, maxlogit
+                                         self.max_det_per_image, energy.data_ptr(), maxlogit.data_ptr(), anchor.data_ptr()),
+                   'effdet_gather_ood')
+        return det, count, energy, maxlogit, anchor
 
     def _split_setup(self, x, n):
         """Shallow model copies (shared parameters) with engines that write their OOD rows into one [B, N] buffer."""
@@ -170,10 +172,10 @@ class DetBenchPredict(nn.Module):
         B = x.shape[0]
         n = self.streams if self.streams is not None else (2 if B >= 16 and B % 2 == 0 else 1)
         if n <= 1 or B % n or x.device.type != 'cuda':
-            det, count, energy, maxlogit = self._one(self.model, x, img_scale, img_size)
+            det, count, energy, maxlogit, anchor = self._one(self.model, x, img_scale, img_size)
             self.last_count = count
             self.last_ood = {'energy': energy, 'max_logit': maxlogit, 'anchor_energy': self.model.ood_energy,
-                             'anchor_max_logit': self.model.ood_max_logit}
+                             'anchor_max_logit': self.model.ood_max_logit, 'anchor_index': anchor}
             return det
         if getattr(_fork, 'depth', 0) > 0 and torch.cuda.is_current_stream_capturing():
             raise RuntimeError('DetBenchPredict(streams=%d) would fork sub-batch streams from a stream that is itself a fork inside '
@@ -194,7 +196,8 @@ class DetBenchPredict(nn.Module):
         det = torch.cat([o[0] for o in outs], 0)
         self.last_count = torch.cat([o[1] for o in outs], 0)
         self.last_ood = {'energy': torch.cat([o[2] for o in outs], 0), 'max_logit': torch.cat([o[3] for o in outs], 0),
-                         'anchor_energy': self._ood_buf[0], 'anchor_max_logit': self._ood_buf[1]}
+                         'anchor_energy': self._ood_buf[0], 'anchor_max_logit': self._ood_buf[1],
+                         'anchor_index': torch.cat([o[4] for o in outs], 0)}
         return det
 
     def ragged(self, det):

@@ -129,7 +129,9 @@ def test_infer_validation_iteration_as_written():
             qry_activs, qry_box_out = model(qry_feats, mode='not_cls')                                # :349
             qry_activs = [a.clone() for a in qry_activs]
             anch_confs, obj_embds = model(supp_activs, fast_weights=None, mode='supp_cls')            # :563
-            assert len(anch_confs) == model_config.num_levels and anch_confs[0].shape[:2] == (3, 9)
+            # FLAGS.supp_level_offset defaults to 2 (infer.py:94): the support pass returns the 3 coarsest levels, lining up with
+            # the 3-level proj_anchors of dataloader.py:66
+            assert len(anch_confs) == model_config.num_levels - 2 and anch_confs[0].shape[:2] == (3, 9)
             assert obj_embds[0].shape[1] == model_config.fpn_channels
             fast_weights = [par - 0.01 * torch.ones_like(par) if 'predict_p' in n else par
                             for n, par in model.class_net.named_parameters()]                        # :660-678 (first-order stand-in)

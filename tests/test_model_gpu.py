@@ -68,10 +68,8 @@ def test_fp32_modes_consistent(d0):
 
 
 def test_bf16_measured(d0):
-    """bf16 throughput mode.  The error against the fp32 oracle is MEASURED and printed, not assumed: the
-    seeded random network amplifies any perturbation ~100x through its depth (fp32 eps 6e-8 -> 1e-5 at the
-    heads), so rounding weights + input to bf16 alone (fp32 compute, CPU oracle) already costs 6-12 % rms at
-    the heads.  The assertion therefore bounds the HIP bf16 path against THAT (same rounded weights), loosely."""
+    """bf16 throughput mode, whole network: the error of the head outputs against the fp32 oracle, against the oracle run
+    on bf16-rounded weights + input (fp32 compute), and the cost of that weight rounding alone - measured, printed, bounded."""
     import copy
     m = copy.deepcopy(d0['model']).to(DEV).to(torch.bfloat16)
     x = d0['x'].to(DEV).to(torch.bfloat16)
@@ -88,7 +86,10 @@ def test_bf16_measured(d0):
     w_only = max(rms(a, r) for a, r in zip(list(cls_q) + list(box_q), list(d0['cls']) + list(d0['box'])))
     print('bf16 head outputs, rel-rms: HIP vs fp32 oracle %.3f | HIP vs oracle(bf16-rounded weights) %.3f | '
           'weight rounding alone %.3f' % (vs_fp32, vs_rounded, w_only))
-    assert vs_rounded < 0.5 and vs_fp32 < 0.6
+    # bounds = ~1.6 x the values measured on MI355X in round 2 (0.035 / 0.077 / 0.063 on this BN-calibrated network); the
+    # per-stage bands live in test_configs_gpu.py::test_bf16_per_stage_error_bounds, detection-level agreement in
+    # test_bf16_detection_agreement_*
+    assert vs_rounded < 0.06 and vs_fp32 < 0.12
 
 
 @pytest.mark.parametrize('soft', [False, True])
