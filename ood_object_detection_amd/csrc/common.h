@@ -162,6 +162,13 @@ DEV void mma_chunk(const Frag<float>& a, const Frag<float>& b, f32x4& acc) {
     for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[s], b.v[s], acc, 0, 0, 0);
 }
 
+// mbconv_roll.hip (internal, hidden from the C ABI): rolling-window form of the fused MBConv front half, bf16 only.
+// parts = SE pool partial rows per image when the form applies to the geometry, 0 otherwise.
+__attribute__((visibility("hidden"))) int effdet_mbconv_roll_parts(int H, int W, int Cin, int mid, int k, int stride);
+__attribute__((visibility("hidden"))) int effdet_mbconv_roll_launch(hipStream_t st, const void* X, const float* in_gate, void* Y, const void* W1, const float* s1, const float* t1,
+                              const float* taps, const float* s2, const float* t2, float* pool_partial,
+                              int B, int H, int W, int Cin, int mid, int k, int stride);
+
 // TF "SAME" padding: amount in front (reference semantics live in timm)
 static inline int same_pad_before(int size, int k, int s) {
     int out = (size + s - 1) / s;

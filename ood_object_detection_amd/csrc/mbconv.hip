@@ -806,6 +806,12 @@ int launch_deep(hipStream_t st, const MbArgs& a, const DeepGeometry& g) {
 
 template <typename T>
 int launch_mb(hipStream_t st, MbArgs& a) {
+    if constexpr (sizeof(T) == 2) {
+        // bf16: the rolling-window form (mbconv_roll.hip) wherever its geometry applies
+        if (effdet_mbconv_roll_parts(a.H, a.W, a.Cin, a.mid, a.k, a.stride) > 0)
+            return effdet_mbconv_roll_launch(st, a.X, a.in_gate, a.Y, a.W1, a.s1, a.t1, a.taps, a.s2, a.t2, a.pool_partial,
+                                             a.B, a.H, a.W, a.Cin, a.mid, a.k, a.stride);
+    }
     const DeepGeometry dg = pick_deep<T>(a.H, a.W, a.Cin, a.mid, a.k, a.stride);
     if (dg.use && !a.in_gate) return launch_deep<T>(st, a, dg);                    // gated inputs always take the spatial form
     const Geometry g = pick_tile<T>(a.Ho, a.Wo, a.Cin, a.k, a.stride);
@@ -834,6 +840,10 @@ int launch_mb(hipStream_t st, MbArgs& a) {
 extern "C" int effdet_mbconv_tiles_per_image(int dtype, int H, int W, int Cin, int mid, int k, int stride) {
     if (H <= 0 || W <= 0 || Cin <= 0 || mid <= 0 || (k != 3 && k != 5) || (stride != 1 && stride != 2) || (dtype & ~1)) return EFFDET_EINVAL;
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
+    if (dtype == 1) {
+        const int parts = effdet_mbconv_roll_parts(H, W, Cin, mid, k, stride);
+        if (parts > 0) return parts;
+    }
     const DeepGeometry dg = dtype == 0 ? pick_deep<float>(H, W, Cin, mid, k, stride) : pick_deep<bf16_t>(H, W, Cin, mid, k, stride);
     if (dg.use) return dg.nbands;
     const Geometry g = dtype == 0 ? pick_tile<float>(Ho, Wo, Cin, k, stride) : pick_tile<bf16_t>(Ho, Wo, Cin, k, stride);
@@ -844,6 +854,10 @@ extern "C" int effdet_mbconv_tiles_per_image(int dtype, int H, int W, int Cin, i
 extern "C" int effdet_mbconv_gated_tiles_per_image(int dtype, int H, int W, int Cin, int mid, int k, int stride) {
     if (H <= 0 || W <= 0 || Cin <= 0 || mid <= 0 || (k != 3 && k != 5) || (stride != 1 && stride != 2) || (dtype & ~1)) return EFFDET_EINVAL;
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
+    if (dtype == 1) {
+        const int parts = effdet_mbconv_roll_parts(H, W, Cin, mid, k, stride);
+        if (parts > 0) return parts;
+    }
     const Geometry g = dtype == 0 ? pick_tile<float>(Ho, Wo, Cin, k, stride) : pick_tile<bf16_t>(Ho, Wo, Cin, k, stride);
     if (g.lds > 160 * 1024 || mid % SM_MC) return EFFDET_EINVAL;
     return ((Wo + g.TW - 1) / g.TW) * ((Ho + g.TH - 1) / g.TH);

@@ -1,0 +1,400 @@
+// Rolling-window form of the fused MBConv front half (bfloat16 throughput mode):
+//
+//   expand 1x1 conv (MFMA) -> BN1 -> SiLU -> depthwise k x k (stride 1|2, TF-SAME) -> BN2 -> SiLU (+ SE pool partial sums)
+//
+// replaces timm's InvertedResidual.conv_pw/bn1/act1/conv_dw/bn2/act2 (reached from effdet/efficientdet.py:837), like
+// mbconv.hip's two forms, but every WAVE is an autonomous streaming engine and there is no workgroup barrier at all.
+// A wave owns (image, band of output rows, column strip, 16 expanded channels).  It walks its band one output row at a
+// time and keeps the last KS expanded input rows of its strip in a private LDS ring [KS rows][MT * 16 px][16 ch], so no
+// expanded row is ever computed twice (no y halo).  Per output row:
+//   expand:    S new input rows.  X pixels go straight from global memory (L2) into the MFMA B operand - the loads for
+//              output row oy + 1 are issued before the depthwise phase of row oy, so their latency hides behind it; the
+//              wave's W1 rows (A operand, BN1 scale and - for the gated form - the producing block's SE gate folded in) live
+//              in registers for the whole band; the BN1 shift is the accumulator's initial value; SiLU in registers; one
+//              8-byte LDS store per lane (4 channels of one pixel); zero outside the image (TF-SAME pads the EXPANDED map);
+//   depthwise: one output row on the matrix cores (A = diag(w[t0]) | diag(w[t1]) with BN2's scale folded in, B = two
+//              shifted reads of the ring), BN2 shift as the initial accumulator, SiLU, SE pool sums, 8-byte NHWC stores.
+// LDS reads and writes of one wave execute in order, which is all the synchronisation the ring needs.  The row loop is
+// unrolled over the KS ring phases so that every LDS offset is an immediate.  The x halo (KS - S columns per strip) is the
+// only recomputation.  Workgroups are bundles of `wpg` such waves (same image / band / strip, consecutive channel tiles);
+// blockIdx is remapped so that all workgroups of an image run on one XCD (its L2 then holds that image's X rows once).
+//
+// X loads and Y stores are BUFFER operations with hardware range checking: a lane whose pixel lies outside the strip /
+// image gets an out-of-range offset (the load returns zeros, the store is dropped), so neither needs an exec-mask branch.
+// The loop body is therefore straight-line code and the compiler can COUNT the memory operations in `s_waitcnt vmcnt(N)`:
+// the wait for the prefetched X rows does not also wait for the younger output stores (vmcnt retires in issue order).
+#include "common.h"
+
+namespace {
+
+struct RollArgs {
+    const void* X; void* Y; const void* W1; const float* in_gate;
+    const float* s1; const float* t1; const float* taps; const float* s2; const float* t2;
+    float* pool_partial;
+    int B, H, W, Cin, mid, Ho, Wo, pad_t, pad_l;
+    int TWo, nstrips, band_rows, nbands, IWs, wpg, ngroups, ring_bytes, per_image;
+};
+
+// SiLU of four accumulator values on packed fp32 instructions (the BN shift already sits in the accumulator)
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+DEV f32x4 silu4_fast(const f32x4 x) {
+    const f32x2_ x0 = {x[0], x[1]}, x1 = {x[2], x[3]};
+    const f32x2_ t0 = x0 * -1.4426950408889634f, t1 = x1 * -1.4426950408889634f;
+    const f32x2_ d0 = f32x2_{__builtin_amdgcn_exp2f(t0[0]), __builtin_amdgcn_exp2f(t0[1])} + 1.0f;
+    const f32x2_ d1 = f32x2_{__builtin_amdgcn_exp2f(t1[0]), __builtin_amdgcn_exp2f(t1[1])} + 1.0f;
+    const f32x2_ y0 = x0 * f32x2_{__builtin_amdgcn_rcpf(d0[0]), __builtin_amdgcn_rcpf(d0[1])};
+    const f32x2_ y1 = x1 * f32x2_{__builtin_amdgcn_rcpf(d1[0]), __builtin_amdgcn_rcpf(d1[1])};
+    return f32x4{y0[0], y0[1], y1[0], y1[1]};
+}
+
+template <int V> struct IntC { static constexpr int value = V; };
+
+// NO = output tiles (16 px) per strip row: a compile-time count, so that every output row issues the same number of loads
+// and stores and the compiler can count them in its waits
+template <int KS, int S, int NKC, int MT, int NO>
+__global__ __launch_bounds__(512, (NKC <= 2 ? 4 : 3)) void mbconv_roll_kernel(RollArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    typedef bf16_t T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frow = lane & 15, kg = lane >> 4;
+    // blocks are dealt round-robin over the 8 XCDs: image = (round, xcd), so one image's workgroups share an L2
+    const int xcd = blockIdx.x & 7, rr_ = blockIdx.x >> 3;
+    const int b = (rr_ / p.per_image) * 8 + xcd;
+    if (b >= p.B) return;
+    int q = rr_ % p.per_image;
+    const int group = q % p.ngroups; q /= p.ngroups;
+    const int strip = q % p.nstrips, band = q / p.nstrips;
+    const int c0 = 16 * (group * p.wpg + wave);
+    const int cbytes = p.Cin * 2, mid = p.mid;
+    char* ring = lds + wave * p.ring_bytes;
+    constexpr int rowbytes = MT * 512;                            // [MT * 16 px][16 ch] bf16
+    constexpr int NTAP = KS * KS, NPAIR = (NTAP + 1) / 2;
+    constexpr int OTN = NO;
+
+    // ---- per-wave constants.  Every load of the prologue is issued before the first use.
+    // W1 rows (A operand of the expand): lane (frow, kg) holds 8 consecutive K of channel c0 + frow per 64-byte chunk
+    Frag<T> wf[NKC];
+    const bool gated = p.in_gate != nullptr;
+    const float rs1 = p.s1[c0 + frow], rs2 = p.s2[c0 + frow];
+    f32x4 g0[NKC], g1[NKC];
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc) {
+        const int off = kc * 64 + kg * 16;
+        const bool kv = off < cbytes;
+        wf[kc] = ld_frag<T>(reinterpret_cast<const char*>(p.W1) + (long long)(c0 + frow) * cbytes + (kv ? off : 0));
+        if (gated) {
+            const float* g = p.in_gate + (long long)b * p.Cin + (kv ? off / 2 : 0);
+            g0[kc] = *reinterpret_cast<const f32x4*>(g); g1[kc] = *reinterpret_cast<const f32x4*>(g + 4);
+        }
+    }
+    const int hi = kg >> 1;
+    const bool dactive = (kg & 1) == (frow >> 3);
+    const int dq = (frow & 7) >> 1;
+    float tapv[NPAIR];
+#pragma unroll
+    for (int pr = 0; pr < NPAIR; ++pr) {
+        const int t = 2 * pr + hi;
+        tapv[pr] = p.taps[(long long)(t < NTAP ? t : 0) * mid + c0 + frow];
+    }
+    const f32x4 sh1 = *reinterpret_cast<const f32x4*>(p.t1 + c0 + 4 * kg);
+    const f32x4 t2v = *reinterpret_cast<const f32x4*>(p.t2 + c0 + 4 * kg);
+    // BN1's scale of the row's channel is folded into the bf16 weights (the shift is the accumulator's initial value), and so
+    // is the SE gate of the producing block along K where that block's project conv was composed into W1
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc) {
+        const bool kv = kc * 64 + kg * 16 < cbytes;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float ge = gated ? (e < 4 ? g0[kc][e & 3] : g1[kc][e & 3]) : 1.f;
+            wf[kc].v[e] = kv ? (bf16_t)((float)wf[kc].v[e] * (rs1 * ge)) : (bf16_t)0.f;
+        }
+    }
+    // diagonal tap operands: the lane's single non-zero dword of diag(w[t0]) | diag(w[t1]), BN2's scale folded in
+    unsigned abits[NPAIR];
+#pragma unroll
+    for (int pr = 0; pr < NPAIR; ++pr) {
+        const bool on = dactive && 2 * pr + hi < NTAP;
+        abits[pr] = on ? (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)(tapv[pr] * rs2)) << (16 * (frow & 1)) : 0u;
+    }
+
+    const int oy_b = band * p.band_rows, oy_e = min(p.Ho, oy_b + p.band_rows);
+    const int ox0 = strip * p.TWo, tw = min(p.TWo, p.Wo - ox0);
+    const int ix0 = ox0 * S - p.pad_l, iy_top = oy_b * S - p.pad_t;
+    char* const ring_e = ring + frow * 32 + kg * 8;           // expand store: pixel frow of a tile, channels 4*kg..
+    // Lane constants per tile, the same for every row.  Expand: column validity and byte offset inside an X row.  The loads
+    // are UNCONDITIONAL (no exec branches between them and the waits): a pixel outside the strip / image reads a clamped,
+    // valid pixel and is zeroed by the mask after the SiLU; the K tail beyond Cin of the last chunk reads the pixel's first
+    // bytes against zero weights.  Depthwise: LDS read address and byte offset inside a Y row.
+    constexpr int OOB = 0x7FFFFFF0;                          // beyond every buffer's num_records: load -> 0, store -> dropped
+    float cmask[MT];
+    int xoff[MT], xoffl[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int c = 16 * t + frow, ix = ix0 + c;
+        const bool inside = c < p.IWs && ix >= 0 && ix < p.W;
+        cmask[t] = inside ? 1.f : 0.f;
+        xoff[t] = inside ? ix * cbytes + kg * 16 : OOB;
+        xoffl[t] = (inside && (NKC - 1) * 64 + kg * 16 < cbytes) ? ix * cbytes + (NKC - 1) * 64 + kg * 16 : OOB;
+    }
+    const char* dl[OTN];
+    int yoff[OTN];
+#pragma unroll
+    for (int u = 0; u < OTN; ++u) {
+        const int oxl = 16 * u + frow;
+        const bool ok = oxl < tw;
+        dl[u] = ring + (ok ? oxl * S * 32 : 0) + (kg & 1) * 16;   // invalid lanes read pixel 0 (finite), dropped at the store
+        yoff[u] = ok ? ((ox0 + oxl) * mid + c0 + 4 * kg) * 2 : OOB;
+    }
+    // buffer descriptors of this image's X and Y (wave-uniform: kernel arguments and blockIdx only)
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.X)) + (long long)b * p.H * p.W * cbytes, 0, p.H * p.W * cbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(p.Y) + (long long)b * p.Ho * p.Wo * mid * 2, 0, p.Ho * p.Wo * mid * 2, 0x00020000);
+    // One input row = MT x NKC operand fragments, loaded a whole output row ahead of their use
+    Frag<T> xq[S][MT][NKC];
+    auto load_row = [&](int rel, Frag<T> (&dst)[MT][NKC]) {
+        int iy = iy_top + rel;
+        iy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);             // rows outside the image: any valid row (zeroed by the row mask)
+        const int rowoff = iy * p.W * cbytes;                      // wave-uniform: the buffer op's scalar offset
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int kc = 0; kc < NKC; ++kc) {
+                const u32x4 v = kc + 1 < NKC ? __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff[t] + kc * 64, rowoff, 0)
+                                             : __builtin_amdgcn_raw_buffer_load_b128(xrs, xoffl[t], rowoff, 0);
+                dst[t][kc].v = __builtin_bit_cast(bf16x8, v);
+            }
+    };
+    auto expand_row = [&](int rel, int slot_bytes, const Frag<T> (&src)[MT][NKC]) {
+        const int iy = iy_top + rel;
+        const float rmask = (iy >= 0 && iy < p.H) ? 1.f : 0.f;           // rows outside the image: zeros (TF-SAME pads the expanded map)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            f32x4 acc = sh1;
+#pragma unroll
+            for (int kc = 0; kc < NKC; ++kc) mma_chunk(wf[kc], src[t][kc], acc);
+            const f32x4 v = silu4_fast(acc) * (cmask[t] * rmask);
+            store4<T>(reinterpret_cast<T*>(ring_e + slot_bytes + 512 * t), v[0], v[1], v[2], v[3]);
+        }
+    };
+
+    float pl[4] = {0.f, 0.f, 0.f, 0.f};
+    int next_rel = 0;
+    // prologue: the first KS - S rows of the band's window (ring slots 0 .. KS-S-1), loaded and expanded on the spot
+#pragma unroll 1
+    for (; next_rel < KS - S; ++next_rel) {
+        load_row(next_rel, xq[0]);
+        expand_row(next_rel, next_rel * rowbytes, xq[0]);
+    }
+#pragma unroll
+    for (int r = 0; r < S; ++r) load_row(next_rel + r, xq[r]);
+    int yrow = oy_b * p.Wo * mid * 2;                         // byte offset of the output row inside the image (scalar offset)
+    const int ypitch = p.Wo * mid * 2;
+    int oy = oy_b;
+    // One output row.  PH = ring slot of the first row of its KS-row window.
+    auto step = [&](auto PHC) {
+        constexpr int PH = decltype(PHC)::value;
+        // ---- expand the S new input rows of this output row (fetched one iteration ago), then fetch the next S
+#pragma unroll
+        for (int r = 0; r < S; ++r) expand_row(next_rel + r, ((PH + KS - S + r) % KS) * rowbytes, xq[r]);
+        next_rel += S;
+#pragma unroll
+        for (int r = 0; r < S; ++r) load_row(next_rel + r, xq[r]);      // past the band's end: clamped rows, never used
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- depthwise: one output row out of the ring
+        constexpr int OT = OTN < 2 ? OTN : 2;                   // output tiles in flight together
+        // the per-pair read offsets are loop invariant per ring phase: left alone, the compiler hoists all KS x NPAIR x NO of
+        // them out of the row loop and spills; an opaque copy of the lane's tap selector keeps them (1 + NO adds per pair) here
+        int hsel = hi;
+        asm volatile("" : "+v"(hsel));
+#pragma unroll
+        for (int u0 = 0; u0 < OTN; u0 += OT) {
+            {
+                f32x4 acc[OT];
+#pragma unroll
+                for (int u = 0; u < OT; ++u) acc[u] = t2v;
+#pragma unroll
+                for (int pr = 0; pr < NPAIR; ++pr) {
+                    unsigned bits = abits[pr];
+                    if constexpr (KS == 5) asm volatile("" : "+v"(bits));   // 13 expanded operands would not fit the registers: expand at use
+                    const u32x4 fr = {dq == 0 ? bits : 0u, dq == 1 ? bits : 0u, dq == 2 ? bits : 0u, dq == 3 ? bits : 0u};
+                    Frag<T> af; af.v = __builtin_bit_cast(bf16x8, fr);
+                    const int ta = 2 * pr, tb = 2 * pr + 1 < NTAP ? 2 * pr + 1 : 0;        // constants after unrolling
+                    const int offa = ((PH + ta / KS) % KS) * rowbytes + (ta % KS) * 32, offb = ((PH + tb / KS) % KS) * rowbytes + (tb % KS) * 32;
+                    const int off = hsel ? offb : offa;
+#pragma unroll
+                    for (int u = 0; u < OT; ++u) {
+                        if (u0 + u < OTN) mma_chunk(af, ld_frag<T>(dl[u0 + u < OTN ? u0 + u : 0] + off), acc[u]);
+                    }
+                    // keep the scheduler from hoisting all 2 x 13 ring reads (4 registers each) to the top of the row
+                    if constexpr (KS == 5) { if (pr % 4 == 3) __builtin_amdgcn_sched_barrier(0); }
+                }
+#pragma unroll
+                for (int u = 0; u < OT; ++u) {
+                    if (u0 + u < OTN) {
+                        const f32x4 ov = silu4_fast(acc[u]);
+                        const int yo = yoff[u0 + u < OTN ? u0 + u : 0];
+                        const float vm = yo == OOB ? 0.f : 1.f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pl[r] += ov[r] * vm;
+                        typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+                        typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+                        const bf16x4_ ob = {(bf16_t)ov[0], (bf16_t)ov[1], (bf16_t)ov[2], (bf16_t)ov[3]};
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, ob), yrs, yo, yrow, 0);
+                    }
+                }
+            }
+        }
+        yrow += ypitch;
+        ++oy;
+    };
+#pragma unroll 1
+    while (oy < oy_e) {
+        if constexpr (KS == 3) {
+            step(IntC<0>{});
+            if (oy < oy_e) step(IntC<(S) % 3>{});
+            if (oy < oy_e) step(IntC<(2 * S) % 3>{});
+        } else {
+            step(IntC<0>{});
+            if (oy < oy_e) step(IntC<(S) % 5>{});
+            if (oy < oy_e) step(IntC<(2 * S) % 5>{});
+            if (oy < oy_e) step(IntC<(3 * S) % 5>{});
+            if (oy < oy_e) step(IntC<(4 * S) % 5>{});
+        }
+    }
+    if (p.pool_partial != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = pl[r];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            pl[r] = v;
+        }
+        if (frow == 0) {
+            float* dst = p.pool_partial + ((long long)b * (p.nstrips * p.nbands) + band * p.nstrips + strip) * mid + c0 + 4 * kg;
+            *reinterpret_cast<f32x4*>(dst) = f32x4{pl[0], pl[1], pl[2], pl[3]};
+        }
+    }
+}
+
+struct RollGeometry { bool use; int TWo, nstrips, IWs, IWa, band_rows, nbands, wpg, ngroups, ring_bytes, nkc; size_t lds; };
+
+// Geometry depends on the map and channel sizes only - never on the batch - so that an image's result (including the order
+// in which its SE pool partials are summed) is the same at every batch size.
+RollGeometry pick_roll(int H, int W, int Cin, int mid, int k, int stride) {
+    RollGeometry g{};
+    g.use = false;
+    const int cbytes = Cin * 2;
+    g.nkc = (cbytes + 63) / 64;
+    // Inputs wider than 64 channels stay with mbconv.hip's band x channel-slice form: there every 16-channel wave would stream the
+    // whole X row through its registers (Cin / 32 fragments per pixel tile) and that operand traffic, not the SiLU work, sets the
+    // time (measured: 1.3 - 2x slower than the shared-X form on the 40 x 40 and 20 x 20 maps of d0)
+    if (g.nkc > 2 || mid % 16 || Cin % 8) return g;
+    const int Ho = same_out(H, stride), Wo = same_out(W, stride);
+    const int npair = (k * k + 1) / 2;
+    const int iwa_max = k == 5 ? 48 : 64;                     // waves x KS rows x IWa x 32 B must fit the CU's LDS
+    long long best = -1;
+    for (int ns = 1; ns <= (Wo + 7) / 8; ++ns) {
+        const int two = (Wo + ns - 1) / ns;
+        if ((ns - 1) * two >= Wo) continue;
+        const int iws = (two - 1) * stride + k, iwa = iws <= 32 ? 32 : (iws + 15) / 16 * 16;
+        if (iwa > iwa_max) continue;
+        // the prefetched rows (stride x IWa/16 tiles x K-chunks fragments) must fit the register budget without spills
+        const int mt = iwa / 16;
+        if (stride == 1) {
+            if (mt == 3 && g.nkc > 4) continue;
+            if (mt == 3 && k == 5 && (two + 15) / 16 == 3 && (g.nkc == 2 || g.nkc == 4)) continue;     // these two variants spill
+            if (mt == 4 && (g.nkc > 3 || k == 5)) continue;
+        } else {
+            if (mt == 2 && g.nkc > 4) continue;
+            if (mt >= 3 && (g.nkc > 1 || (mt == 4 && k == 5))) continue;
+        }
+        // rough issue cycles per output row of the strip set: expand tiles (MFMAs + epilogue) + depthwise tiles
+        const long long cost = (long long)ns * ((iwa / 16) * stride * (g.nkc * 16 + 48) + ((two + 15) / 16) * (npair * 16 + 56));
+        if (best < 0 || cost < best) { best = cost; g.TWo = two; g.nstrips = ns; g.IWs = iws; g.IWa = iwa; }
+    }
+    if (best < 0) return g;
+    g.ring_bytes = k * g.IWa * 32;
+    // waves per workgroup: a divisor of the channel-tile count that packs the CU's wave slots (16 at <= 128 VGPRs, 12 above)
+    const int tiles = mid / 16, slots = g.nkc <= 2 ? 16 : 12;
+    int bestfill = -1;
+    for (int d = 1; d <= 8; ++d) {
+        if (tiles % d) continue;
+        const int fill = (slots / d) * d;
+        if (fill > bestfill || (fill == bestfill && d > g.wpg)) { bestfill = fill; g.wpg = d; }
+    }
+    g.ngroups = tiles / g.wpg;
+    g.nbands = Ho / 40 > 0 ? Ho / 40 : 1;
+    g.band_rows = (Ho + g.nbands - 1) / g.nbands;
+    g.nbands = (Ho + g.band_rows - 1) / g.band_rows;
+    g.lds = (size_t)g.wpg * g.ring_bytes;
+    g.use = true;
+    return g;
+}
+
+template <int KS, int S, int NKC>
+void (*roll_kernel_for(int mt, int no))(RollArgs) {
+    // MT = ceil(IWs / 16) input tiles, NO = ceil(TWo / 16) output tiles: stride 1 -> NO in {MT - 1, MT}; stride 2 -> MT in {2 NO - 1 .. 2 NO + 1}
+    if constexpr (S == 1) {
+        if (mt == 2) return no == 1 ? mbconv_roll_kernel<KS, S, NKC, 2, 1> : no == 2 ? mbconv_roll_kernel<KS, S, NKC, 2, 2> : nullptr;
+        if constexpr (NKC <= 4) {
+            if (mt == 3) return no == 2 ? mbconv_roll_kernel<KS, S, NKC, 3, 2> : no == 3 ? mbconv_roll_kernel<KS, S, NKC, 3, 3> : nullptr;
+        }
+        if constexpr (NKC <= 3 && KS == 3) {
+            if (mt == 4) return no == 3 ? mbconv_roll_kernel<KS, S, NKC, 4, 3> : no == 4 ? mbconv_roll_kernel<KS, S, NKC, 4, 4> : nullptr;
+        }
+    } else {
+        if constexpr (NKC <= 4) {
+            if (mt == 2) return no == 1 ? mbconv_roll_kernel<KS, S, NKC, 2, 1> : nullptr;
+        }
+        if constexpr (NKC == 1) {
+            if (mt == 3) return no == 1 ? mbconv_roll_kernel<KS, S, NKC, 3, 1> : no == 2 ? mbconv_roll_kernel<KS, S, NKC, 3, 2> : nullptr;
+            if constexpr (KS == 3) {
+                if (mt == 4) return no == 2 ? mbconv_roll_kernel<KS, S, NKC, 4, 2> : nullptr;
+            }
+        }
+    }
+    return nullptr;
+}
+
+template <int KS, int S>
+int launch_roll_ks(hipStream_t st, const RollArgs& r, const RollGeometry& g) {
+    void (*kern)(RollArgs) = nullptr;
+    const int mt = g.IWa / 16, no = (g.TWo + 15) / 16;
+    switch (g.nkc) {
+        case 1: kern = roll_kernel_for<KS, S, 1>(mt, no); break;
+        case 2: kern = roll_kernel_for<KS, S, 2>(mt, no); break;
+        case 3: kern = roll_kernel_for<KS, S, 3>(mt, no); break;
+        case 4: kern = roll_kernel_for<KS, S, 4>(mt, no); break;
+        case 5: kern = roll_kernel_for<KS, S, 5>(mt, no); break;
+        case 6: kern = roll_kernel_for<KS, S, 6>(mt, no); break;
+        default: break;
+    }
+    if (kern == nullptr) return EFFDET_EINVAL;
+    if (g.lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return EFFDET_ELAUNCH;
+    }
+    const int rounds = (r.B + 7) / 8;
+    hipLaunchKernelGGL(kern, dim3(rounds * r.per_image * 8), dim3(g.wpg * 64), g.lds, st, r);
+    return effdet_check_launch();
+}
+
+}  // namespace
+
+// internal (not part of the C ABI): used by mbconv.hip's launcher
+int effdet_mbconv_roll_parts(int H, int W, int Cin, int mid, int k, int stride) {
+    const RollGeometry g = pick_roll(H, W, Cin, mid, k, stride);
+    return g.use ? g.nstrips * g.nbands : 0;
+}
+
+int effdet_mbconv_roll_launch(hipStream_t st, const void* X, const float* in_gate, void* Y, const void* W1, const float* s1, const float* t1,
+                              const float* taps, const float* s2, const float* t2, float* pool_partial,
+                              int B, int H, int W, int Cin, int mid, int k, int stride) {
+    const RollGeometry g = pick_roll(H, W, Cin, mid, k, stride);
+    if (!g.use) return EFFDET_EINVAL;
+    RollArgs r{X, Y, W1, in_gate, s1, t1, taps, s2, t2, pool_partial, B, H, W, Cin, mid, same_out(H, stride), same_out(W, stride),
+               same_pad_before(H, k, stride), same_pad_before(W, k, stride), g.TWo, g.nstrips, g.band_rows, g.nbands, g.IWs,
+               g.wpg, g.ngroups, g.ring_bytes, g.nstrips * g.nbands * g.ngroups};
+    if (k == 3) return stride == 1 ? launch_roll_ks<3, 1>(st, r, g) : launch_roll_ks<3, 2>(st, r, g);
+    return stride == 1 ? launch_roll_ks<5, 1>(st, r, g) : launch_roll_ks<5, 2>(st, r, g);
+}

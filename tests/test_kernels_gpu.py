@@ -133,7 +133,46 @@ def test_mbconv_expand_dw_fused(dtype, Cin, mid, H, W, k, s):
     assert _rel(_hip.nchw(y), ref) < TOL[dtype]
     pooled = part.sum(1).cpu() / (Ho * Wo)
     pref = _hip.nchw(y).cpu().mean((2, 3))
-    assert float((pooled - pref).abs().max()) < 1e-4 * max(1.0, float(pref.abs().max()))
+    # bf16: the rolling-window kernel pools the fp32 values it is about to round for the store (|rounding| <= 2^-9 per element)
+    assert float((pooled - pref).abs().max()) < (1e-4 if dtype == torch.float32 else 1e-3) * max(1.0, float(pref.abs().max()))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('Cin,mid,H,W,k,s', [(32, 96, 40, 36, 3, 2), (32, 96, 64, 64, 3, 2), (16, 48, 21, 50, 5, 1)])
+def test_mbconv_expand_dw_gated(dtype, Cin, mid, H, W, k, s):
+    """the gated form (block 1.0 of the backbone: block 0.0's project conv is composed into the expand weights, its SE gate
+    multiplies the input along K): expand(x * gate) -> depthwise, vs the oracle's separate ops"""
+    import _hip
+    from ood_object_detection_amd import _lib
+    lib = _lib.load()
+    B = 3
+    x = _rand(B, Cin, H, W, seed=70).to(dtype)
+    gate = torch.sigmoid(_rand(B, Cin, seed=75))
+    w1 = _rand(mid, Cin, 1, 1, seed=71, scale=1.5 * Cin ** -0.5).to(dtype)
+    s1, t1 = torch.rand(mid) + 0.5, _rand(mid, seed=72, scale=0.2)
+    wd = _rand(mid, 1, k, k, seed=73, scale=1.0 / k)
+    s2, t2 = torch.rand(mid) + 0.5, _rand(mid, seed=74, scale=0.2)
+    xg = (x.float() * gate[:, :, None, None]).to(dtype).float()
+    e = om.silu(F.conv2d(xg, w1.float()) * s1[None, :, None, None] + t1[None, :, None, None])
+    if dtype == torch.bfloat16:
+        e = e.to(dtype).float()
+    ref = om.silu(om.conv2d_pad(e, wd, None, s, 'same', groups=mid) * s2[None, :, None, None] + t2[None, :, None, None])
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    xd = _hip.nhwc(x, dtype).to(DEV)
+    y = torch.empty(B, Ho, Wo, mid, dtype=dtype, device=DEV)
+    nt = lib.effdet_mbconv_gated_tiles_per_image(_hip.DT[dtype], H, W, Cin, mid, k, s)
+    assert nt > 0
+    part = torch.full((B, nt, mid), float('nan'), dtype=torch.float32, device=DEV)
+    gd = gate.contiguous().to(DEV)
+    dv = [t.contiguous().to(DEV) for t in (w1.reshape(mid, Cin), s1, t1, wd.permute(2, 3, 0, 1).reshape(k * k, mid), s2, t2)]
+    rc = lib.effdet_mbconv_expand_dw_gated(_hip.stream(DEV), _hip.DT[dtype], xd.data_ptr(), gd.data_ptr(), y.data_ptr(),
+                                           *[t.data_ptr() for t in dv], part.data_ptr(), B, H, W, Cin, mid, k, s)
+    assert rc == 0
+    assert _rel(_hip.nchw(y), ref) < TOL[dtype]
+    pooled = part.sum(1).cpu() / (Ho * Wo)
+    pref = _hip.nchw(y).cpu().mean((2, 3))
+    # bf16: the rolling-window kernel pools the fp32 values it is about to round for the store (|rounding| <= 2^-9 per element)
+    assert float((pooled - pref).abs().max()) < (1e-4 if dtype == torch.float32 else 1e-3) * max(1.0, float(pref.abs().max()))
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
@@ -167,7 +206,8 @@ def test_stem_dw_fused(dtype, C, H, W):
     assert _rel(_hip.nchw(y), ref) < TOL[dtype]
     pooled = part.sum(1).cpu() / (Ho * Wo)
     pref = _hip.nchw(y).cpu().mean((2, 3))
-    assert float((pooled - pref).abs().max()) < 1e-4 * max(1.0, float(pref.abs().max()))
+    # bf16: the rolling-window kernel pools the fp32 values it is about to round for the store (|rounding| <= 2^-9 per element)
+    assert float((pooled - pref).abs().max()) < (1e-4 if dtype == torch.float32 else 1e-3) * max(1.0, float(pref.abs().max()))
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
