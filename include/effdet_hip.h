@@ -130,7 +130,9 @@ int effdet_maxpool_same(void* stream, int dtype, const void* X, long long x_imag
  *   (0 same size, 1 nearest x2 upsample, 2 max-pool 3x3/s2 SAME);
  *   fuse_mode 0: single input, 1: sum_i (x_i*w_i)/den ('fastattn'), 2: sum_i x_i*w_i ('attn','sum');
  *   dw_w [9][F] fp32; pw_w [N][F] (dtype); scale/shift [rows][N] fp32 indexed by affine_row[l]
- *   (scale may be NULL); out_ptr[l] + b*out_image_stride[l] + (y*W+x)*N. */
+ *   (scale may be NULL); out_ptr[l] + b*out_image_stride[l] + (y*W+x)*N.
+ *   dtype 3 (= 1 | 2): bfloat16 inputs / weights, float32 OUTPUTS written straight from the accumulators (out pointers and
+ *   strides then address float32 elements) - used for the box regressions, which decode reads as float32 (anchors.py:136). */
 int effdet_sepconv_fused(void* stream, int dtype, int B, int nlevels, const int* level_hw, int n_in,
                          const void* const* in_ptr, const long long* in_image_stride, const int* in_hw,
                          const int* in_mode, int fuse_mode, const float* fuse_w, float fuse_den, int pre_act,
@@ -173,7 +175,9 @@ int effdet_topk_select(void* stream, int dtype, const void* cls_all, const float
                        long long* out_indices, long long* out_classes, void* workspace, long long workspace_bytes);
 
 /* generate_detections, first half (effdet/anchors.py:132-144): decode, clip (when img_scale and img_size
- * are given), sigmoid, keep score > 0.01 (order kept).  Outputs are [B,k(,4)] with count[b] valid rows. */
+ * are given), sigmoid, keep score > 0.01 (order kept).  Outputs are [B,k(,4)] with count[b] valid rows.
+ * dtype 0: logits and box regressions float32; 1: both bfloat16; 3 (= 1 | 2): bfloat16 logits, float32 box regressions
+ * (what a bfloat16 model's box head writes, see effdet_sepconv_fused). */
 int effdet_decode_threshold(void* stream, int dtype, const void* cls_topk, const void* box_topk,
                             const float* anchors, const long long* indices, const long long* classes,
                             const float* img_scale, const float* img_size, int B, int k,

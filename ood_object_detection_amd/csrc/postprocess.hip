@@ -448,7 +448,7 @@ __global__ __launch_bounds__(1024) void topk_sort_kernel(const TopkState* state,
 
 // ------------------------------------------------------------------------------------------------
 struct DecodeArgs {
-    const void* cls; const void* box; int dtype;
+    const void* cls; const void* box; int dtype; int box_dtype;
     const float* anchors;
     const long long* indices; const long long* classes;
     const float* img_scale; const float* img_size;
@@ -482,8 +482,8 @@ __global__ __launch_bounds__(256) void decode_threshold_kernel(DecodeArgs p) {
             const float ya = (a[0] + a[2]) / 2, xa = (a[1] + a[3]) / 2;
             const float ha = a[2] - a[0], wa = a[3] - a[1];
             const long long br = p.gather_anchors > 0 ? (long long)b * p.gather_anchors + p.indices[o] : o;
-            const float ty = ld_as_float(p.box, p.dtype, br * 4 + 0), tx = ld_as_float(p.box, p.dtype, br * 4 + 1);
-            const float th = ld_as_float(p.box, p.dtype, br * 4 + 2), tw = ld_as_float(p.box, p.dtype, br * 4 + 3);
+            const float ty = ld_as_float(p.box, p.box_dtype, br * 4 + 0), tx = ld_as_float(p.box, p.box_dtype, br * 4 + 1);
+            const float th = ld_as_float(p.box, p.box_dtype, br * 4 + 2), tw = ld_as_float(p.box, p.box_dtype, br * 4 + 3);
             const float w = expf(tw) * wa, h = expf(th) * ha;
             const float yc = ty * ha + ya, xc = tx * wa + xa;
             y1 = yc - h / 2.f; x1 = xc - w / 2.f; y2 = yc + h / 2.f; x2 = xc + w / 2.f;
@@ -942,8 +942,8 @@ extern "C" int effdet_decode_threshold(void* stream, int dtype, const void* cls_
                                        float* boxes, float* scores, int* classes_out, int* src, int* count, float* maxcoord) {
     EFFDET_ENTER();
     if (!cls_topk || !box_topk || !anchors || !indices || !classes || !boxes || !scores || !classes_out || !src || !count || !maxcoord) return EFFDET_EINVAL;
-    if (B <= 0 || k <= 0 || (dtype & ~1)) return EFFDET_EINVAL;
-    DecodeArgs a{cls_topk, box_topk, dtype, anchors, indices, classes, img_scale, img_size, k, boxes, scores, classes_out, src, count, maxcoord, 0};
+    if (B <= 0 || k <= 0 || (dtype & ~3)) return EFFDET_EINVAL;
+    DecodeArgs a{cls_topk, box_topk, dtype & 1, (dtype & 2) ? 0 : (dtype & 1), anchors, indices, classes, img_scale, img_size, k, boxes, scores, classes_out, src, count, maxcoord, 0};
     hipLaunchKernelGGL(decode_threshold_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     return effdet_check_launch();
 }
@@ -956,8 +956,8 @@ extern "C" int effdet_decode_threshold_gather(void* stream, int dtype, const voi
                                               float* boxes, float* scores, int* classes_out, int* src, int* count, float* maxcoord) {
     EFFDET_ENTER();
     if (!cls_topk || !box_all || !anchors || !indices || !classes || !boxes || !scores || !classes_out || !src || !count || !maxcoord) return EFFDET_EINVAL;
-    if (B <= 0 || k <= 0 || n_anchors <= 0 || (dtype & ~1)) return EFFDET_EINVAL;
-    DecodeArgs a{cls_topk, box_all, dtype, anchors, indices, classes, img_scale, img_size, k, boxes, scores, classes_out, src, count, maxcoord, n_anchors};
+    if (B <= 0 || k <= 0 || n_anchors <= 0 || (dtype & ~3)) return EFFDET_EINVAL;
+    DecodeArgs a{cls_topk, box_all, dtype & 1, (dtype & 2) ? 0 : (dtype & 1), anchors, indices, classes, img_scale, img_size, k, boxes, scores, classes_out, src, count, maxcoord, n_anchors};
     hipLaunchKernelGGL(decode_threshold_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     return effdet_check_launch();
 }

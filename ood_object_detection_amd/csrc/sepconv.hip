@@ -42,6 +42,7 @@ struct SepArgs {
     float fw[3]; float fden;
     float fwn[3];                              // fw / fden (throughput mode multiplies instead of dividing)
     int vec_ok;                                // output rows are dword aligned: 8-channel pieces go out as vectors
+    int out_f32;                               // outputs are written as float32 whatever T is (box regressions of a bf16 model)
     int pre_act, post_act;
     const float* dw_w;                         // [9][F]
     const void* pw_w;                          // [N][F]
@@ -493,7 +494,13 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void sepconv_kernel(SepArg
                     }
                     const bool group_full = 32 * J + 32 <= n_count;     // uniform: only the last group of a chunk has a tail
                     const int nvalid = group_full ? 8 : n_count - cb;
-                    if (pix_in[i] && nvalid > 0) store_piece<T>(out + pix_off[i] + n_begin + cb, vals[J], nvalid, p.vec_ok != 0);
+                    if (pix_in[i] && nvalid > 0) {
+                        if (sizeof(T) == 2 && p.out_f32)
+                            store_piece<float>(reinterpret_cast<float*>(L.out) + (long long)b * L.out_image_stride + pix_off[i] + n_begin + cb,
+                                               vals[J], nvalid, true);
+                        else
+                            store_piece<T>(out + pix_off[i] + n_begin + cb, vals[J], nvalid, p.vec_ok != 0);
+                    }
                     if constexpr (META) {
                         if (p.stat_partial != nullptr && pix_in[i]) {
 #pragma unroll
@@ -660,7 +667,9 @@ static int sepconv_common(
     if (nlevels < 1 || nlevels > 5 || n_in < 1 || n_in > 3 || B <= 0) return EFFDET_EINVAL;
     if (!level_hw || !in_ptr || !in_image_stride || !in_hw || !in_mode || !dw_w || !pw_w || !shift || !affine_row ||
         !out_ptr || !out_image_stride) return EFFDET_EINVAL;
-    if (F <= 0 || F % 8 || N <= 0 || (dtype & ~1) || fuse_mode < 0 || fuse_mode > 2) return EFFDET_EINVAL;
+    const int out_f32 = (dtype & 2) ? 1 : 0;          // dtype | 2: compute in bf16 / f32 as bit 0 says, write float32 outputs
+    dtype &= 1;
+    if (F <= 0 || F % 8 || N <= 0 || fuse_mode < 0 || fuse_mode > 2) return EFFDET_EINVAL;
     if (fuse_mode != 0 && !fuse_w) return EFFDET_EINVAL;
     if (fuse_mode == 0 && n_in != 1) return EFFDET_EINVAL;
     if (ood_classes > 0) {
@@ -670,7 +679,8 @@ static int sepconv_common(
     a.nlevels = nlevels; a.n_in = n_in; a.fuse_mode = fuse_mode; a.fden = fuse_den;
     for (int i = 0; i < 3; ++i) a.fw[i] = (fuse_mode != 0 && i < n_in) ? fuse_w[i] : 0.f;
     for (int i = 0; i < 3; ++i) a.fwn[i] = fuse_mode == 1 ? a.fw[i] / fuse_den : a.fw[i];
-    const size_t esz = dtype == 0 ? 4 : 2;
+    const size_t esz = (dtype == 0 || out_f32) ? 4 : 2;
+    a.out_f32 = out_f32;
     a.vec_ok = ((size_t)N * esz) % 4 == 0 && (ood_classes <= 0 || ((size_t)ood_classes * esz) % 4 == 0);
     a.pre_act = pre_act; a.post_act = post_act; a.dw_w = dw_w; a.pw_w = pw_w; a.scale = scale; a.shift = shift;
     a.F = F; a.N = N; a.ood_classes = ood_classes > 0 ? ood_classes : 0; a.num_anchors = num_anchors;
@@ -708,7 +718,7 @@ static int sepconv_common(
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (meta) {                                  // MetaHead layers: generic-width kernels with the extra inputs / outputs
-        if (ood_classes > 0 || fuse_mode != 0) return EFFDET_EINVAL;
+        if (ood_classes > 0 || fuse_mode != 0 || out_f32) return EFFDET_EINVAL;
         return dtype == 0 ? launch_sep<float, 8, 8, 64, false, 256, 0, true>(st, a, B)
                           : launch_sep<bf16_t, 8, 16, 64, false, 512, 0, true>(st, a, B);
     }

@@ -109,9 +109,9 @@ def batched_detections(cls_topk, box_topk, anchor_boxes, indices, classes, img_s
     B, k = indices.shape
     dev = cls_topk.device
     bsrc = box_all if box_all is not None else box_topk
-    if cls_topk.dtype != bsrc.dtype or cls_topk.dtype not in (torch.float32, torch.bfloat16):
-        raise RuntimeError('cls/box outputs must both be float32 or bfloat16')
-    dt = 0 if cls_topk.dtype == torch.float32 else 1
+    if cls_topk.dtype not in (torch.float32, torch.bfloat16) or bsrc.dtype not in (cls_topk.dtype, torch.float32):
+        raise RuntimeError('cls outputs must be float32 or bfloat16, box outputs the same dtype or float32')
+    dt = 0 if cls_topk.dtype == torch.float32 else (3 if bsrc.dtype == torch.float32 else 1)     # | 2: float32 box regressions
     cls_topk, bsrc = cls_topk.contiguous(), bsrc.contiguous()
     indices, classes = indices.contiguous(), classes.contiguous()
     anchors = anchor_boxes.to(device=dev, dtype=torch.float32).contiguous()

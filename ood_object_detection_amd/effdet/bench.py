@@ -33,6 +33,11 @@ def _post_process(cls_outputs: List[torch.Tensor], box_outputs: Optional[List[to
     B = c0.shape[0]
     cls_all = _packed(cls_outputs, num_levels, num_classes)
     box_all = _packed(box_outputs, num_levels, 4) if box_outputs is not None else None
+    # a bf16 model's box head writes float32 regressions (engine.py): the select kernel gathers rows of the logits' dtype only,
+    # so mixed dtypes take the box rows through the returned indices afterwards
+    box_late = box_all if (box_all is not None and box_all.dtype != cls_all.dtype) else None
+    if box_late is not None:
+        box_all = None
     n_anchors = cls_all.shape[1]
     k = max_detection_points
     dt = 0 if cls_all.dtype == torch.float32 else 1
@@ -51,6 +56,8 @@ def _post_process(cls_outputs: List[torch.Tensor], box_outputs: Optional[List[to
                                       B, n_anchors, num_classes, box_all.data_ptr() if box_all is not None else None, k,
                                       out_cls.data_ptr(), out_box.data_ptr() if out_box is not None else None, idx.data_ptr(), cls_id.data_ptr(),
                                       ws.data_ptr(), ws_bytes), 'effdet_topk_select')
+    if box_late is not None:
+        out_box = torch.gather(box_late, 1, idx.unsqueeze(-1).expand(B, k, 4))
     return out_cls, out_box, idx, cls_id
 
 

@@ -20,6 +20,8 @@ class _DetectionLossFn(torch.autograd.Function):
         lib = _lib.load()
         if cls_all.device.type != 'cuda':
             raise RuntimeError('DetectionLoss runs on the GPU only (no CPU fallback)')
+        if cls_all.dtype == torch.bfloat16 and box_all.dtype == torch.float32:
+            box_all = box_all.to(torch.bfloat16)             # a bf16 inference model writes float32 box regressions (engine.py)
         if cls_all.dtype != box_all.dtype or cls_all.dtype not in (torch.float32, torch.bfloat16):
             raise RuntimeError('head outputs must both be float32 or bfloat16')
         B, N, C = cls_all.shape

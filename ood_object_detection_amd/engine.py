@@ -477,7 +477,7 @@ class Engine(object):
         self._fpn_plan = plan
 
     def _sepconv_call(self, level_hw, level_inputs, fuse_mode, fw, den, pre_act, taps, wq, scale, shift, affine_rows,
-                      post_act, F, N, out_ptrs, out_strides, what, ood=None):
+                      post_act, F, N, out_ptrs, out_strides, what, ood=None, out_f32=False):
         nl, n_in = len(level_hw), len(level_inputs[0])
         c_hw = _arr(ctypes.c_int, [v for hw in level_hw for v in hw])
         c_ptr = _arr(ctypes.c_void_p, [i[0] for lv in level_inputs for i in lv])
@@ -495,13 +495,14 @@ class Engine(object):
             self._keep.append(c_ooff)
             ood_args = (ood['classes'], self.A, ood['energy'].data_ptr(), ood['maxlogit'].data_ptr(), ood['stride'], c_ooff)
         self._keep += [c_hw, c_ptr, c_str, c_ihw, c_mode, c_fw, c_aff, c_out, c_ostr]
-        args = (self.dt, self.B, nl, c_hw, n_in, c_ptr, c_str, c_ihw, c_mode, fuse_mode, c_fw, ctypes.c_float(den), pre_act,
+        args = (self.dt | (2 if (out_f32 and self.dt == 1) else 0), self.B, nl, c_hw, n_in, c_ptr, c_str, c_ihw, c_mode, fuse_mode, c_fw, ctypes.c_float(den), pre_act,
                 taps.data_ptr(), wq.data_ptr(), scale.data_ptr() if scale is not None else None, shift.data_ptr(),
                 c_aff, post_act, F, N, c_out, c_ostr) + ood_args
         es = self.pyr_es
         in_px = sum(i[2][0] * i[2][1] for lv in level_inputs for i in lv)
         out_px = sum(h * w for h, w in level_hw)
-        meta = dict(kind='sepconv', bytes=self.B * (in_px * F + out_px * N) * es + N * F * es + 9 * F * 4 +
+        oes_ = 4 if out_f32 else es
+        meta = dict(kind='sepconv', bytes=self.B * (in_px * F * es + out_px * N * oes_) + N * F * es + 9 * F * 4 +
                     (2 * self.B * out_px * self.A * 4 if ood is not None else 0),
                     flops=2 * self.B * out_px * (9 * F + F * N))
         return (self.lib.effdet_sepconv_fused, args, what, meta)
@@ -533,7 +534,9 @@ class Engine(object):
         N = A * P
         self.N = N
         self.cls_all = self._new(B, N, C)
-        self.box_all = self._new(B, N, 4)
+        # box regressions are written as float32 straight from the accumulators, whatever the model dtype (1.2 MB / image): decode
+        # (anchors.py:136 `.float()`) then sees unrounded values
+        self.box_all = self._new(B, N, 4, dtype=torch.float32)
         if self._ood_out is not None:                      # caller-provided [B, N] float32 views (DetBenchPredict's split batches)
             self.ood_energy, self.ood_max_logit = self._ood_out
             if tuple(self.ood_energy.shape) != (B, N) or tuple(self.ood_max_logit.shape) != (B, N) or not self.ood_energy.is_contiguous() \
@@ -548,7 +551,7 @@ class Engine(object):
         def level_ptrs(t, width):
             return [t.data_ptr() + off * width * es for off in self.level_off]
 
-        def plan_for(head, name, out_t, K, ood):
+        def plan_for(head, name, out_t, K, ood, out_f32=False):
             plan = []
             src = self.pyr
             bufs = [t1, t2]
@@ -573,19 +576,20 @@ class Engine(object):
             wq = self._w(conv.conv_pw.weight.reshape(NO, F))
             t = self._f32(conv.conv_pw.bias.detach().float().reshape(1, NO))
             ins = [[(p, P * F, hw, 0)] for p, hw in zip(level_ptrs(src, F), self.level_hw)]
-            outs = [out_t.data_ptr() + off * NO * es for off in self.level_off]
+            oes = out_t.element_size()
+            outs = [out_t.data_ptr() + off * NO * oes for off in self.level_off]
             oodd = None
             if ood:
                 oodd = dict(classes=K, energy=self.ood_energy, maxlogit=self.ood_max_logit, stride=N,
                             level_off=[off * A for off in self.level_off])
             plan.append(self._sepconv_call(self.level_hw, ins, 0, [], 1.0, 0, taps, wq, None, t, [0] * L, 0, F, NO,
-                                           outs, [P * NO] * L, '%s.predict' % name, ood=oodd))
+                                           outs, [P * NO] * L, '%s.predict' % name, ood=oodd, out_f32=out_f32))
             return plan
 
         # infer.py:186-191 replaces `model.class_net` by a MetaHead (functional head, own launches in effdet/meta_head.py):
         # backbone / BiFPN / box head then still run from this plan, the class outputs come from the MetaHead's forward
         self._cls_plan = plan_for(model.class_net, 'class_net', self.cls_all, C, True) if hasattr(model.class_net, 'conv_rep') else None
-        self._box_plan = plan_for(model.box_net, 'box_net', self.box_all, 4, False)
+        self._box_plan = plan_for(model.box_net, 'box_net', self.box_all, 4, False, out_f32=True)
 
     def head_views(self, t, K):
         out = []
