@@ -104,11 +104,16 @@ class _FeatureInfo(object):
 class EfficientNetFeatures(nn.Module):
     """Parameter container; `forward` is provided by the owning EfficientDet's engine."""
 
-    def __init__(self, name, **unused_backbone_args):
+    def __init__(self, name, drop_path_rate=0.0, **unused_backbone_args):
         super().__init__()
         self.name = name
         stem, stages = efficientnet_arch(name)
         self.arch = (stem, stages)
+        # Stochastic depth (timm's `drop_path_rate` in config.backbone_args, 0.2 for every tf_efficientdet config and the value
+        # pretrain.py:49,94 passes): block i of n drops its residual branch per SAMPLE with probability rate * i / n while the
+        # backbone module is in training mode; applied by the training engine (train_engine.py), never at inference.
+        self.drop_path_rate = float(drop_path_rate)
+        self.drop_path_masks = None     # tests: explicit keep masks {block index: float tensor [B] of 0 / 1} instead of random ones
         self.conv_stem = nn.Conv2d(3, stem, 3, stride=2, bias=False)
         self.bn1 = _bn(stem)
         self.blocks = nn.Sequential(*[
@@ -134,6 +139,17 @@ class EfficientNetFeatures(nn.Module):
             elif isinstance(m, nn.BatchNorm2d):
                 m.weight.data.fill_(1.0)
                 m.bias.data.zero_()
+
+    def block_drop_rates(self):
+        """per block (flat order) drop probability: drop_path_rate * block_index / block_count (timm's EfficientNetBuilder);
+        only blocks with a residual connection use it"""
+        n = sum(len(b) for b in self.arch[1])
+        rates, i = [], 0
+        for blocks in self.arch[1]:
+            for b in blocks:
+                rates.append(self.drop_path_rate * i / n if b['residual'] else 0.0)
+                i += 1
+        return rates
 
     def forward(self, x):
         raise RuntimeError('EfficientNetFeatures has no standalone forward: call EfficientDet(x, mode="bb")')

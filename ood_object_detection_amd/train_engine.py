@@ -5,7 +5,8 @@ Reference: pretrain.py:226-236 (`model(x, mode='bb')` -> `model(feats, mode='fpn
 float32 only (the reference trains in fp32).  BatchNorm follows each module's own `.training` flag like nn.BatchNorm2d:
 batch statistics (+ running-stat update) where it is set - by default BiFPN and heads - and running statistics where
 it is not (pretrain.py:168-176 puts the backbone's BN in eval mode; that is the only backbone mode built).
-Stochastic depth / dropout of the timm backbone (`drop_path_rate` in backbone_args) are NOT applied: the step is
+Stochastic depth of the timm backbone (`drop_path_rate` in backbone_args) IS applied while the backbone module is in training
+mode (per-sample keep masks, timm's drop_path); with it off (rate 0 or backbone.eval()) the step is
 deterministic, and bitwise reproducible (all reductions are fixed-order).
 
 Division of labour: every activation-sized operation (anything O(B*H*W*C)) is a HIP kernel of csrc/train_net.hip (plus
@@ -424,6 +425,11 @@ class TrainEngine(object):
         col = ops.new(B, Ho, Wo, 32)
         _lib.check(self.lib.effdet_train_im2col_stem(ops.st(), x.data_ptr(), col.data_ptr(), B, H, W), 'effdet_train_im2col_stem')
         saved = dict(blocks=[])
+        # stochastic depth (timm drop_path: x / keep_prob * floor(keep_prob + U[0,1)) per sample, then + shortcut), active while the
+        # backbone MODULE is in training mode - pretrain.py:168-176 only puts its BatchNorm layers in eval mode
+        drop_rates = bb.block_drop_rates() if (bb.training and bb.drop_path_rate > 0.0) else None
+        fixed_masks = getattr(bb, 'drop_path_masks', None)
+        flat_idx = 0
 
         class _StemConv(object):                      # conv_stem as a 1x1 conv over the 32-wide patches
             pass
@@ -454,7 +460,18 @@ class TrainEngine(object):
                 a2 = ops.silu(z2)
                 ag, r['se'] = self._se_fwd(a2, m.se, b['se'])
                 z3, r['proj'] = self._pw_bneval_fwd(ag, proj, bnp, pn)
+                r['drop'] = None
+                if b['residual'] and drop_rates is not None and drop_rates[flat_idx] > 0.0:
+                    keep = 1.0 - drop_rates[flat_idx]
+                    if fixed_masks is not None and flat_idx in fixed_masks:
+                        mask = fixed_masks[flat_idx].to(device=self.dev, dtype=torch.float32).reshape(B)
+                    else:
+                        mask = torch.floor(keep + torch.rand(B, device=self.dev, dtype=torch.float32))
+                    # per-image scale as a [B, C] table for the element-wise kernel (op 4: a * v0[img, c])
+                    r['drop'] = (mask / keep).reshape(B, 1).expand(B, b['cout']).contiguous()
+                    z3 = ops.ew(4, z3, v=(r['drop'], None, None, None), hw=z3.shape[1] * z3.shape[2])
                 cur = ops.add(z3, cur) if b['residual'] else z3
+                flat_idx += 1
                 saved['blocks'].append(r)
             if si in (2, 4, 6):
                 feats.append(cur)
@@ -478,7 +495,8 @@ class TrainEngine(object):
                     dcur = df if dcur is None else ops.add(dcur, df)
             if dcur is None:
                 raise RuntimeError('no gradient reached the last backbone stage')
-            dag = self._pw_bneval_bwd(r['proj'], dcur, grads)
+            dz3 = dcur if r.get('drop') is None else ops.ew(4, dcur, v=(r['drop'], None, None, None), hw=dcur.shape[1] * dcur.shape[2])
+            dag = self._pw_bneval_bwd(r['proj'], dz3, grads)
             da2 = self._se_bwd(r['se'], dag, grads, r['p'] + 'se.')
             dz2 = ops.silu_bwd(r['z2'], da2)
             dx = self._dw_bneval_bwd(r['dw'], dz2, grads)

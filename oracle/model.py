@@ -143,8 +143,12 @@ def silu(x):
 # ----------------------------------------------------------------------------------------------
 # backbone
 # ----------------------------------------------------------------------------------------------
-def backbone_forward(sd, backbone_name, x, prefix='backbone.', eps=1e-3, pad_type='same'):
+def backbone_forward(sd, backbone_name, x, prefix='backbone.', eps=1e-3, pad_type='same', drop_scales=None):
+    """drop_scales (training restatement): {flat block index: [B] tensor} = timm's drop_path factor floor(keep + U) / keep of the
+    residual branch of that block (timm `drop_path`, layers/drop.py - absent dependency, restated from the published code:
+    `x.div(keep_prob) * random_tensor` then `x += shortcut`; per-block rate drop_path_rate * idx / n_blocks)"""
     stem, stages = efficientnet_spec(backbone_name)
+    flat_idx = 0
     g = lambda k: sd[prefix + k]
     x = conv2d_pad(x, g('conv_stem.weight'), None, 2, pad_type)
     x = silu(bn_eval(x, sd, prefix + 'bn1.', eps))
@@ -168,7 +172,10 @@ def backbone_forward(sd, backbone_name, x, prefix='backbone.', eps=1e-3, pad_typ
                 x = conv2d_pad(x, sd[p + 'conv_pwl.weight'], None, 1, pad_type)
                 x = bn_eval(x, sd, p + 'bn3.', eps)
             if blk['residual']:
+                if drop_scales is not None and flat_idx in drop_scales:
+                    x = x * drop_scales[flat_idx].to(x).view(-1, 1, 1, 1)
                 x = x + shortcut
+            flat_idx += 1
         if si in FEATURE_STAGES:
             feats.append(x)
     return feats
@@ -281,14 +288,14 @@ def head_forward(sd, cfg, feats, prefix):
     return outs
 
 
-def efficientdet_forward(sd, cfg, x, fpn_nodes, mode='full_net'):
+def efficientdet_forward(sd, cfg, x, fpn_nodes, mode='full_net', drop_scales=None):
     """EfficientDet.forward (efficientdet.py:895-933) for the modes that do not need MetaHead."""
     sd = {k: v.float() for k, v in sd.items() if torch.is_tensor(v)}
     info = backbone_feature_info(cfg.backbone_name)
     if mode == 'bb':
-        return backbone_forward(sd, cfg.backbone_name, x, pad_type=cfg.pad_type)
+        return backbone_forward(sd, cfg.backbone_name, x, pad_type=cfg.pad_type, drop_scales=drop_scales)
     if mode in ('full_net', 'fpn', 'supp_bb'):
-        feats = backbone_forward(sd, cfg.backbone_name, x, pad_type=cfg.pad_type)
+        feats = backbone_forward(sd, cfg.backbone_name, x, pad_type=cfg.pad_type, drop_scales=drop_scales)
         activs = bifpn_forward(sd, cfg, feats, fpn_nodes, info)
         if mode == 'fpn':
             return feats, activs
