@@ -7,7 +7,8 @@ module's own parameters in the reference's list order; `ret_activs` returns the 
 
 HIP path: one `effdet_sepconv_meta` launch per layer for all levels, `effdet_bn_batch_stats` in between (the batch
 statistics are folded into a per-level scale / shift that the next layer applies while loading its halo tile).
-Forward only: gradients w.r.t. fast weights (the inner-loop update itself) are not built."""
+With grad mode on and trainable weights / inputs the forward is the differentiable float32 path of effdet/meta_grad.py
+(first-order gradients w.r.t. every fast weight and input level: the inner-loop update of infer.py:658-681)."""
 import math
 from typing import List, Optional
 
@@ -91,8 +92,13 @@ class MetaHead(nn.Module):
         x0 = x[levels[0]]
         if x0.device.type != 'cuda' or x0.dtype not in _DT:
             raise RuntimeError('MetaHead runs on the GPU in float32 / bfloat16 only (no CPU fallback)')
-        if torch.is_grad_enabled() and any(t.requires_grad for t in list(x) + list(conv_dw_rep) + list(predict)):
-            raise NotImplementedError('the MetaHead HIP path is forward-only: call it under torch.no_grad()')
+        if torch.is_grad_enabled() and any(t.requires_grad for t in list(x) + list(conv_dw_rep) + list(conv_pw_rep) + list(conv_pb_rep) +
+                                           list(predict) + list(bn_rep_w) + list(bn_rep_b)):
+            # the MAML inner / outer loop (infer.py:561-681): differentiable float32 path on the training kernels, first-order
+            # gradients with respect to every (fast) weight and every input level
+            from .meta_grad import meta_head_train_forward
+            return meta_head_train_forward(self, x, conv_dw_rep, conv_pw_rep, conv_pb_rep, bn_rep_w, bn_rep_b, predict,
+                                           self.predict_class if both else None, levels, ret_activs, both)
         lib = _lib.load()
         dev, dtype, dt = x0.device, x0.dtype, _DT[x0.dtype]
         B, F, A = x0.shape[0], self.num_channels, self.num_anchors

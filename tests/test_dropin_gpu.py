@@ -158,6 +158,83 @@ def test_infer_validation_iteration_as_written():
             del sys.modules[k]
 
 
+def test_infer_training_iteration_inner_and_outer_gradients():
+    """infer.py:561-685 as the script writes it: support pass through the MetaHead with grad, BCE on the anchor confidences,
+    `torch.autograd.grad(..., model.class_net.parameters(), allow_unused=True, only_inputs=True, create_graph=True)` (:658),
+    fast weights `par - par_lr * inner_grad` (:660-678), query pass `mode='qry_cls'` with them (:681), `loss_fn` (:683),
+    `final_loss.backward()` (:687) - the outer gradient reaches the head's parameters and the learnable inner learning rates.
+    (First-order MAML: the HIP backward is not itself differentiable, see effdet/meta_grad.py.)"""
+    import torch.nn.functional as F
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'ood_object_detection_amd'))
+    try:
+        for k in [k for k in sys.modules if k == 'effdet' or k.startswith('effdet.')]:
+            del sys.modules[k]
+        from effdet.config import get_efficientdet_config
+        from effdet.efficientdet import EfficientDet, MetaHead
+        from effdet.loss import DetectionLoss
+        torch.manual_seed(0)
+        h = get_efficientdet_config('tf_efficientdet_d0')
+        h.image_size = (128, 128)
+        h.num_classes = 4
+        model = EfficientDet(h, pretrained_backbone=False)
+        class_net_init_params = {n: v.data.detach().clone() for n, v in model.named_parameters() if 'class_net' in n}
+        model.class_net = MetaHead(model.config, pretrain_init=class_net_init_params)                 # infer.py:191
+        model.config.num_classes = 1                                                                  # :192
+        model_config = model.config
+        model.to('cuda')
+        loss_fn = DetectionLoss(model_config)                                                         # :212
+        learnable_lr = [torch.nn.Parameter(torch.tensor(0.1, device='cuda')) for _ in range(model_config.box_class_repeats + 2)]
+        g = torch.Generator().manual_seed(3)
+        supp_imgs = torch.randn(3, 3, 128, 128, generator=g).to('cuda')
+        qry_imgs = torch.randn(2, 3, 128, 128, generator=g).to('cuda')
+        with torch.no_grad():
+            supp_activs = model(supp_imgs, mode='supp_bb')                                            # :343
+            qry_feats = model(qry_imgs, mode='bb')
+            qry_activs, qry_box_out = model(qry_feats, mode='not_cls')                                # :349
+            qry_activs = [a.clone() for a in qry_activs]
+            qry_box_out = [b.clone() for b in qry_box_out]
+        # ---- inner step(s) on the support set
+        anch_confs, obj_embds = model(supp_activs, fast_weights=None, mode='supp_cls')                # :563
+        assert len(anch_confs) == 3 and anch_confs[0].requires_grad
+        cls_logits = torch.cat([c.movedim(1, 3).reshape(-1) for c in anch_confs])
+        target = torch.rand(cls_logits.shape, generator=g).to('cuda')
+        supp_class_loss = F.binary_cross_entropy_with_logits(cls_logits, target)                      # :656
+        inner_grad = torch.autograd.grad(supp_class_loss, model.class_net.parameters(), allow_unused=True, only_inputs=True,
+                                         create_graph=True)                                           # :658
+        fast_weights = []
+        for p_ix, (n, par) in enumerate(model.class_net.named_parameters()):                          # :660-678
+            if 'bn_' in n:
+                update_par = par
+            else:
+                par_lr = learnable_lr[-2] if 'predict_dw' in n else (learnable_lr[-1] if 'predict_p' in n else learnable_lr[int(n[7])])
+                assert inner_grad[p_ix] is not None, n
+                update_par = par - par_lr * inner_grad[p_ix]
+            fast_weights.append(update_par)
+        # ---- query pass with the fast weights, loss, backward
+        qry_class_out = model(qry_activs, fast_weights=fast_weights, mode='qry_cls')                  # :681
+        sizes = [c.shape[-1] for c in qry_class_out]
+        rs = np.random.RandomState(1)
+        qry_cls_anchors = [torch.from_numpy(rs.choice([-2, -1, -1, -1, 0], size=(2, s, s, 9)).astype(np.int64)).to('cuda') for s in sizes]
+        qry_bbox_anchors = [torch.from_numpy((rs.normal(0, 0.2, (2, s, s, 36)) * (rs.uniform(size=(2, s, s, 36)) < 0.3)).astype(np.float32)).to('cuda') for s in sizes]
+        qry_num_positives = torch.tensor([5.0, 3.0], device='cuda')
+        qry_loss, qry_class_loss, qry_box_loss = loss_fn(qry_class_out, qry_box_out, qry_cls_anchors, qry_bbox_anchors, qry_num_positives)  # :683
+        qry_loss.backward()                                                                           # :687
+        got = {n: p.grad for n, p in model.class_net.named_parameters()}
+        assert all(v is not None and bool(torch.isfinite(v).all()) for v in got.values())
+        assert float(got['predict_pw'].abs().max()) > 0 and float(got['conv_pw0'].abs().max()) > 0
+        assert all(lr.grad is not None and bool(torch.isfinite(lr.grad).all()) for lr in learnable_lr)
+        assert any(float(lr.grad.abs()) > 0 for lr in learnable_lr)
+        # the inner step moved the query outputs
+        with torch.no_grad():
+            base = model(qry_activs, fast_weights=None, mode='qry_cls')
+        assert not torch.equal(base[0], qry_class_out[0].detach())
+    finally:
+        sys.path.remove(os.path.join(root, 'ood_object_detection_amd'))
+        for k in [k for k in sys.modules if k == 'effdet' or k.startswith('effdet.')]:
+            del sys.modules[k]
+
+
 def test_integration_md_ctypes_stubs_run():
     """the ctypes bindings printed in INTEGRATION.md (section B) are executed verbatim and compared with the package's own
     callables: documentation that cannot rot"""

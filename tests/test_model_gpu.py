@@ -684,3 +684,86 @@ def test_nested_fork_inside_capture_is_refused():
         g.replay()
         torch.cuda.synchronize()
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize('both,offset', [(False, 0), (True, 2)])
+def test_meta_head_gradients_match_oracle_autograd(golden, both, offset):
+    """the MAML inner loop's gradients (infer.py:658: autograd.grad of a loss on the MetaHead outputs w.r.t. the head's
+    parameters; :681 the query pass with fast weights): d loss / d (every weight, every input level) from the HIP training
+    kernels against torch autograd through the oracle's MetaHead restatement (itself pinned to the reference class)"""
+    from _seeded import meta_lists, meta_nets_case, seeded_tensor
+    from ood_object_detection_amd.effdet.config import get_efficientdet_config
+    from ood_object_detection_amd.effdet.meta_head import MetaHead
+    g = golden('meta_nets')
+    c = meta_nets_case(g)
+    cfg = get_efficientdet_config('tf_efficientdet_d0')
+    L, R = c['L'], c['R']
+    mh = MetaHead(cfg, pretrain_init=c['init'])
+    with torch.no_grad():
+        mh.predict_pw.copy_(c['extra']['predict_pw']); mh.predict_pb.copy_(c['extra']['predict_pb'])
+    if both:
+        mh.add_head()
+        mh.predict_pw_sep.data.copy_(c['extra']['predict_pw_sep']); mh.predict_pb_sep.data.copy_(c['extra']['predict_pb_sep'])
+    mh = mh.to(DEV)
+    xs = [t.clone().to(DEV).requires_grad_() for t in c['x']]
+    nlev = L - offset
+    # a loss that reaches every output: random cotangents for outputs, x_pred activations (and the separate class head)
+    go = [seeded_tensor(61, 'go%d' % i, (c['B'], 9, s, s)) for i, s in enumerate(c['sizes'][offset:])]
+    ga = [seeded_tensor(61, 'ga%d' % i, (c['B'], c['F'], s, s)) * 0.3 for i, s in enumerate(c['sizes'][offset:])]
+    gc = [seeded_tensor(61, 'gc%d' % i, (c['B'], 9, s, s)) for i, s in enumerate(c['sizes'][offset:])]
+
+    def loss_of(outs, acts, couts):
+        t = sum((o * w.to(o.device)).sum() for o, w in zip(outs, go)) + sum((a * w.to(a.device)).sum() for a, w in zip(acts, ga))
+        if couts is not None:
+            t = t + sum((o * w.to(o.device)).sum() for o, w in zip(couts, gc))
+        return t
+    # ---- HIP: module parameters, then again through explicit fast weights
+    params = list(mh.parameters())
+    if both:
+        co, ao, act = mh(xs, ret_activs=True, level_offset=offset, heads='both')
+    else:
+        (ao, act), co = mh(xs, ret_activs=True, level_offset=offset), None
+    assert len(ao) == nlev and ao[0].requires_grad
+    grads = torch.autograd.grad(loss_of(ao, act, co), params + xs[offset:], allow_unused=True)
+    names = [n for n, _ in mh.named_parameters()]
+    # ---- oracle on the CPU
+    dw, pw, pb, pred, bw, bb = meta_lists(c['init'], c['extra'], L, R)
+    leaf = lambda ts: [t.clone().requires_grad_() for t in ts]
+    dw, pw, pb, pred, bw, bb = leaf(dw), leaf(pw), leaf(pb), leaf(pred), leaf(bw), leaf(bb)
+    pc = leaf([c['extra']['predict_pw_sep'], c['extra']['predict_pb_sep']]) if both else None
+    xr = [t.clone().requires_grad_() for t in c['x']]
+    res = om.meta_head_forward(dw, pw, pb, bw, bb, pred, xr, level_offset=offset, predict_class=pc)
+    ro, ra, rc = (res[0], res[1], res[2]) if both else (res[0], res[1], None)
+    ref_named = {}
+    for r in range(R):
+        ref_named['conv_dw%d' % r], ref_named['conv_pw%d' % r], ref_named['conv_pb%d' % r] = dw[r], pw[r], pb[r]
+    ref_named['predict_dw'], ref_named['predict_pw'], ref_named['predict_pb'] = pred
+    for lev in range(L):
+        for r in range(R):
+            ref_named['bn_w%d%d' % (r, lev)], ref_named['bn_b%d%d' % (r, lev)] = bw[lev * R + r], bb[lev * R + r]
+    if both:
+        ref_named['predict_pw_sep'], ref_named['predict_pb_sep'] = pc
+    ref_grads = torch.autograd.grad(loss_of(ro, ra, rc), [ref_named[n] for n in names] + xr[offset:], allow_unused=True)
+    gmax = max(float(r.abs().max()) for r in ref_grads if r is not None)
+    worst = []
+    for n, a, r in zip(names + ['x%d' % i for i in range(offset, L)], grads, ref_grads):
+        if r is None:                                   # levels below the offset do not reach the loss
+            assert a is None or float(a.abs().max()) == 0.0, n
+            continue
+        assert a is not None, n
+        floor = 1e-5 * gmax
+        if n.startswith('conv_pb'):
+            floor = 1e-4 * gmax                         # bias in front of a batch-statistics BN: analytically zero gradient
+        worst.append((float((a.cpu() - r).abs().max()) / max(float(r.abs().max()), floor), n))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 2e-3, worst[:6]
+    # the fast-weight path (reference list order) gives the same gradients as the parameter path
+    fw = [p.detach().clone().requires_grad_() for p in (mh.conv_dw_rep + mh.conv_pw_rep + mh.conv_pb_rep + mh.predict + mh.bn_rep_w + mh.bn_rep_b)]
+    out_f = mh([t.detach() for t in xs], fast_weights=fw)
+    gf = torch.autograd.grad(sum((o * w.to(DEV)).sum() for o, w in zip(out_f, [seeded_tensor(61, 'go%d' % i, (c['B'], 9, s, s)) for i, s in enumerate(c['sizes'])])), fw, allow_unused=True)
+    assert all(x is not None for x in gf[:3 * R + 3])
+    # one SGD inner step on the fast weights changes the query output (infer.py:660-681)
+    with torch.no_grad():
+        fw2 = [w - 0.1 * (gg if gg is not None else torch.zeros_like(w)) for w, gg in zip(fw, gf)]
+        out_q = mh([t.detach() for t in xs], fast_weights=fw2)
+        assert not torch.equal(out_q[0], out_f[0].detach())
