@@ -354,6 +354,14 @@ int effdet_eval_ap(void* stream, const float* scores, const int* classes, const 
 
 /* ---- OOD evaluation helpers -------------------------------------------- */
 
+/* The fork's novelty score (infer.py:425-427, 465-471, 607-616), reported beside energy / max-logit:
+ * embds [n,d] fp32 = ProjectionNet outputs (normalised inside, F.normalize p=2), confs [n] = anchor confidences (logits),
+ * proto_idx [m] int64 = rows of embds that form the cluster (`max_idxs` of the episode code).
+ * soft_thresh = sigmoid(dot_mult * (conf + dot_add)); sim = mean_j (use_max = 0) or max_j (use_max = 1) of the cosine
+ * similarity to the prototypes; score = soft_thresh * sim.  m * d <= 16384. */
+int effdet_novelty_score(void* stream, const float* embds, const float* confs, const long long* proto_idx, int n, int d, int m,
+                         float dot_mult, float dot_add, int use_max, float* score, float* soft_thresh, float* sim);
+
 /* Image-level OOD score out[b] = max_a(-energy[b, a]) over the per-anchor energies [B, N]. */
 int effdet_ood_image_score(void* stream, const float* energy, int B, long long N, float* out);
 /* AUROC of in-distribution scores `pos` against OOD scores `neg` by exact pair counting:

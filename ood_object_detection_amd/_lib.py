@@ -56,6 +56,8 @@ SIGNATURES = {
                                       c_int, c_float, c_void_p]),
     'effdet_adam_clip_step_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_float, c_float, c_float, c_float,
                                           c_void_p, c_float, c_void_p]),
+    'effdet_novelty_score': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int,
+                                     c_void_p, c_void_p, c_void_p]),
     'effdet_ood_image_score': (c_int, [c_void_p, c_void_p, c_int, c_ll, c_void_p]),
     'effdet_auroc_counts': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'effdet_sepconv_meta': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

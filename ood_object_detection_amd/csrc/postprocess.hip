@@ -835,6 +835,62 @@ __global__ __launch_bounds__(256) void auroc_count_kernel(const float* pos, cons
 
 }  // namespace
 
+// The fork's novelty ("OOD-ish") score (infer.py:425-427, 465-471, 607-616): with proj = F.normalize(ProjectionNet
+// output, p=2) and the cluster prototypes the episode code picked (`max_idxs`),
+//     soft_thresh = sigmoid(dot_mult * (conf + dot_add));  sim_avg_i = mean_j <proj_i, proj_proto_j>;  sim_max_i = max_j ...
+//     score_i = soft_thresh_i * sim_avg_i  (sim_target 'avg')   |   soft_thresh_i * sim_max_i  (sim_target 'max', without the
+//     target_clust factor of :467, which belongs to the loss).
+// One workgroup normalises the m prototypes into LDS once, then each wave scores anchors: the embedding row is normalised in
+// registers (F.normalize: x / max(||x||, 1e-12)) and dotted with every prototype.
+namespace {
+__global__ __launch_bounds__(256) void novelty_score_kernel(const float* embds, const float* confs, const long long* proto, int n, int d, int m,
+                                                            float dot_mult, float dot_add, int use_max,
+                                                            float* score, float* soft_thresh, float* sim) {
+    extern __shared__ float pl_[];                     // [m][d] normalised prototypes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int j = wave; j < m; j += 4) {
+        const float* row = embds + proto[j] * (long long)d;
+        float ss = 0.f;
+        for (int c = lane; c < d; c += 64) { const float v = row[c]; ss += v * v; }
+        ss = wave_reduce_sum(ss);
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        for (int c = lane; c < d; c += 64) pl_[j * d + c] = row[c] * inv;
+    }
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * 4 + wave; i < n; i += (long long)gridDim.x * 4) {
+        const float* row = embds + i * d;
+        float ss = 0.f;
+        for (int c = lane; c < d; c += 64) { const float v = row[c]; ss += v * v; }
+        ss = wave_reduce_sum(ss);
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        float acc_sum = 0.f, acc_max = -INFINITY;
+        for (int j = 0; j < m; ++j) {
+            float dot = 0.f;
+            for (int c = lane; c < d; c += 64) dot += (row[c] * inv) * pl_[j * d + c];
+            dot = wave_reduce_sum(dot);
+            acc_sum += dot; acc_max = fmaxf(acc_max, dot);
+        }
+        if (lane == 0) {
+            const float st = 1.0f / (1.0f + expf(-(dot_mult * (confs[i] + dot_add))));
+            const float sv = use_max ? acc_max : acc_sum / (float)m;
+            soft_thresh[i] = st; sim[i] = sv; score[i] = st * sv;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int effdet_novelty_score(void* stream, const float* embds, const float* confs, const long long* proto_idx, int n, int d, int m,
+                                    float dot_mult, float dot_add, int use_max, float* score, float* soft_thresh, float* sim) {
+    EFFDET_ENTER();
+    if (!embds || !confs || !proto_idx || !score || !soft_thresh || !sim || n <= 0 || d <= 0 || m <= 0) return EFFDET_EINVAL;
+    const size_t lds = (size_t)m * d * 4;
+    if (lds > 64 * 1024) return EFFDET_EINVAL;                      // up to 64 prototypes of 256 dimensions
+    int blocks = (n + 3) / 4; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(novelty_score_kernel, dim3(blocks), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+                       embds, confs, proto_idx, n, d, m, dot_mult, dot_add, use_max, score, soft_thresh, sim);
+    return effdet_check_launch();
+}
+
 extern "C" int effdet_ood_image_score(void* stream, const float* energy, int B, long long N, float* out) {
     EFFDET_ENTER();
     if (!energy || !out || B <= 0 || N <= 0) return EFFDET_EINVAL;

@@ -97,3 +97,78 @@ class DetectionLoss(nn.Module):
                        num_classes=self.num_classes, alpha=self.alpha, gamma=self.gamma, delta=self.delta,
                        box_loss_weight=self.box_loss_weight, label_smoothing=self.label_smoothing,
                        legacy_focal=self.legacy_focal)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Episode-level auxiliary losses the fork's scripts import next to DetectionLoss (infer.py:17, pretrain.py:15).  They act on
+# the small per-episode tensors of the few-shot logic (similarity targets, anchor confidences), not on the detection hot
+# path of SURVEY §8: plain differentiable tensor expressions on whatever device their inputs live on.
+# ------------------------------------------------------------------------------------------------------------------------
+def cosine_loss(input, target, margin=0., reduction='mean'):
+    """effdet/loss.py:97-101: pairs labelled 1 are pulled to similarity 1, the others pushed below `margin`; hinge at 0; mean."""
+    per = torch.where(target == 1., 1 - input, input - margin)
+    return per.clamp(min=0.).mean()
+
+
+def _signed_weight_sums(err, weights):
+    ws = torch.sign(err) * weights
+    return ws[ws > 0.].sum(), ws[ws < 0.].sum()
+
+
+def smooth_l1_loss(input, target, beta: float = 1. / 9, weights=None, size_average: bool = False):
+    """effdet/loss.py:121-154: L1 below beta = 1e-5, else quadratic inside |err| < beta and linear outside; optional weights.
+    Returns the mean (size_average) or (sum, sum of positive signed weights, sum of negative signed weights)."""
+    err = input - target
+    a = err.abs()
+    loss = a if beta < 1e-5 else torch.where(a < beta, 0.5 * a.pow(2) / beta, a - 0.5 * beta)
+    pos = neg = None
+    if weights is not None:
+        if beta < 1e-5:                        # same failure as the reference, whose pure-L1 branch never defines `err` (:132-147)
+            raise UnboundLocalError("local variable 'err' referenced before assignment (smooth_l1_loss: beta < 1e-5 with weights)")
+        loss = loss * weights
+        pos, neg = _signed_weight_sums(err, weights)
+    if size_average:
+        return loss.mean()
+    if weights is None:
+        raise UnboundLocalError('smooth_l1_loss(size_average=False) returns the weighted sign sums: pass weights (as the reference requires)')
+    return loss.sum(), pos, neg
+
+
+def l2_loss(input, target, beta: float = 1. / 9, weights=None, size_average: bool = False):
+    """effdet/loss.py:156-168: squared error (optionally weighted), always the mean, plus the two signed weight sums."""
+    err = input - target
+    loss = err ** 2
+    if weights is None:
+        raise UnboundLocalError('l2_loss returns the weighted sign sums: pass weights (as the reference requires)')
+    loss = loss * weights
+    pos, neg = _signed_weight_sums(err, weights)
+    return loss.mean(), pos, neg
+
+
+class SupportLoss(nn.Module):
+    """effdet/loss.py:404-439 -> class_loss_fn (:188-221) -> new_focal_loss (:49-95): per level, alpha-weighted (alpha given at
+    call time, may be None) `loss_func(logits, targets)` ('ce': BCE with logits, 'mse'), label smoothing, divided by
+    sum(num_positives) + 1, summed over everything.  cls_targets are dense float maps [B, A*C, H, W] like the outputs."""
+
+    def __init__(self, config, loss_type):
+        super().__init__()
+        self.config = config
+        self.num_classes = config.num_classes
+        self.alpha, self.gamma, self.label_smoothing = config.alpha, config.gamma, config.label_smoothing
+        if loss_type not in ('ce', 'mse'):
+            raise ValueError("loss_type must be 'ce' or 'mse'")
+        self.loss_type = loss_type
+
+    def forward(self, cls_outputs, cls_targets, num_positives, alpha):
+        import torch.nn.functional as F
+        norm = num_positives.sum() + 1.0
+        total = []
+        for out, tgt in zip(cls_outputs, cls_targets):
+            logits, t = out.permute(0, 2, 3, 1), tgt.permute(0, 2, 3, 1).to(out.dtype)
+            factor = None if alpha is None else t * alpha + (1. - t) * (1. - alpha)
+            if self.label_smoothing > 0.:
+                t = t * (1. - self.label_smoothing) + .5 * self.label_smoothing
+            per = F.binary_cross_entropy_with_logits(logits, t, reduction='none') if self.loss_type == 'ce' else F.mse_loss(logits, t, reduction='none')
+            per = per / norm if factor is None else factor * per / norm
+            total.append(per.sum())
+        return torch.stack(total).sum()

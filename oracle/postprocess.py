@@ -225,3 +225,16 @@ def image_ood_score(energy):
     """[B, N] per-anchor energies -> [B] max_a(-energy_a)."""
     import numpy as np
     return (-np.asarray(energy, dtype=np.float32)).max(axis=1)
+
+
+def novelty_score(proj_embds, confs, proto_idx, dot_mult, dot_add, sim_target='avg'):
+    """infer.py:425-427 / 607-616 verbatim in meaning: proj = F.normalize(embds, p=2); sim_mat = proj @ proj.t();
+    soft_thresh = sigmoid(dot_mult * (confs + dot_add)); 'avg': soft_thresh * sim_mat[:, max_idxs].mean(1) (:469-471, :616);
+    'max': soft_thresh * sim_mat[:, max_idxs].max(1) (:453, :612 without the loss-side target_clust factor)."""
+    import torch.nn.functional as F
+    proj = F.normalize(proj_embds.float(), p=2)
+    sim_mat = torch.matmul(proj, proj.t())
+    st = (dot_mult * (confs.float() + dot_add)).sigmoid()
+    cols = sim_mat[:, proto_idx]
+    sim = cols.mean(1) if sim_target == 'avg' else cols.max(1)[0]
+    return st * sim, st, sim

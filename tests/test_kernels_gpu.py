@@ -727,3 +727,20 @@ def test_detection_evaluator_golden(golden, tag):
     m = ev.evaluate(names)
     assert (np.isnan(r['mean_ap']) and np.isnan(m['Precision/mAP@0.5IOU'])) or abs(m['Precision/mAP@0.5IOU'] - r['mean_ap']) < 1e-12
     assert np.allclose([m['AP@0.5IOU/c%d' % i] for i in range(C)], r['per_class_ap'], rtol=0, atol=1e-12, equal_nan=True)
+
+
+@pytest.mark.parametrize('target', ['avg', 'max'])
+def test_novelty_score_matches_infer_py_expressions(target):
+    """the fork's soft_thresh * similarity score (infer.py:425-427, 465-471, 607-616) against the literal torch expressions"""
+    from ood_object_detection_amd import ood
+    g = torch.Generator().manual_seed(8)
+    n, d, m = 3000, 64, 25
+    e = torch.randn(n, d, generator=g) * 3.0
+    e[5] = 0.0                                        # a zero row: F.normalize's eps path
+    conf = torch.randn(n, generator=g) * 2.0 - 3.0
+    proto = torch.randperm(n, generator=g)[:m]
+    ref, st, sim = op.novelty_score(e, conf, proto, 3.0, 3.0, target)
+    out = ood.novelty_score(e.to(DEV), conf.to(DEV), proto.to(DEV), 3.0, 3.0, target)
+    assert float((out['soft_thresh'].cpu() - st).abs().max()) <= 1e-6
+    assert float((out['sim'].cpu() - sim).abs().max()) <= 2e-6
+    assert float((out['score'].cpu() - ref).abs().max()) <= 2e-6

@@ -20,6 +20,7 @@ Fixtures written
     config.npz                model_config.get_efficientdet_config + fpn_config.bifpn_config dumps
     bifpn_head.npz            EfficientDet(config) forward (reference BiFpn/HeadNet code on stub
                               conv layers and the oracle backbone): key/shape list + outputs
+    aux_losses.npz            loss.cosine_loss / smooth_l1_loss / l2_loss / SupportLoss values (+ one gradient each)
     meta_nets.npz             the reference's own MetaHead / AnchorNet / ProjectionNet classes
                               (efficientdet.py:569-830) on seeded weights and inputs: forwards, fast_weights,
                               level_offset, separate head, weighted_median, encoding tables
@@ -374,6 +375,41 @@ def gen_meta_nets():
     save('meta_nets', **out)
 
 
+def gen_aux_losses():
+    """the episode-level losses infer.py / pretrain.py import next to DetectionLoss (effdet/loss.py:97-168, 404-439)"""
+    from absl import flags
+    from effdet.config import get_efficientdet_config
+    from effdet.loss import SupportLoss, cosine_loss, l2_loss, smooth_l1_loss
+    out = {}
+    x = torch.from_numpy(seeded_array(71, 'x', (400,), scale=0.8))
+    t = torch.from_numpy((seeded_array(71, 't', (400,)) > 0.3).astype(np.float32) * 2 - 1)
+    w = torch.from_numpy(seeded_array(71, 'w', (400,), kind='uniform'))
+    tgt = torch.from_numpy(seeded_array(71, 'tgt', (400,), scale=0.5))
+    out['cos_0'] = cosine_loss(x.clone(), t, margin=0.)
+    out['cos_m'] = cosine_loss(x.clone(), t, margin=0.2)
+    a, b, c = smooth_l1_loss(x.clone(), tgt, beta=1. / 9, weights=w)
+    out['sl1_b9'] = torch.stack([a, b, c])
+    out['sl1_b9_mean'] = smooth_l1_loss(x.clone(), tgt, beta=1. / 9, weights=w.clone(), size_average=True)
+    out['sl1_b0_mean'] = smooth_l1_loss(x.clone(), tgt, beta=0.0, size_average=True)     # (beta < 1e-5 with weights raises in the reference)
+    a, b, c = l2_loss(x.clone(), tgt, weights=w)
+    out['l2'] = torch.stack([a, b, c])
+    cfg = get_efficientdet_config('tf_efficientdet_d0')
+    cfg.num_classes = 1
+    sizes = [8, 4, 2]
+    co = [torch.from_numpy(seeded_array(72, 'co%d' % i, (2, 9, s, s), scale=1.5)) for i, s in enumerate(sizes)]
+    ct = [torch.from_numpy(seeded_array(72, 'ct%d' % i, (2, 9, s, s), kind='uniform')) for i, s in enumerate(sizes)]
+    npos = torch.tensor([3., 5.])
+    for lt in ('ce', 'mse'):
+        for tag, alpha, ls in (('a25', 0.25, 0.0), ('none', None, 0.0), ('ls', 0.25, 0.1)):
+            cfg.label_smoothing = ls
+            leaf = [c.clone().requires_grad_() for c in co]
+            v = SupportLoss(cfg, lt)(leaf, ct, npos, alpha)
+            out['sup_%s_%s' % (lt, tag)] = v.detach()
+            out['sup_%s_%s_g0' % (lt, tag)] = torch.autograd.grad(v, leaf)[0]
+    out['meta'] = np.array(sizes)
+    save('aux_losses', **out)
+
+
 def gen_evaluation():
     """mAP / CorLoc of the reference's ObjectDetectionEvaluator (effdet/evaluation/detection_evaluator.py:96-316) the way
     pretrain.py:246-252 drives it."""
@@ -399,6 +435,6 @@ def gen_evaluation():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['anchors', 'post_process', 'decode', 'soft_nms', 'generate_detections', 'loss',
-                             'labeler', 'config', 'bifpn_head', 'evaluation', 'meta_nets']
+                             'labeler', 'config', 'bifpn_head', 'evaluation', 'meta_nets', 'aux_losses']
     for w in which:
         globals()['gen_' + w]()
