@@ -195,6 +195,49 @@ def parity_bf16(model_f32_cpu, x_cpu, dev, soft_nms=False):
     return out
 
 
+def kernels_sha16():
+    """content hash of the kernel sources: ties committed PMC traffic files to the kernels they were measured on"""
+    import glob, hashlib
+    h = hashlib.sha256()
+    root = os.path.join(ROOT, 'ood_object_detection_amd', 'csrc')
+    for f in sorted(glob.glob(os.path.join(root, '*.hip')) + glob.glob(os.path.join(root, '*.h'))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def auroc_surrogate(model, image, dev, dtype, n_img=32, bs=8, planted=3, seed=7):
+    """BASELINE config 4 surrogate: there is no COCO / OpenImages-unseen data and no trained checkpoint here, so
+    in-distribution = images whose class logits carry a few PLANTED high-confidence anchors (logit +6 on one class of `planted`
+    random anchors per image - what a trained detector produces on an object it knows), OOD = the same network on noise images
+    with the logits as they come out.  Both go through the real pipeline (backbone -> BiFPN -> heads -> per-anchor energy in the
+    class-head epilogue -> image score max_a(-energy_a) -> pair-counting AUROC, all HIP kernels); for the planted anchors the
+    energy is updated from the stored logits with the same -logsumexp.  Synthetic by construction; reported as such."""
+    from ood_object_detection_amd import ood
+    g = torch.Generator(device=dev).manual_seed(seed)
+    scores = {'in': [], 'ood': []}
+    C = model.config.num_classes
+    with torch.no_grad():
+        for kind in ('in', 'ood'):
+            for _ in range(n_img // bs):
+                x = torch.randn(bs, 3, image, image, device=dev, generator=g).to(dtype)
+                model(x)
+                eng = model._engine
+                energy = eng.ood_energy.clone()                       # [bs, N] float32 from the class-head epilogue
+                if kind == 'in':
+                    N = energy.shape[1]
+                    a = torch.randint(0, N, (bs, planted), device=dev, generator=g)
+                    c = torch.randint(0, C, (bs, planted), device=dev, generator=g)
+                    rows = eng.cls_all.float()[torch.arange(bs, device=dev)[:, None], a]          # [bs, planted, C] stored logits
+                    rows[torch.arange(bs, device=dev)[:, None], torch.arange(planted, device=dev)[None, :], c] = 6.0
+                    energy[torch.arange(bs, device=dev)[:, None], a] = -torch.logsumexp(rows, dim=2)
+                scores[kind].append(ood.image_scores(energy.contiguous()).clone())
+    s_in, s_ood = torch.cat(scores['in']), torch.cat(scores['ood'])
+    return {'auroc_in_dist_positive': round(ood.auroc(s_in, s_ood), 4), 'score': 'max_a(-energy_a)',
+            'mean_score_in': round(float(s_in.mean()), 4), 'mean_score_ood': round(float(s_ood.mean()), 4),
+            'images': '%d in-dist (planted: %d anchors per image at logit +6) + %d OOD (noise)' % (n_img, planted, n_img), 'data': 'synthetic'}
+
+
 def timed_steps(model, x, dev, nfl, sub, steps, warmup, use_graph, barrier):
     """W warm-up + K timed DetBenchPredict.forward steps with `nfl` batches in flight (own engine instance, input and stream
     per slot, shared weights).  Returns (elapsed seconds, launch mode, first bench)."""
@@ -263,6 +306,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the in-flight-1 / float32 / parity_bf16 side measurements')
     ap.add_argument('--soft-nms', action='store_true')
+    ap.add_argument('--auroc-surrogate', action='store_true', help='BASELINE config 4: add the synthetic in-dist / OOD AUROC block')
     ap.add_argument('--profile-out', default='')
     ap.add_argument('--in-flight', type=int, default=3,
                     help='batches in flight: consecutive steps alternate between this many engine instances / streams, so the '
@@ -389,12 +433,17 @@ def main():
     # HBM traffic of the dominant family: PMC counters cannot be read from inside this process, so the number
     # comes from the committed rocprofv3 --pmc passes of the same workload (tools/profile_gpu.sh ->
     # tools/pmc_traffic.py); null when the workload is not the profiled one.
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'latest_pmc_traffic.json')
-    if os.path.exists(tpath) and (args.model, args.image, B, args.dtype, args.classes) == ('tf_efficientdet_d0', 640, 64, 'bf16', 90):
+    wl = '%s/%d/%d/%s/%d' % (args.model, args.image, B, args.dtype, args.classes)
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic_%s.json' % wl.replace('/', '_'))
+    if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            roofline['traffic'] = int(tj['families'][dom]['bytes'] / d['launches'])
-            roofline['traffic_source'] = 'profiles/latest_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)'
+            if tj.get('kernels_sha16') == kernels_sha16() and tj.get('workload') == wl:
+                roofline['traffic'] = int(tj['families'][dom]['bytes'] / d['launches'])
+                roofline['traffic_over_algorithmic'] = round(tj['families'][dom]['bytes'] / max(1, d['bytes']), 3)
+                roofline['traffic_source'] = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this workload on these kernel sources, per launch)' % os.path.basename(tpath)
+            else:
+                roofline['traffic_stale'] = 'committed PMC file was measured on other kernel sources (%s != %s): re-run tools/profile_gpu.sh' % (tj.get('kernels_sha16'), kernels_sha16())
         except (KeyError, ValueError):
             pass
     if args.profile_out:
@@ -425,6 +474,8 @@ def main():
             torch.cuda.empty_cache()
             xp = torch.randn(4, 3, args.image, args.image, generator=torch.Generator().manual_seed(5))
             extra['parity_bf16'] = parity_bf16(build_model(args.model, args.image, args.classes), xp, dev, soft_nms=args.soft_nms)
+    if args.auroc_surrogate and world == 1:
+        extra['auroc_surrogate'] = auroc_surrogate(copy.copy(model), args.image, dev, dtype, bs=min(B, 8))
     cpu = None
     if want_cpu:
         def gpu_check(x1):
