@@ -285,9 +285,11 @@ RollGeometry pick_roll(int H, int W, int Cin, int mid, int k, int stride) {
     g.use = false;
     const int cbytes = Cin * 2;
     g.nkc = (cbytes + 63) / 64;
-    // Inputs wider than 64 channels stay with mbconv.hip's band x channel-slice form: there every 16-channel wave would stream the
-    // whole X row through its registers (Cin / 32 fragments per pixel tile) and that operand traffic, not the SiLU work, sets the
-    // time (measured: 1.3 - 2x slower than the shared-X form on the 40 x 40 and 20 x 20 maps of d0)
+    // Inputs wider than 64 channels stay with mbconv.hip's band x channel-slice form.  Both ways of feeding such a layer to
+    // 16-channel waves were built and measured on d0 (40 x 40 and 20 x 20 maps, round 2): X through each wave's own registers
+    // (Cin / 32 fragments per pixel tile: no registers left to prefetch, 3 waves per SIMD) ran 1.3 - 2x slower, and X staged
+    // once per workgroup in LDS with a barrier per row ran within +-10 % of that form - those small maps simply do not have
+    // enough rows x channel tiles to fill the chip with row-streaming waves - so neither is kept.
     if (g.nkc > 2 || mid % 16 || Cin % 8) return g;
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
     const int npair = (k * k + 1) / 2;
@@ -301,11 +303,8 @@ RollGeometry pick_roll(int H, int W, int Cin, int mid, int k, int stride) {
         // the prefetched rows (stride x IWa/16 tiles x K-chunks fragments) must fit the register budget without spills
         const int mt = iwa / 16;
         if (stride == 1) {
-            if (mt == 3 && g.nkc > 4) continue;
-            if (mt == 3 && k == 5 && (two + 15) / 16 == 3 && (g.nkc == 2 || g.nkc == 4)) continue;     // these two variants spill
-            if (mt == 4 && (g.nkc > 3 || k == 5)) continue;
+            if (mt == 4 && g.nkc > 1 && k == 5) continue;
         } else {
-            if (mt == 2 && g.nkc > 4) continue;
             if (mt >= 3 && (g.nkc > 1 || (mt == 4 && k == 5))) continue;
         }
         // rough issue cycles per output row of the strip set: expand tiles (MFMAs + epilogue) + depthwise tiles
@@ -314,12 +313,12 @@ RollGeometry pick_roll(int H, int W, int Cin, int mid, int k, int stride) {
     }
     if (best < 0) return g;
     g.ring_bytes = k * g.IWa * 32;
-    // waves per workgroup: a divisor of the channel-tile count that packs the CU's wave slots (16 at <= 128 VGPRs, 12 above)
-    const int tiles = mid / 16, slots = g.nkc <= 2 ? 16 : 12;
+    // waves per workgroup: a divisor of the channel-tile count that packs the CU's 16 wave slots
+    const int tiles = mid / 16;
     int bestfill = -1;
     for (int d = 1; d <= 8; ++d) {
         if (tiles % d) continue;
-        const int fill = (slots / d) * d;
+        const int fill = (16 / d) * d;
         if (fill > bestfill || (fill == bestfill && d > g.wpg)) { bestfill = fill; g.wpg = d; }
     }
     g.ngroups = tiles / g.wpg;
@@ -363,10 +362,6 @@ int launch_roll_ks(hipStream_t st, const RollArgs& r, const RollGeometry& g) {
     switch (g.nkc) {
         case 1: kern = roll_kernel_for<KS, S, 1>(mt, no); break;
         case 2: kern = roll_kernel_for<KS, S, 2>(mt, no); break;
-        case 3: kern = roll_kernel_for<KS, S, 3>(mt, no); break;
-        case 4: kern = roll_kernel_for<KS, S, 4>(mt, no); break;
-        case 5: kern = roll_kernel_for<KS, S, 5>(mt, no); break;
-        case 6: kern = roll_kernel_for<KS, S, 6>(mt, no); break;
         default: break;
     }
     if (kern == nullptr) return EFFDET_EINVAL;
