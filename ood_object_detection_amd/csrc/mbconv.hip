@@ -436,8 +436,14 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void mbconv_deep_kernel(Mb
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fpiece = lane >> 4;
-    const int b = blockIdx.y;
-    const int chunk = blockIdx.x % p.nchunks, band = blockIdx.x / p.nchunks;
+    // blocks are dealt round-robin over the 8 XCDs: image = (round, xcd), so that all channel slices / bands of an image run on
+    // ONE XCD and its L2 fetches that image's X once (it was fetched by up to 8 L2s: 2.6x read amplification in the counters)
+    const int xcd_ = blockIdx.x & 7, rr_ = blockIdx.x >> 3;
+    const int per_image_ = p.nchunks * p.nbands;
+    const int b = (rr_ / per_image_) * 8 + xcd_;
+    if (b >= p.B) return;
+    const int bx_ = rr_ % per_image_;
+    const int chunk = bx_ % p.nchunks, band = bx_ / p.nchunks;
     const int Cin = p.Cin, mid = p.mid, W = p.W;
     const int cbytes = Cin * (int)sizeof(T);
     const int nkc = (cbytes + 63) / 64;
@@ -800,7 +806,7 @@ int launch_deep(hipStream_t st, const MbArgs& a, const DeepGeometry& g) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return EFFDET_ELAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3(g.nchunks * g.nbands, a.B), dim3(NTH), g.lds, st, d);
+    hipLaunchKernelGGL(kern, dim3(((a.B + 7) / 8) * g.nchunks * g.nbands * 8), dim3(NTH), g.lds, st, d);
     return effdet_check_launch();
 }
 
