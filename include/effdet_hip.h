@@ -47,6 +47,7 @@ int effdet_stem_conv(void* stream, int in_dtype, int out_dtype, const void* X, c
 int effdet_stem_dw_fused(void* stream, int in_dtype, int dtype, const void* X, const void* Wk,
                          const float* s1, const float* t1, const float* taps, const float* s2, const float* t2,
                          void* Y, float* pool_partial, int B, int H, int W, int C);
+int effdet_stem_dw_parts(int dtype, int H, int W, int C);      /* pool partial rows per image of the kernel that will run (bf16: rolling-window form) */
 int effdet_stem_dw_tiles_per_image(int H, int W);
 
 /* Input normalisation of the reference's PrefetchLoader (effdet/data/loader.py:114-128):

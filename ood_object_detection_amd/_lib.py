@@ -31,6 +31,7 @@ SIGNATURES = {
     'effdet_stem_dw_fused_u8': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
     'effdet_stem_dw_tiles_per_image': (c_int, [c_int, c_int]),
+    'effdet_stem_dw_parts': (c_int, [c_int, c_int, c_int, c_int]),
     'effdet_pw_gemm_bn_act': (c_int, [c_void_p, c_int, c_void_p, c_ll, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                       c_int, c_void_p, c_void_p, c_int, c_void_p, c_ll, c_ll]),
     'effdet_dwconv_bn_act': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

@@ -169,6 +169,13 @@ __attribute__((visibility("hidden"))) int effdet_mbconv_roll_launch(hipStream_t 
                               const float* taps, const float* s2, const float* t2, float* pool_partial,
                               int B, int H, int W, int Cin, int mid, int k, int stride);
 
+// stem_roll.hip (internal): rolling-window form of the fused stem + stage-0 depthwise, bf16 only; parts = SE pool partial rows
+// per image when the form applies, 0 otherwise
+__attribute__((visibility("hidden"))) int effdet_stem_roll_parts(int H, int W, int C);
+__attribute__((visibility("hidden"))) int effdet_stem_roll_launch(hipStream_t st, int in_dtype, const void* X, const float* mean, const float* stdv,
+                            const void* Wk, const float* s1, const float* t1, const float* taps, const float* s2, const float* t2,
+                            void* Y, float* pool_partial, int B, int H, int W, int C);
+
 // TF "SAME" padding: amount in front (reference semantics live in timm)
 static inline int same_pad_before(int size, int k, int s) {
     int out = (size + s - 1) / s;

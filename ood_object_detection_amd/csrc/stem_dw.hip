@@ -273,6 +273,17 @@ size_t sd_lds_bytes(int C) {
 
 }  // namespace
 
+// SE pool partial rows per image of the kernel effdet_stem_dw_fused[_u8] will run for (dtype, H, W, C)
+extern "C" int effdet_stem_dw_parts(int dtype, int H, int W, int C) {
+    if (H <= 0 || W <= 0 || C <= 0 || (dtype & ~1)) return EFFDET_EINVAL;
+    if (dtype == 1) {
+        const int parts = effdet_stem_roll_parts(H, W, C);
+        if (parts > 0) return parts;
+    }
+    const int Ho = same_out(H, 2), Wo = same_out(W, 2);
+    return ((Ho + SD_TH - 1) / SD_TH) * ((Wo + SD_TW - 1) / SD_TW);
+}
+
 extern "C" int effdet_stem_dw_tiles_per_image(int H, int W) {
     if (H <= 0 || W <= 0) return EFFDET_EINVAL;
     const int Ho = same_out(H, 2), Wo = same_out(W, 2);
@@ -294,6 +305,8 @@ static int stem_dw_common(void* stream, int in_dtype, int dtype, const void* X, 
     a.tiles_x = (a.Wo + SD_TW - 1) / SD_TW; a.tiles_y = (a.Ho + SD_TH - 1) / SD_TH;
     a.vec_in = in_dtype == 1 && dtype == 1 && W % 2 == 0 && a.pad_l % 2 == 0 && reinterpret_cast<uintptr_t>(X) % 4 == 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == 1 && effdet_stem_roll_parts(H, W, C) > 0)          // bf16: the rolling-window form (stem_roll.hip) where it applies
+        return effdet_stem_roll_launch(st, in_dtype, X, mean, stdv, Wk, s1, t1, taps, s2, t2, Y, pool_partial, B, H, W, C);
     dim3 grid(a.tiles_x * a.tiles_y, B), block(256);
     const size_t lds = dtype == 0 ? sd_lds_bytes<float>(C) : sd_lds_bytes<bf16_t>(C);
     void (*kern)(SdArgs) = nullptr;

@@ -1,0 +1,358 @@
+// Rolling-window form of the fused network entry (bfloat16 throughput mode):
+//
+//   conv_stem 3x3 / s2 (TF-SAME) + bn1 + SiLU  ->  blocks.0.0.conv_dw 3x3 / s1 + bn1 + SiLU  (+ SE pool partial sums)
+//
+// replaces timm's conv_stem / bn1 / act1 and blocks.0.0.conv_dw / bn1 / act1 (reached from effdet/efficientdet.py:837), like
+// stem_dw.hip, with the structure of mbconv_roll.hip: every WAVE is an autonomous streaming engine without workgroup
+// barriers.  A wave owns (image, band of output rows, column strip) and ALL NJ = C / 16 channel tiles (the im2col operand is
+// the expensive part: it is built once and used for every tile).  Per output row it
+//   input:    fetches the 2 new rows of the 3 input planes (NCHW float32 / bfloat16 / raw uint8 with the loader's normalisation)
+//             one output row ahead, and interleaves them as [px][c0 c1 c2 0] bf16 (8 bytes per pixel) into a private 4-row LDS ring;
+//   stem:     one new stem row on the matrix cores: per kernel row ky the 3 taps x 4 (padded) channels of a pixel are 24
+//             contiguous bytes of that image, so with K ordered (ky, kx, c4) a lane's MFMA operand is ONE 16-byte LDS read;
+//             two MFMAs (ky 0 | 1, ky 2 | -) per 16 pixels x 16 channels, BN scale folded into the weights, shift as the
+//             initial accumulator, SiLU, zero outside the stem map, 8-byte store into the tile's 3-row ring;
+//   depthwise: the output row from the rings (diag(w[t0]) | diag(w[t1]) operands, mbconv_roll.hip), BN shift as the initial
+//             accumulator, SiLU, pool sums, range-checked 8-byte buffer stores.
+// Every input row is read from HBM once per strip (the tile form re-read a 37 x 37 patch per 16 x 16 outputs: 4.4x).
+// Needs an even pad_l (even W) and C = 32 (the b0 .. b2 stems); anything else takes stem_dw.hip's tile form.
+#include "common.h"
+
+namespace {
+
+struct SrArgs {
+    const void* X; const void* Wk;                // X NCHW; Wk [C][32] bf16 with k = (ky*3 + kx)*3 + ci (the engine's layout)
+    float nmean[3], nstd[3];
+    const float* s1; const float* t1; const float* taps; const float* s2; const float* t2;
+    void* Y; float* pool_partial;
+    int B, H, W, C, Ho, Wo, pad_t, pad_l;
+    int TWo, nstrips, band_rows, nbands, wpg, per_image;
+};
+
+typedef float f32x2r __attribute__((ext_vector_type(2)));
+DEV f32x4 silu4r(const f32x4 x) {
+    const f32x2r x0 = {x[0], x[1]}, x1 = {x[2], x[3]};
+    const f32x2r t0 = x0 * -1.4426950408889634f, t1 = x1 * -1.4426950408889634f;
+    const f32x2r d0 = f32x2r{__builtin_amdgcn_exp2f(t0[0]), __builtin_amdgcn_exp2f(t0[1])} + 1.0f;
+    const f32x2r d1 = f32x2r{__builtin_amdgcn_exp2f(t1[0]), __builtin_amdgcn_exp2f(t1[1])} + 1.0f;
+    const f32x2r y0 = x0 * f32x2r{__builtin_amdgcn_rcpf(d0[0]), __builtin_amdgcn_rcpf(d0[1])};
+    const f32x2r y1 = x1 * f32x2r{__builtin_amdgcn_rcpf(d1[0]), __builtin_amdgcn_rcpf(d1[1])};
+    return f32x4{y0[0], y0[1], y1[0], y1[1]};
+}
+
+template <int V> struct IntS { static constexpr int value = V; };
+
+constexpr int SR_TW = 30;                   // output columns per strip: 32 stem columns with the halo = 2 pixel tiles
+constexpr int SR_IPX = 72;                  // input pixels staged per row (2 * 32 + 1 = 65 used), 8 bytes each
+constexpr int SR_IROW = SR_IPX * 8;         // 576 bytes
+constexpr int SR_RING = 3 * 1024;           // per channel tile: 3 stem rows x 32 px x 16 ch bf16
+
+// IN: 0 float32, 1 bfloat16, 2 uint8 (normalised on the fly).  NJ = C / 16 channel tiles.
+template <int IN, int NJ>
+__global__ __launch_bounds__(512, 4) void stem_roll_kernel(SrArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    typedef bf16_t T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frow = lane & 15, kg = lane >> 4;
+    const int xcd = blockIdx.x & 7, rr_ = blockIdx.x >> 3;
+    const int b = (rr_ / p.per_image) * 8 + xcd;
+    if (b >= p.B) return;
+    const int q = (rr_ % p.per_image) * p.wpg + wave;              // (band, strip) of this wave
+    const int strip = q % p.nstrips, band = q / p.nstrips;
+    if (band >= p.nbands) return;                                   // waves are autonomous: no barrier follows
+    const int C = p.C;
+    char* const wl = lds + wave * (4 * SR_IROW + NJ * SR_RING);
+    char* const irows = wl;                                         // [4][SR_IPX][4] bf16 interleaved input rows
+    char* const rings = wl + 4 * SR_IROW;                           // [NJ][3][32 px][16 ch]
+
+    // ---- constants.  Stem weights as MFMA A operands: chunk 0 = (ky 0 | ky 1), chunk 1 = (ky 2 | zero); inside a ky the 16
+    // K slots are (kx, c4) = 12 real values + 4 zeros; the lane (row m = frow, pieces of 8 K) holds K = 8*kg .. 8*kg + 7.
+    Frag<T> wf[NJ][2];
+    f32x4 sh1[NJ], t2v[NJ];
+    unsigned abits[NJ][5];
+    const int hi = kg >> 1;
+    const bool dactive = (kg & 1) == (frow >> 3);
+    const int dq = (frow & 7) >> 1;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int ch = 16 * j + frow;
+        const float rs1 = p.s1[ch], rs2 = p.s2[ch];
+        const bf16_t* wrow = reinterpret_cast<const bf16_t*>(p.Wk) + (long long)ch * 32;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ky = 2 * c + (kg >> 1);                       // kernel row of this lane's half of the chunk
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int slot = 8 * (kg & 1) + e;                  // 0..15 inside the ky: kx = slot / 4, ci = slot % 4
+                const int kx = slot >> 2, ci = slot & 3;
+                const bool real = ky < 3 && kx < 3 && ci < 3;
+                wf[j][c].v[e] = real ? (bf16_t)((float)wrow[(ky * 3 + kx) * 3 + ci] * rs1) : (bf16_t)0.f;
+            }
+        }
+        sh1[j] = *reinterpret_cast<const f32x4*>(p.t1 + 16 * j + 4 * kg);
+        t2v[j] = *reinterpret_cast<const f32x4*>(p.t2 + 16 * j + 4 * kg);
+#pragma unroll
+        for (int pr = 0; pr < 5; ++pr) {
+            const int t = 2 * pr + hi;
+            const bool on = dactive && t < 9;
+            const float wv = on ? p.taps[(long long)(t < 9 ? t : 0) * C + ch] * rs2 : 0.f;
+            abits[j][pr] = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)wv) << (16 * (frow & 1));
+        }
+    }
+    const int oy_b = band * p.band_rows, oy_e = min(p.Ho, oy_b + p.band_rows);
+    const int ox0 = strip * p.TWo, tw = min(p.TWo, p.Wo - ox0);
+    const int sx0 = ox0 - 1;                                        // stem column of ring column 0
+    const int ix0 = 2 * sx0 - p.pad_l;                              // input column of staged pixel 0 (even)
+    // lane constants.  Staging: lane l handles input pixels l and l + 64 (the 65th) of a row.
+    constexpr int OOB = 0x7FFFFFF0;
+    const int esz = IN == 0 ? 4 : (IN == 1 ? 2 : 1);
+    int ivoff[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c = lane + 64 * h, ix = ix0 + c;
+        ivoff[h] = (c < 65 && ix >= 0 && ix < p.W) ? ix * esz : OOB;
+    }
+    float cmask[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int sx = sx0 + 16 * t + frow;
+        cmask[t] = (sx >= 0 && sx < p.Wo) ? 1.f : 0.f;
+    }
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.X)) + (long long)b * 3 * p.H * p.W * esz, 0, 3 * p.H * p.W * esz, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(p.Y) + (long long)b * p.Ho * p.Wo * C * 2, 0, p.Ho * p.Wo * C * 2, 0x00020000);
+    const int plane = p.H * p.W * esz;
+    const char* dl[2];
+    int yoff[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int oxl = 16 * u + frow;
+        const bool ok = oxl < tw;
+        dl[u] = rings + (ok ? oxl * 32 : 0) + (kg & 1) * 16;
+        yoff[u] = ok ? ((ox0 + oxl) * C + 4 * kg) * 2 : OOB;
+    }
+    char* const ring_e = rings + frow * 32 + kg * 8;
+    // im2col operand address inside a staged input row: pixel 2 * (16 t + frow) + 2 * (kg & 1), i.e. 16-byte aligned
+    const int xf_lane = (2 * frow + 2 * (kg & 1)) * 8;
+
+    // One input row = 3 planes x 2 lane-halves raw values, fetched one output row ahead.  bfloat16 input: lanes 0 .. 32 load a
+    // DWORD = two pixels per plane (ix0, W and pad_l are even, so a pair never straddles the image border): 6 loads per step
+    // instead of 12 two-byte ones, and one 16-byte LDS store per lane.
+    float raw[2][3][2];
+    unsigned rawd[2][3];
+    const int dvoff = (lane < 33 && ix0 + 2 * lane >= 0 && ix0 + 2 * lane < p.W) ? (ix0 + 2 * lane) * 2 : OOB;
+    auto fetch_rows = [&](int iy0) {                                  // input rows iy0, iy0 + 1
+        if constexpr (IN == 1) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                int iy = iy0 + r;
+                const bool rin = iy >= 0 && iy < p.H;
+                iy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(xrs, dvoff, ci * plane + iy * p.W * 2, 0);
+                    rawd[r][ci] = rin ? v : 0u;
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            int iy = iy0 + r;
+            const bool rin = iy >= 0 && iy < p.H;
+            iy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int so = ci * plane + iy * p.W * esz;
+                    float v;
+                    if constexpr (IN == 0) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ivoff[h], so, 0));
+                    else if constexpr (IN == 1) v = (float)__builtin_bit_cast(bf16_t, __builtin_amdgcn_raw_buffer_load_b16(xrs, ivoff[h], so, 0));
+                    else v = ((float)__builtin_amdgcn_raw_buffer_load_b8(xrs, ivoff[h], so, 0) - (ci == 0 ? p.nmean[0] : ci == 1 ? p.nmean[1] : p.nmean[2])) /
+                             (ci == 0 ? p.nstd[0] : ci == 1 ? p.nstd[1] : p.nstd[2]);
+                    // rows / columns outside the image are TF-SAME zero padding of the INPUT (uint8: zero after normalisation too)
+                    raw[r][ci][h] = (rin && ivoff[h] != OOB) ? v : 0.f;
+                }
+        }
+    };
+    auto commit_rows = [&](int iy0) {                                 // raw -> interleaved bf16 pixels in ring slots (iy & 3)
+        if constexpr (IN == 1) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                char* dst = irows + ((iy0 + r) & 3) * SR_IROW;
+                // {c0 c1} | {c2 0} of pixel 2*lane, then of pixel 2*lane + 1
+                const u32x4 v = {(rawd[r][0] & 0xFFFFu) | (rawd[r][1] << 16), rawd[r][2] & 0xFFFFu,
+                                 (rawd[r][0] >> 16) | (rawd[r][1] & 0xFFFF0000u), rawd[r][2] >> 16};
+                if (lane < 36) *reinterpret_cast<u32x4*>(dst + lane * 16) = v;
+            }
+            return;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            char* dst = irows + ((iy0 + r) & 3) * SR_IROW;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = lane + 64 * h;
+                if (c < SR_IPX) {
+                    typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+                    *reinterpret_cast<bf16x4_*>(dst + c * 8) = bf16x4_{(bf16_t)raw[r][0][h], (bf16_t)raw[r][1][h], (bf16_t)raw[r][2][h], (bf16_t)0.f};
+                }
+            }
+        }
+    };
+    // stem row sy -> ring slot `slot` of every channel tile (zeros when sy is outside the stem map: the depthwise conv pads IT)
+    auto stem_row = [&](int sy, int slot_bytes) {
+        const int iy0 = 2 * sy - p.pad_t;                             // first of its three input rows
+        const float rmask = (sy >= 0 && sy < p.Ho) ? 1.f : 0.f;
+        const char* r0 = irows + ((iy0 + (kg >> 1)) & 3) * SR_IROW + xf_lane;          // chunk 0: ky = kg >> 1 (0 | 1)
+        const char* r1 = irows + ((iy0 + 2) & 3) * SR_IROW + xf_lane;                  // chunk 1: ky = 2 (upper half: zero weights)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const Frag<T> x0 = ld_frag<T>(r0 + t * 256), x1 = ld_frag<T>(r1 + t * 256);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                f32x4 acc = sh1[j];
+                mma_chunk(wf[j][0], x0, acc);
+                mma_chunk(wf[j][1], x1, acc);
+                const f32x4 v = silu4r(acc) * (cmask[t] * rmask);
+                store4<T>(reinterpret_cast<T*>(ring_e + j * SR_RING + slot_bytes + 512 * t), v[0], v[1], v[2], v[3]);
+            }
+        }
+    };
+
+    float pl[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pl[j][r] = 0.f;
+    // ---- prologue: stem rows oy_b - 1 and oy_b (ring slots 0, 1).  Input rows of stem row s: 2s - pad_t .. + 2.
+    const int s_first = oy_b - 1;
+    {
+        const int iyA = 2 * s_first - p.pad_t;
+        fetch_rows(iyA); commit_rows(iyA);
+        fetch_rows(iyA + 2); commit_rows(iyA + 2);
+        stem_row(s_first, 0);
+        fetch_rows(iyA + 3); commit_rows(iyA + 3);                    // (row iyA + 3 again with iyA + 4: rows are committed in pairs)
+        stem_row(s_first + 1, 1024);
+    }
+    int snext = s_first + 2;                                          // next stem row to compute
+    fetch_rows(2 * snext - p.pad_t + 1);                              // its two new input rows (the first was committed already)
+    int yrow = oy_b * p.Wo * C * 2;
+    const int ypitch = p.Wo * C * 2;
+    int oy = oy_b;
+    auto step = [&](auto PHC) {
+        constexpr int PH = decltype(PHC)::value;                      // ring slot of stem row oy - 1
+        const int iyn = 2 * snext - p.pad_t + 1;
+        commit_rows(iyn);
+        stem_row(snext, ((PH + 2) % 3) * 1024);
+        ++snext;
+        fetch_rows(2 * snext - p.pad_t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        int hsel = hi;
+        asm volatile("" : "+v"(hsel));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            f32x4 acc[2] = {t2v[j], t2v[j]};
+#pragma unroll
+            for (int pr = 0; pr < 5; ++pr) {
+                unsigned bits = abits[j][pr];
+                asm volatile("" : "+v"(bits));        // expand the diagonal operand at use: NJ x 5 hoisted fragments would spill
+                const u32x4 fr = {dq == 0 ? bits : 0u, dq == 1 ? bits : 0u, dq == 2 ? bits : 0u, dq == 3 ? bits : 0u};
+                Frag<T> af; af.v = __builtin_bit_cast(bf16x8, fr);
+                const int ta = 2 * pr, tb = 2 * pr + 1 < 9 ? 2 * pr + 1 : 0;
+                const int offa = ((PH + ta / 3) % 3) * 1024 + (ta % 3) * 32, offb = ((PH + tb / 3) % 3) * 1024 + (tb % 3) * 32;
+                const int off = (hsel ? offb : offa) + j * SR_RING;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) mma_chunk(af, ld_frag<T>(dl[u] + off), acc[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const f32x4 ov = silu4r(acc[u]);
+                const float vm = yoff[u] == OOB ? 0.f : 1.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pl[j][r] += ov[r] * vm;
+                typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+                typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+                const bf16x4_ ob = {(bf16_t)ov[0], (bf16_t)ov[1], (bf16_t)ov[2], (bf16_t)ov[3]};
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, ob), yrs, yoff[u] == OOB ? OOB : yoff[u] + 32 * j, yrow, 0);
+            }
+        }
+        yrow += ypitch;
+        ++oy;
+    };
+#pragma unroll 1
+    while (oy < oy_e) {
+        step(IntS<0>{});
+        if (oy < oy_e) step(IntS<1>{});
+        if (oy < oy_e) step(IntS<2>{});
+    }
+    if (p.pool_partial != nullptr) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = pl[j][r];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                pl[j][r] = v;
+            }
+            if (frow == 0) {
+                float* dst = p.pool_partial + ((long long)b * (p.nstrips * p.nbands) + band * p.nstrips + strip) * C + 16 * j + 4 * kg;
+                *reinterpret_cast<f32x4*>(dst) = f32x4{pl[j][0], pl[j][1], pl[j][2], pl[j][3]};
+            }
+        }
+    }
+}
+
+struct SrGeometry { bool use; int TWo, nstrips, band_rows, nbands, wpg, per_image; size_t lds; };
+
+// map sizes only (never the batch): an image's result is the same at every batch size
+SrGeometry pick_stem_roll(int H, int W, int C) {
+    SrGeometry g{};
+    g.use = false;
+    if (C != 32) return g;                                            // 2 channel tiles (b0 .. b2 stems); wider stems spill at 128 registers
+    if (same_pad_before(W, 3, 2) % 2) return g;                       // the 16-byte operand reads need an even left pad
+    const int Ho = same_out(H, 2), Wo = same_out(W, 2);
+    if (Wo < 16 || Ho < 8) return g;
+    g.nstrips = (Wo + SR_TW - 1) / SR_TW;
+    g.TWo = (Wo + g.nstrips - 1) / g.nstrips;
+    g.nbands = Ho / 20 > 0 ? Ho / 20 : 1;                           // ~20-row bands: enough waves to fill the chip several times over
+    g.band_rows = (Ho + g.nbands - 1) / g.nbands;
+    g.nbands = (Ho + g.band_rows - 1) / g.band_rows;
+    g.wpg = 4;
+    g.per_image = (g.nstrips * g.nbands + g.wpg - 1) / g.wpg;
+    g.lds = (size_t)g.wpg * (4 * SR_IROW + (C / 16) * SR_RING);
+    g.use = true;
+    return g;
+}
+
+}  // namespace
+
+int effdet_stem_roll_parts(int H, int W, int C) {
+    const SrGeometry g = pick_stem_roll(H, W, C);
+    return g.use ? g.nstrips * g.nbands : 0;
+}
+
+int effdet_stem_roll_launch(hipStream_t st, int in_dtype, const void* X, const float* mean, const float* stdv, const void* Wk,
+                            const float* s1, const float* t1, const float* taps, const float* s2, const float* t2,
+                            void* Y, float* pool_partial, int B, int H, int W, int C) {
+    const SrGeometry g = pick_stem_roll(H, W, C);
+    if (!g.use) return EFFDET_EINVAL;
+    SrArgs a;
+    a.X = X; a.Wk = Wk;
+    for (int i = 0; i < 3; ++i) { a.nmean[i] = in_dtype == 2 ? mean[i] : 0.f; a.nstd[i] = in_dtype == 2 ? stdv[i] : 1.f; }
+    a.s1 = s1; a.t1 = t1; a.taps = taps; a.s2 = s2; a.t2 = t2; a.Y = Y; a.pool_partial = pool_partial;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.Ho = same_out(H, 2); a.Wo = same_out(W, 2);
+    a.pad_t = same_pad_before(H, 3, 2); a.pad_l = same_pad_before(W, 3, 2);
+    a.TWo = g.TWo; a.nstrips = g.nstrips; a.band_rows = g.band_rows; a.nbands = g.nbands; a.wpg = g.wpg; a.per_image = g.per_image;
+    void (*kern)(SrArgs) = nullptr;
+    const int nj = C / 16;
+#define SR_PICK(IN_) (nj == 2 ? stem_roll_kernel<IN_, 2> : nullptr)
+    kern = in_dtype == 0 ? SR_PICK(0) : in_dtype == 1 ? SR_PICK(1) : SR_PICK(2);
+#undef SR_PICK
+    if (kern == nullptr) return EFFDET_EINVAL;
+    const int rounds = (B + 7) / 8;
+    hipLaunchKernelGGL(kern, dim3(rounds * g.per_image * 8), dim3(g.wpg * 64), g.lds, st, a);
+    return effdet_check_launch();
+}

@@ -147,7 +147,7 @@ class Engine(object):
                         nblk = lib.effdet_dwconv_blocks_per_image(ho, wo, b['mid'])
                         exp_max = max(exp_max, B * h * w * b['mid'])
                 else:
-                    nblk = max(lib.effdet_dwconv_blocks_per_image(ho, wo, b['mid']), lib.effdet_stem_dw_tiles_per_image(H, W))
+                    nblk = max(lib.effdet_dwconv_blocks_per_image(ho, wo, b['mid']), lib.effdet_stem_dw_parts(dt, H, W, stem_c))
                 if nblk <= 0:
                     raise NotImplementedError('block geometry (mid=%d) is outside the built range' % b['mid'])
                 part_max = max(part_max, B * nblk * b['mid'])
@@ -263,7 +263,7 @@ class Engine(object):
                                           flops=2 * b['k'] * b['k'] * B * ho * wo * b['mid'])))
                     pw_out, bn_out = m.conv_pwl, m.bn3
                 elif si == 0 and bi == 0 and self._fuse_stem:
-                    nblk = lib.effdet_stem_dw_tiles_per_image(H, W)       # launched by run_backbone (takes x)
+                    nblk = lib.effdet_stem_dw_parts(dt, H, W, stem_c)     # launched by run_backbone (takes x)
                     pw_out, bn_out = m.conv_pw, m.bn2
                     mid_buf = dbuf
                 else:

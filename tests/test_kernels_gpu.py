@@ -176,7 +176,7 @@ def test_mbconv_expand_dw_gated(dtype, Cin, mid, H, W, k, s):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('C,H,W', [(32, 64, 96), (48, 70, 38), (40, 34, 34), (32, 33, 35)])   # last: odd width -> scalar patch load
+@pytest.mark.parametrize('C,H,W', [(32, 64, 96), (48, 70, 38), (40, 34, 34), (32, 33, 35), (32, 100, 172), (32, 37, 64)])   # (32, 33, 35): odd width -> scalar patch load
 def test_stem_dw_fused(dtype, C, H, W):
     """conv_stem + BN + SiLU -> depthwise 3x3 + BN + SiLU (+ pool partials) in one launch vs the oracle ops"""
     import _hip
@@ -195,7 +195,7 @@ def test_stem_dw_fused(dtype, C, H, W):
     Ho, Wo = ref.shape[2], ref.shape[3]
     wk = torch.zeros(C, 32)
     wk[:, :27] = w.float().permute(0, 2, 3, 1).reshape(C, 27)
-    nt = lib.effdet_stem_dw_tiles_per_image(H, W)
+    nt = lib.effdet_stem_dw_parts(_hip.DT[dtype], H, W, C)       # bf16 with C = 32 and an even left pad: the rolling-window form
     y = torch.empty(B, Ho, Wo, C, dtype=dtype, device=DEV)
     part = torch.full((B, nt, C), float('nan'), dtype=torch.float32, device=DEV)
     dv = [t.contiguous().to(DEV) for t in (wk.to(dtype), s1, t1, wd.permute(2, 3, 0, 1).reshape(9, C), s2, t2)]
