@@ -143,8 +143,8 @@ DEV void store_piece(T* dst, const float (&v)[8], int nvalid, bool vec_ok) {
 }
 
 // FT: the channel count when known at compile time (all index arithmetic folds), 0 = read it from the arguments
-template <typename T, int TH, int TW, int BN, bool OOD, int NTH, int FT, bool META = false>
-__global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void sepconv_kernel(SepArgs p) {
+template <typename T, int TH, int TW, int BN, bool OOD, int NTH, int FT, bool META = false, int NIN = 3>
+__global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META ? 8 : 4) : 2) void sepconv_kernel(SepArgs p) {
     constexpr int BM = TH * TW;
     constexpr int HW_ = (TH + 2) * (TW + 2);
     constexpr int NWAVE = NTH / 64;
@@ -164,11 +164,15 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void sepconv_kernel(SepArg
     constexpr bool MF = sizeof(T) == 2 && TW == 16 && NTH == 512;
     constexpr int HROW = FC + (MF ? 8 : 0);          // halo row pitch in elements
     constexpr int HALO_BYTES = HW_ * HROW * (int)sizeof(T);
-    const int r0 = HALO_BYTES > BN * arow ? HALO_BYTES : BN * arow;
+    // 64-channel layers (one halo pass): the depthwise output waits in registers until every wave has read the halo and
+    // then overwrites it, with the W chunk behind it -> 30 KB instead of 47 KB per workgroup, four workgroups per CU
+    constexpr bool CP = MF && FT == 64 && !META;
+    const int r0 = CP ? (HALO_BYTES > (BM + BN) * arow ? HALO_BYTES : (BM + BN) * arow)
+                      : (HALO_BYTES > BN * arow ? HALO_BYTES : BN * arow);
     char* halo = lds;
-    char* Wt = lds;
-    char* At = lds + r0;
-    float* dww = reinterpret_cast<float*>(At + BM * arow);   // [9][F]
+    char* Wt = CP ? lds + BM * arow : lds;
+    char* At = CP ? lds : lds + r0;
+    float* dww = reinterpret_cast<float*>(CP ? lds + r0 : At + BM * arow);   // [9][F]
     float* cs = dww + 9 * F;                                  // [2][BN] scale | shift of the current chunk
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -214,9 +218,11 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void sepconv_kernel(SepArg
         __syncthreads();
         // HU halo items per step: their input loads are all issued before the first use (the loop has a runtime
         // trip count, so the compiler would otherwise expose one memory round trip per item)
-        constexpr int HU = NTH == 512 ? 3 : 2;              // bf16 tile: all 1440 items of a 64-channel pass in one batch
+        // bf16 tile: all 1440 items of a 64-channel pass in one batch; the 64-register variant (four workgroups per CU) keeps two
+        // batches when a node fuses several inputs
+        constexpr int HU = NTH == 512 ? ((FT == 64 && !OOD && !META && NIN > 1) ? 2 : 3) : 2;
         for (int it0 = tid; it0 < HW_ * fcg; it0 += HU * NTH) {
-            Raw8<T> xin[HU][3];
+            Raw8<T> xin[HU][NIN];
             bool ok[HU];
 #pragma unroll
             for (int u = 0; u < HU; ++u) {
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void sepconv_kernel(SepArg
                 if (ok[u]) {
                     const int c = fc0 + cgh * 8;
 #pragma unroll
-                    for (int i = 0; i < 3; ++i)
+                    for (int i = 0; i < NIN; ++i)
                         if (i < p.n_in) xin[u][i] = fetch_input<T>(ib[i], L.in[i], y, x, F, c);
                 }
             }
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void sepconv_kernel(SepArg
                         v = unpack8<T>(xin[u][0]);
                     } else {
 #pragma unroll
-                        for (int i = 0; i < 3; ++i) {
+                        for (int i = 0; i < NIN; ++i) {
                             if (i < p.n_in) {
                                 const F8 xi = unpack8<T>(xin[u][i]);
                                 if (divide) {
@@ -289,6 +295,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void sepconv_kernel(SepArg
             // by those taps; the accumulator (4 channels x 1 pixel per lane) goes straight into the A tile.
             const int frow_ = lane & 15, fp_ = lane >> 4;
             const int j = wave & 3, part = wave >> 2;
+            f32x4 keep[CP ? TH / 2 : 1];
             if (16 * j < fcn) {
                 const int hi = fp_ >> 1;
                 const bool active = (fp_ & 1) == (frow_ >> 3);
@@ -316,8 +323,19 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void sepconv_kernel(SepArg
                         const int off = hi ? (t1 / 3) * RB + (t1 % 3) * CB : (t0 / 3) * RB + (t0 % 3) * CB;
                         mma_chunk(afr[pr], ld_frag<T>(base + off), acc);
                     }
-                    if (16 * j + 4 * fp_ < fcn)
+                    if constexpr (CP) keep[pt] = acc;
+                    else if (16 * j + 4 * fp_ < fcn)
                         store4<T>(reinterpret_cast<T*>(At + (16 * ty + frow_) * arow) + fc0 + 16 * j + 4 * fp_, acc[0], acc[1], acc[2], acc[3]);
+                }
+            }
+            if constexpr (CP) {
+                __syncthreads();                                     // every wave has read its halo rows: the A tile may overwrite them
+                if (16 * j < fcn) {
+#pragma unroll
+                    for (int pt = 0; pt < TH / 2; ++pt) {
+                        const int ty = part * (TH / 2) + pt;
+                        store4<T>(reinterpret_cast<T*>(At + (16 * ty + frow_) * arow) + fc0 + 16 * j + 4 * fp_, keep[pt][0], keep[pt][1], keep[pt][2], keep[pt][3]);
+                    }
                 }
             }
         } else {
@@ -584,17 +602,18 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2) void sepconv_kernel(SepArg
 }
 
 template <typename T, int TH, int TW, int BN>
-size_t sep_lds_bytes(int F) {
+size_t sep_lds_bytes(int F, bool cp = false) {
     constexpr int BM = TH * TW;
     constexpr int HW_ = (TH + 2) * (TW + 2);
     const int nkc = (F * (int)sizeof(T) + 63) / 64;
     const int arow = nkc * 64 + 16;
     const size_t halo = (size_t)HW_ * (FC + (sizeof(T) == 2 && TW == 16 ? 8 : 0)) * sizeof(T);
     const size_t wt = (size_t)BN * arow;
+    if (cp) return (halo > wt + (size_t)BM * arow ? halo : wt + (size_t)BM * arow) + (size_t)9 * F * 4 + (size_t)2 * BN * 4;
     return (halo > wt ? halo : wt) + (size_t)BM * arow + (size_t)9 * F * 4 + (size_t)2 * BN * 4;
 }
 
-template <typename T, int TH, int TW, int BN, bool OOD, int NTH, int FT, bool META = false>
+template <typename T, int TH, int TW, int BN, bool OOD, int NTH, int FT, bool META = false, int NIN = 3>
 int launch_sep(hipStream_t st, SepArgs& a, int B) {
     int tiles = 0;
     for (int i = 0; i < a.nlevels; ++i) {
@@ -603,10 +622,10 @@ int launch_sep(hipStream_t st, SepArgs& a, int B) {
         a.lv[i].tile_begin = tiles;
         tiles += a.lv[i].tiles_x * a.lv[i].tiles_y;
     }
-    const size_t lds = sep_lds_bytes<T, TH, TW, BN>(a.F) + (META ? (size_t)(NTH / 64) * 2 * BN * 4 : 0);   // + statistics scratch
+    const size_t lds = sep_lds_bytes<T, TH, TW, BN>(a.F, sizeof(T) == 2 && TW == 16 && NTH == 512 && FT == 64 && !META) + (META ? (size_t)(NTH / 64) * 2 * BN * 4 : 0);   // + statistics scratch
     if (lds > 160 * 1024) return EFFDET_EINVAL;
     a.tiles_total = tiles;
-    auto kern = sepconv_kernel<T, TH, TW, BN, OOD, NTH, FT, META>;
+    auto kern = sepconv_kernel<T, TH, TW, BN, OOD, NTH, FT, META, NIN>;
     if (lds > 64 * 1024) {
         static bool attr_done = false;           // one per template instantiation
         if (!attr_done) {
@@ -621,7 +640,10 @@ int launch_sep(hipStream_t st, SepArgs& a, int B) {
 
 template <typename T, int TH, int TW, int NTH, int FT>
 int dispatch_sep_f(hipStream_t st, SepArgs& a, int B) {
-    return a.ood_classes > 0 ? launch_sep<T, TH, TW, 96, true, NTH, FT>(st, a, B) : launch_sep<T, TH, TW, 64, false, NTH, FT>(st, a, B);
+    if (a.ood_classes > 0) return launch_sep<T, TH, TW, 96, true, NTH, FT>(st, a, B);
+    // head layers read one input: a variant without the registers of the other two
+    if (FT == 64 && a.n_in == 1) return launch_sep<T, TH, TW, 64, false, NTH, FT, false, 1>(st, a, B);
+    return launch_sep<T, TH, TW, 64, false, NTH, FT>(st, a, B);
 }
 
 // the BiFPN widths of tf_efficientdet_d0..d4 get compile-time channel counts; anything else the generic kernel

@@ -45,18 +45,29 @@ DEV void st_f(void* p, int dtype, long long i, float v) {
     if (dtype == 0) reinterpret_cast<float*>(p)[i] = v; else reinterpret_cast<bf16_t*>(p)[i] = (bf16_t)v;
 }
 
+constexpr int LE = 16;                  // elements per thread: a block reduces LE * LT elements to one partial
+
 __global__ __launch_bounds__(LT) void loss_kernel(LossArgs p) {
     __shared__ float sm[4];
-    float norm = 1.0f;
-    for (int b = 0; b < p.B; ++b) norm += p.num_pos[b];          // sum(num_positives) + 1, same order everywhere
+    __shared__ float s_norm;
+    if (threadIdx.x == 0) {
+        float n = 1.0f;
+        for (int b = 0; b < p.B; ++b) n += p.num_pos[b];          // sum(num_positives) + 1, same order everywhere
+        s_norm = n;
+    }
+    __syncthreads();
+    const float norm = s_norm;
     const long long blk = blockIdx.x;
     float acc = 0.f;
     if (blk < p.ncls_blocks) {
         const long long total = (long long)p.B * p.N * p.C;
-        const long long i = blk * LT + threadIdx.x;
-        if (i < total) {
+        const float inv_norm = 1.0f / norm;
+#pragma unroll 4
+        for (int e = 0; e < LE; ++e) {
+            const long long i = (blk * LE + e) * LT + threadIdx.x;
+            if (i >= total) break;
             const long long bn = i / p.C;
-            const int c = (int)(i % p.C);
+            const int c = (int)(i - bn * p.C);
             const long long t = p.cls_t[bn];
             const float x = ld_f(p.cls, p.dtype, i);
             const float hot = (t == c) ? 1.0f : 0.0f;
@@ -64,10 +75,10 @@ __global__ __launch_bounds__(LT) void loss_kernel(LossArgs p) {
             const float ts = p.ls > 0.f ? hot * (1.0f - p.ls) + 0.5f * p.ls : hot;
             const float ce = fmaxf(x, 0.f) - x * ts + log1pf(expf(-fabsf(x)));
             const float mask = (t != -2) ? 1.0f : 0.0f;
-            acc = (1.0f / norm) * alpha_f * ce * mask;
+            acc += inv_norm * alpha_f * ce * mask;
             if (p.gcls) {
                 const float sg = 1.0f / (1.0f + expf(-x));
-                st_f(p.gcls, p.dtype, i, (1.0f / norm) * alpha_f * (sg - ts) * mask);
+                st_f(p.gcls, p.dtype, i, inv_norm * alpha_f * (sg - ts) * mask);
             }
         }
         const float s = block_sum(acc, sm);
@@ -75,9 +86,11 @@ __global__ __launch_bounds__(LT) void loss_kernel(LossArgs p) {
     } else {
         const long long bb = blk - p.ncls_blocks;
         const long long total = (long long)p.B * p.N * 4;
-        const long long i = bb * LT + threadIdx.x;
         const float bnorm = norm * 4.0f;
-        if (i < total) {
+#pragma unroll 4
+        for (int e = 0; e < LE; ++e) {
+            const long long i = (bb * LE + e) * LT + threadIdx.x;
+            if (i >= total) break;
             const float t = p.box_t[i];
             const float x = ld_f(p.box, p.dtype, i);
             const float w = (t != 0.0f) ? 1.0f : 0.0f;
@@ -85,7 +98,7 @@ __global__ __launch_bounds__(LT) void loss_kernel(LossArgs p) {
             const float a = fabsf(err);
             const float q = fminf(a, p.delta);
             const float lin = a - q;
-            acc = (0.5f * q * q + p.delta * lin) * w;
+            acc += (0.5f * q * q + p.delta * lin) * w;
             if (p.gbox) {
                 const float g = (a <= p.delta) ? err : (err > 0.f ? p.delta : -p.delta);
                 st_f(p.gbox, p.dtype, i, p.box_w * g * w / bnorm);
@@ -96,16 +109,22 @@ __global__ __launch_bounds__(LT) void loss_kernel(LossArgs p) {
     }
 }
 
-__global__ __launch_bounds__(LT) void loss_finish_kernel(LossArgs p, float* out3) {
-    __shared__ float sm[4];
+// fixed-order final sum of the per-block partials: 1024 threads stride over them, then a tree through LDS
+__global__ __launch_bounds__(1024) void loss_finish_kernel(LossArgs p, float* out3) {
+    __shared__ float smc[1024], smb[1024];
     float norm = 1.0f;
     for (int b = 0; b < p.B; ++b) norm += p.num_pos[b];
     float c = 0.f, bx = 0.f;
-    for (long long i = threadIdx.x; i < p.ncls_blocks; i += LT) c += p.partial[i];
-    for (long long i = threadIdx.x; i < p.nbox_blocks; i += LT) bx += p.partial[p.ncls_blocks + i];
-    const float cs = block_sum(c, sm);
-    const float bs = block_sum(bx, sm);
+    for (long long i = threadIdx.x; i < p.ncls_blocks; i += 1024) c += p.partial[i];
+    for (long long i = threadIdx.x; i < p.nbox_blocks; i += 1024) bx += p.partial[p.ncls_blocks + i];
+    smc[threadIdx.x] = c; smb[threadIdx.x] = bx;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { smc[threadIdx.x] += smc[threadIdx.x + o]; smb[threadIdx.x] += smb[threadIdx.x + o]; }
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
+        const float cs = smc[0], bs = smb[0];
         const float box_loss = bs / (norm * 4.0f);
         out3[1] = cs; out3[2] = box_loss; out3[0] = cs + p.box_w * box_loss;
     }
@@ -239,7 +258,8 @@ __global__ __launch_bounds__(LT) void label_targets_kernel(LabelArgs p) {
 
 extern "C" long long effdet_detection_loss_workspace_floats(int B, long long N, int C) {
     if (B <= 0 || N <= 0 || C <= 0) return EFFDET_EINVAL;
-    const long long ncls = ((long long)B * N * C + LT - 1) / LT, nbox = ((long long)B * N * 4 + LT - 1) / LT;
+    const long long per = (long long)LT * LE;
+    const long long ncls = ((long long)B * N * C + per - 1) / per, nbox = ((long long)B * N * 4 + per - 1) / per;
     return ncls + nbox;
 }
 
@@ -254,12 +274,12 @@ extern "C" int effdet_detection_loss(void* stream, int dtype, const void* cls, c
     if (need <= 0 || workspace_floats < need) return EFFDET_EINVAL;
     LossArgs a{cls, box, dtype, cls_t, box_t, num_positives, B, N, C, alpha, delta, box_loss_weight, label_smoothing,
                grad_cls, grad_box, workspace, 0, 0};
-    a.ncls_blocks = ((long long)B * N * C + LT - 1) / LT;
-    a.nbox_blocks = ((long long)B * N * 4 + LT - 1) / LT;
+    a.ncls_blocks = ((long long)B * N * C + (long long)LT * LE - 1) / ((long long)LT * LE);
+    a.nbox_blocks = ((long long)B * N * 4 + (long long)LT * LE - 1) / ((long long)LT * LE);
     if (a.ncls_blocks + a.nbox_blocks > 0x7fffffffLL) return EFFDET_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(loss_kernel, dim3((unsigned)(a.ncls_blocks + a.nbox_blocks)), dim3(LT), 0, st, a);
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(LT), 0, st, a, out3);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, st, a, out3);
     return effdet_check_launch();
 }
 
