@@ -9,7 +9,7 @@ per-launch profiling pass = 16 dispatches per launch site)."""
 import json, sys
 
 FAMILIES = {'mbconv': ('mbconv_front_kernel', 'mbconv_deep_kernel', 'mbconv_roll_kernel'), 'sepconv': ('sepconv_kernel',),
-            'pw_gemm': ('pw_gemm_kernel',), 'stem_dw': ('stem_dw_kernel',), 'se_gate': ('se_gate_kernel',),
+            'pw_gemm': ('pw_gemm_kernel',), 'stem_dw': ('stem_dw_kernel', 'stem_roll_kernel'), 'se_gate': ('se_gate_kernel',),
             'topk': ('topk_', 'anchor_collect', 'pair_finish', 'row_max'), 'nms': ('nms_', 'decode_threshold', 'gather_ood')}
 
 
@@ -50,7 +50,7 @@ def main():
     fetch, write, forwards, dst = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     workload = sys.argv[5] if len(sys.argv) > 5 else ''
     if forwards <= 0:
-        forwards = calls_of(fetch, 'stem_dw_kernel') or calls_of(fetch, 'stem_conv')
+        forwards = calls_of(fetch, 'stem_roll_kernel') or calls_of(fetch, 'stem_dw_kernel') or calls_of(fetch, 'stem_conv')
     rd, wr = pmc_section(fetch, 'FETCH_SIZE'), pmc_section(write, 'WRITE_SIZE')
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
