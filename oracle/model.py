@@ -328,8 +328,9 @@ def meta_head_forward(conv_dw_rep, conv_pw_rep, conv_pb_rep, bn_rep_w, bn_rep_b,
                       predict_class=None, eps=1e-5):
     """MetaHead.forward (effdet/efficientdet.py:636-695) with explicit weight lists in the reference's order
     (bn lists are level-major: index level * num_layers + rep).  Returns (outputs, x_pred activations[, class_outputs]).
-    Parity unpinned: the reference class allocates CUDA buffers in __init__ and cannot be instantiated in the CPU
-    container; this is a line-by-line restatement of its forward."""
+    Pinned: tools/make_golden.py instantiates the reference class on the CPU (its `.to('cuda')` calls neutralised in that
+    script only) and tests/golden/meta_nets.npz holds its outputs; tests/test_oracle_golden.py checks this restatement
+    against them."""
     num_layers = len(conv_dw_rep)
     outputs, activs, class_outputs = [], [], []
     for level in range(level_offset, len(x)):
@@ -353,8 +354,8 @@ def meta_head_forward(conv_dw_rep, conv_pw_rep, conv_pb_rep, bn_rep_w, bn_rep_b,
 
 def anchor_net_forward(sd, x, num_levels, eps=1e-3, prefix=''):
     """AnchorNet.forward (effdet/efficientdet.py:817-830) from a state dict: per level conv_rep[i] (SeparableConv, TF-SAME
-    3x3 = symmetric pad 1) -> bn_rep[i][level] (eval) -> Swish, then anchor_out.  Parity unpinned (FLAGS-driven
-    constructor; restated from the forward)."""
+    3x3 = symmetric pad 1) -> bn_rep[i][level] (eval) -> Swish, then anchor_out.  Pinned by tests/golden/meta_nets.npz (reference
+    AnchorNet run by tools/make_golden.py with the absl stub supplying its FLAGS)."""
     outs = []
     n_rep = len({k.split('.')[1] for k in sd if k.startswith(prefix + 'conv_rep.')})
     for level in range(len(x)):
