@@ -40,12 +40,17 @@ struct GemmNtArgs {
     float* C2;                                 // optional second output with the row map of C: silu(C)
 };
 
-template <bool VEC>
+// VW: widest aligned load the rows allow (4 = 16 bytes, 2 = 8 bytes: e.g. the 810-channel class head, 1 = scalar)
+template <int VW>
 DEV Frag<float> ld_k4(const float* row, int k, int K) {
     Frag<float> f;
-    if constexpr (VEC) {
+    if constexpr (VW == 4) {
         if (k + 3 < K) f.v = *reinterpret_cast<const f32x4*>(row + k);
         else f.v = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else if constexpr (VW == 2) {
+        const f32x2 lo = (k + 1 < K) ? *reinterpret_cast<const f32x2*>(row + k) : f32x2{0.f, 0.f};
+        const f32x2 hi = (k + 3 < K) ? *reinterpret_cast<const f32x2*>(row + k + 2) : f32x2{0.f, 0.f};
+        f.v = f32x4{lo[0], lo[1], hi[0], hi[1]};
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) f.v[i] = (k + i < K) ? row[k + i] : 0.f;
@@ -53,7 +58,7 @@ DEV Frag<float> ld_k4(const float* row, int k, int K) {
     return f;
 }
 
-template <bool VEC>
+template <int VEC>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
@@ -127,7 +132,7 @@ struct GemmTnArgs {
 
 // 32 rows of dY [32 n] and X [64 k] per step are staged in LDS with 16-byte global loads (rows padded to 48 / 80 floats:
 // the two 16-lane groups of a half-wave land on disjoint banks), then every wave feeds 8 of those rows to the matrix cores.
-template <bool VY, bool VX>
+template <int VY, bool VX>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
     constexpr int RT = 32, SY = 48, SX = 80;
     __shared__ float sY[RT * SY];
@@ -154,8 +159,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
             if (m < me) {
                 const float* row = p.dY + row_off(p.ym, m);
                 const int n = n0 + yc;
-                if (VY && n + 3 < p.N) vy = *reinterpret_cast<const f32x4*>(row + n);
-                else {
+                if (VY == 4 && n + 3 < p.N) vy = *reinterpret_cast<const f32x4*>(row + n);
+                else if (VY == 2 && n + 1 < p.N) {                  // rows are 8-byte aligned (N even): two half-width loads
+                    const f32x2 lo = *reinterpret_cast<const f32x2*>(row + n);
+                    const f32x2 hi = n + 3 < p.N ? *reinterpret_cast<const f32x2*>(row + n + 2) : f32x2{0.f, 0.f};
+                    vy = f32x4{lo[0], lo[1], hi[0], hi[1]};
+                } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) vy[e] = n + e < p.N ? row[n + e] : 0.f;
                 }
@@ -772,8 +781,11 @@ extern "C" int effdet_train_gemm_nt(void* stream, const float* A, long long a_rp
                 (C2 == nullptr || reinterpret_cast<uintptr_t>(C2) % 16 == 0);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)gx, (unsigned)((N + 63) / 64));
-    if (vec) hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(256), 0, st, p);
+    const bool vec2 = K % 2 == 0 && p.am.ld % 2 == 0 && p.am.img_stride % 2 == 0 &&
+                      reinterpret_cast<uintptr_t>(A) % 8 == 0 && reinterpret_cast<uintptr_t>(W) % 8 == 0;
+    if (vec) hipLaunchKernelGGL(gemm_nt_kernel<4>, grid, dim3(256), 0, st, p);
+    else if (vec2) hipLaunchKernelGGL(gemm_nt_kernel<2>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, dim3(256), 0, st, p);
     return effdet_check_launch();
 }
 
@@ -812,10 +824,14 @@ extern "C" int effdet_train_gemm_tn(void* stream, const float* dY, long long y_r
     const dim3 grid((unsigned)((N + 31) / 32), (unsigned)((K + 1 + 63) / 64), (unsigned)S);
     const bool vy = p.ym.ld % 4 == 0 && p.ym.img_stride % 4 == 0 && reinterpret_cast<uintptr_t>(dY) % 16 == 0;
     const bool vx = p.xm.ld % 4 == 0 && p.xm.img_stride % 4 == 0 && reinterpret_cast<uintptr_t>(X) % 16 == 0;
-    if (vy && vx) hipLaunchKernelGGL((gemm_tn_kernel<true, true>), grid, dim3(256), 0, st, p);
-    else if (vx) hipLaunchKernelGGL((gemm_tn_kernel<false, true>), grid, dim3(256), 0, st, p);
-    else if (vy) hipLaunchKernelGGL((gemm_tn_kernel<true, false>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_tn_kernel<false, false>), grid, dim3(256), 0, st, p);
+    const bool vy2 = N % 2 == 0 && p.ym.ld % 2 == 0 && p.ym.img_stride % 2 == 0 && reinterpret_cast<uintptr_t>(dY) % 8 == 0;
+    if (vy && vx) hipLaunchKernelGGL((gemm_tn_kernel<4, true>), grid, dim3(256), 0, st, p);
+    else if (vx) {
+        if (vy2) hipLaunchKernelGGL((gemm_tn_kernel<2, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_tn_kernel<1, true>), grid, dim3(256), 0, st, p);
+    }
+    else if (vy) hipLaunchKernelGGL((gemm_tn_kernel<4, false>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_tn_kernel<1, false>), grid, dim3(256), 0, st, p);
     int rc = effdet_check_launch();
     if (rc) return rc;
     ReduceSplitArgs r{workspace, out, N, K, S};
