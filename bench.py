@@ -196,11 +196,15 @@ def parity_bf16(model_f32_cpu, x_cpu, dev, soft_nms=False):
 
 
 def kernels_sha16():
-    """content hash of the kernel sources: ties committed PMC traffic files to the kernels they were measured on"""
+    """content hash of the inference kernel sources: ties committed PMC traffic files to the kernels they were measured on
+    (the training-only translation units do not run in this bench and are left out)"""
     import glob, hashlib
     h = hashlib.sha256()
     root = os.path.join(ROOT, 'ood_object_detection_amd', 'csrc')
+    skip = ('train_ops.hip', 'train_net.hip', 'evaluation.hip')
     for f in sorted(glob.glob(os.path.join(root, '*.hip')) + glob.glob(os.path.join(root, '*.h'))):
+        if os.path.basename(f) in skip:
+            continue
         h.update(os.path.basename(f).encode())
         h.update(open(f, 'rb').read())
     return h.hexdigest()[:16]
