@@ -58,17 +58,26 @@ DEV Frag<float> ld_k4(const float* row, int k, int K) {
     return f;
 }
 
+// A wave owns 32 rows x 64 columns: every W fragment it fetches feeds two row tiles, and the fragments of the next 16 k are
+// requested before the current ones go to the matrix cores (the loop has a runtime trip count; without the explicit
+// double buffer every step would expose one L2 round trip).  The k order per output element is unchanged: sequential.
 template <int VEC>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
+    constexpr int RT = 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
-    const long long m0 = ((long long)blockIdx.x * 4 + wave) * 16;
+    const long long m0 = ((long long)blockIdx.x * 4 + wave) * (16 * RT);
     const int n0 = blockIdx.y * 64;
     if (m0 >= p.M) return;                                   // wave-uniform, no barriers in this kernel
-    long long m = m0 + r16;
-    const bool mv = m < p.M;
-    if (!mv) m = p.M - 1;
-    const float* arow = p.A + row_off(p.am, m);
+    const float* arow[RT];
+    bool mv[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        long long m = m0 + 16 * i + r16;
+        mv[i] = m < p.M;
+        if (!mv[i]) m = p.M - 1;
+        arow[i] = p.A + row_off(p.am, m);
+    }
     const float* wrow[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -76,47 +85,64 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
         if (n >= p.N) n = p.N - 1;
         wrow[t] = p.W + (long long)n * p.K;
     }
-    f32x4 acc[4];
+    f32x4 acc[RT][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    Frag<float> bc[RT], ac[4];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) bc[i] = ld_k4<VEC>(arow[i], 4 * g, p.K);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) ac[t] = ld_k4<VEC>(wrow[t], 4 * g, p.K);
     for (int k0 = 0; k0 < p.K; k0 += 16) {
-        const int k = k0 + 4 * g;
-        const Frag<float> b = ld_k4<VEC>(arow, k, p.K);
-        Frag<float> a[4];
+        const int kn = k0 + 16 + 4 * g;                       // past the end of K: ld_k4 returns zeros without touching memory
+        Frag<float> bn[RT], an[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) a[t] = ld_k4<VEC>(wrow[t], k, p.K);
+        for (int i = 0; i < RT; ++i) bn[i] = ld_k4<VEC>(arow[i], kn, p.K);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) mma_chunk(a[t], b, acc[t]);
+        for (int t = 0; t < 4; ++t) an[t] = ld_k4<VEC>(wrow[t], kn, p.K);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < RT; ++i) mma_chunk(ac[t], bc[i], acc[i][t]);
+#pragma unroll
+        for (int i = 0; i < RT; ++i) bc[i] = bn[i];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) ac[t] = an[t];
     }
-    if (!mv) return;
-    const long long coff = row_off(p.cm, m0 + r16);
-    float* crow = p.C + coff;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int n = n0 + 16 * t + 4 * g;
-        if (p.vec_out) {                                     // N % 4 == 0 and 16-byte aligned rows: one store per lane and tile
-            if (n < p.N) {
-                f32x4 v = acc[t];
-                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                if (p.accumulate) v += *reinterpret_cast<const f32x4*>(crow + n);
-                *reinterpret_cast<f32x4*>(crow + n) = v;
-                if (p.C2) {
-                    f32x4 q;
+    for (int i = 0; i < RT; ++i) {
+        if (!mv[i]) continue;
+        const long long coff = row_off(p.cm, m0 + 16 * i + r16);
+        float* crow = p.C + coff;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) q[r] = silu_f(v[r]);
-                    *reinterpret_cast<f32x4*>(p.C2 + coff + n) = q;
+        for (int t = 0; t < 4; ++t) {
+            const int n = n0 + 16 * t + 4 * g;
+            if (p.vec_out) {                                     // N % 4 == 0 and 16-byte aligned rows: one store per lane and tile
+                if (n < p.N) {
+                    f32x4 v = acc[i][t];
+                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                    if (p.accumulate) v += *reinterpret_cast<const f32x4*>(crow + n);
+                    *reinterpret_cast<f32x4*>(crow + n) = v;
+                    if (p.C2) {
+                        f32x4 q;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) q[r] = silu_f(v[r]);
+                        *reinterpret_cast<f32x4*>(p.C2 + coff + n) = q;
+                    }
                 }
+                continue;
             }
-            continue;
-        }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (n + r < p.N) {
-                float v = acc[t][r];
-                if (p.bias) v += p.bias[n + r];
-                if (p.accumulate) v += crow[n + r];
-                crow[n + r] = v;
-                if (p.C2) p.C2[coff + n + r] = silu_f(v);
+            for (int r = 0; r < 4; ++r) {
+                if (n + r < p.N) {
+                    float v = acc[i][t][r];
+                    if (p.bias) v += p.bias[n + r];
+                    if (p.accumulate) v += crow[n + r];
+                    crow[n + r] = v;
+                    if (p.C2) p.C2[coff + n + r] = silu_f(v);
+                }
             }
         }
     }
@@ -152,15 +178,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
     const int Kx = p.K + 1;
     const int yr = tid >> 3, yc = (tid & 7) * 4;             // dY piece of this thread: row yr, columns yc..yc+3
     const int xr = tid >> 4, xc = (tid & 15) * 4;            // X pieces: rows xr and xr + 16, columns xc..xc+3
-    for (long long m0 = mb; m0 < me; m0 += RT) {
-        f32x4 vy = f32x4{0.f, 0.f, 0.f, 0.f}, vx[2];
+    f32x4 vy, vx[2];
+    auto fetch = [&](long long m0) {                          // 32 rows of dY / X -> registers (loads only)
+        vy = f32x4{0.f, 0.f, 0.f, 0.f};
         {
             const long long m = m0 + yr;
             if (m < me) {
                 const float* row = p.dY + row_off(p.ym, m);
                 const int n = n0 + yc;
                 if (VY == 4 && n + 3 < p.N) vy = *reinterpret_cast<const f32x4*>(row + n);
-                else if (VY == 2 && n + 1 < p.N) {                  // rows are 8-byte aligned (N even): two half-width loads
+                else if (VY == 2 && n + 1 < p.N) {              // rows are 8-byte aligned (N even): two half-width loads
                     const f32x2 lo = *reinterpret_cast<const f32x2*>(row + n);
                     const f32x2 hi = n + 3 < p.N ? *reinterpret_cast<const f32x2*>(row + n + 2) : f32x2{0.f, 0.f};
                     vy = f32x4{lo[0], lo[1], hi[0], hi[1]};
@@ -184,11 +211,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
                 }
             }
         }
+    };
+    fetch(mb);
+    for (long long m0 = mb; m0 < me; m0 += RT) {
         __syncthreads();                                      // the previous step's operands have been consumed
         *reinterpret_cast<f32x4*>(sY + yr * SY + yc) = vy;
         *reinterpret_cast<f32x4*>(sX + xr * SX + xc) = vx[0];
         *reinterpret_cast<f32x4*>(sX + (xr + 16) * SX + xc) = vx[1];
         __syncthreads();
+        if (m0 + RT < me) fetch(m0 + RT);                     // the next step's rows are in flight while this one is multiplied
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             const int r = 8 * wave + 4 * st + g;
@@ -772,7 +803,7 @@ extern "C" int effdet_train_gemm_nt(void* stream, const float* A, long long a_rp
     p.A = A; p.W = W; p.bias = bias; p.C = C; p.M = M; p.K = K; p.N = N; p.accumulate = accumulate; p.C2 = C2;
     p.am = make_rowmap(a_rpi, a_img_stride, a_ld, M, K);
     p.cm = make_rowmap(c_rpi, c_img_stride, c_ld, M, N);
-    const long long gx = (M + 63) / 64;
+    const long long gx = (M + 127) / 128;                    // 4 waves x 32 rows
     if (gx > 0x7fffffffLL) return EFFDET_EINVAL;
     const bool vec = K % 4 == 0 && p.am.ld % 4 == 0 && p.am.img_stride % 4 == 0 &&
                      reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(W) % 16 == 0;
