@@ -82,6 +82,12 @@ int effdet_pw_gemm_bn_act(void* stream, int dtype, const void* A, long long M, i
                           const float* scale, const float* shift, int act, const void* residual,
                           const float* gate, int rows_per_image,
                           void* C, long long c_image_stride, long long ldc);
+/* n <= 8 independent GEMMs of this form (no gate, no residual, dense [M][N] outputs) in ONE launch; every N must select the
+ * same output-channel tile (N <= 96).  The BiFPN's lateral 1x1 convs of the backbone features (ResampleFeatureMap.conv,
+ * effdet/efficientdet.py:155-158): six small problems that each fill a fraction of the chip. */
+int effdet_pw_gemm_group(void* stream, int dtype, int n, const void* const* A, const long long* M, const int* K,
+                         const void* const* W, const int* N, const float* const* scale, const float* const* shift,
+                         int act, void* const* C);
 
 /* depthwise k x k (k = 3|5, stride 1|2, TF-SAME) + folded BN + SiLU.  Wt: [k*k][C] fp32.
  * If pool_partial != NULL it receives [B][effdet_dwconv_blocks_per_image(Ho,Wo,C)][C] partial sums of

@@ -34,6 +34,8 @@ SIGNATURES = {
     'effdet_stem_dw_parts': (c_int, [c_int, c_int, c_int, c_int]),
     'effdet_pw_gemm_bn_act': (c_int, [c_void_p, c_int, c_void_p, c_ll, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                       c_int, c_void_p, c_void_p, c_int, c_void_p, c_ll, c_ll]),
+    'effdet_pw_gemm_group': (c_int, [c_void_p, c_int, c_int, P(c_void_p), P(c_ll), P(c_int), P(c_void_p), P(c_int), P(c_void_p),
+                                     P(c_void_p), c_int, P(c_void_p)]),
     'effdet_dwconv_bn_act': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                      c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
     'effdet_dwconv_blocks_per_image': (c_int, [c_int, c_int, c_int]),

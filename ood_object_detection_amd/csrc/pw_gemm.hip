@@ -39,7 +39,7 @@ constexpr int KCH = 2;                           // 64-byte K-chunks per pipelin
 // CU (20x20 maps) - twice the waves per SIMD to hide the per-stage latencies, at the price of reading each W
 // fragment from LDS once per 16 instead of once per 32 pixels
 template <typename T, int BN, int PT, int NTH>
-__global__ __launch_bounds__(NTH, 2) void pw_gemm_kernel(PwArgs p) {
+DEV void pw_gemm_body(const PwArgs& p, const int bid) {
     constexpr int EPC = VecTraits<T>::EPC;          // elements per 16-byte piece
     constexpr int KPC = 64 / (int)sizeof(T);        // elements per 64-byte K-chunk
     constexpr int NT = BN / 16, NP = NT / 2;
@@ -54,8 +54,8 @@ __global__ __launch_bounds__(NTH, 2) void pw_gemm_kernel(PwArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fpiece = lane >> 4;
     const int K = p.K, N = p.N;
-    const int nt = blockIdx.x % p.n_tiles;
-    const int mt = blockIdx.x / p.n_tiles;
+    const int nt = bid % p.n_tiles;
+    const int mt = bid / p.n_tiles;
     const int img = mt / p.tiles_per_image;
     const int pix0 = (mt - img * p.tiles_per_image) * PW_PIX;
     const int n0 = nt * BN;
@@ -244,19 +244,73 @@ __global__ __launch_bounds__(NTH, 2) void pw_gemm_kernel(PwArgs p) {
     }
 }
 
+template <typename T, int BN, int PT, int NTH>
+__global__ __launch_bounds__(NTH, 2) void pw_gemm_kernel(PwArgs p) {
+    pw_gemm_body<T, BN, PT, NTH>(p, blockIdx.x);
+}
+
+// Several independent GEMMs of one tile shape in ONE launch (the BiFPN's lateral 1x1 convs of the backbone features: six
+// small problems that would otherwise each leave most of the chip idle)
+constexpr int PW_GROUP_MAX = 8;
+struct PwGroupArgs { int n; int first[PW_GROUP_MAX + 1]; PwArgs p[PW_GROUP_MAX]; };
+
+template <typename T, int BN, int PT, int NTH>
+__global__ __launch_bounds__(NTH, 2) void pw_gemm_group_kernel(PwGroupArgs g) {
+    int i = 0;
+#pragma unroll
+    for (int q = 1; q < PW_GROUP_MAX; ++q) if (q < g.n && (int)blockIdx.x >= g.first[q]) i = q;
+    pw_gemm_body<T, BN, PT, NTH>(g.p[i], (int)blockIdx.x - g.first[i]);
+}
+
 template <typename T>
-int launch_pw(hipStream_t st, PwArgs& a) {
-    // output-channel tile: the smallest of {32, 64, 96, 128, 160, 192} that covers N, else equal tiles <= 192
+int pw_prepare(PwArgs& a, int& bn, long long& blocks) {
     int ntl = (a.N + 191) / 192;
-    int bn = ((a.N + ntl - 1) / ntl + 31) / 32 * 32;
+    bn = ((a.N + ntl - 1) / ntl + 31) / 32 * 32;
     a.tiles_per_image = (a.rows_per_image + PW_PIX - 1) / PW_PIX;
     const long long images = a.M / a.rows_per_image;
     a.n_tiles = (a.N + bn - 1) / bn;
-    const long long blocks = images * a.tiles_per_image * a.n_tiles;
+    blocks = images * a.tiles_per_image * a.n_tiles;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return EFFDET_EINVAL;
     const size_t esz = sizeof(T);
     a.vec_ok = ((size_t)a.N * esz) % 16 == 0 && ((size_t)a.ldc * esz) % 16 == 0 && ((size_t)a.c_image_stride * esz) % 16 == 0 &&
                reinterpret_cast<uintptr_t>(a.C) % 16 == 0 && (a.res == nullptr || reinterpret_cast<uintptr_t>(a.res) % 16 == 0);
+    return EFFDET_OK;
+}
+
+template <typename T>
+int launch_pw_group(hipStream_t st, PwGroupArgs& g) {
+    int bn0 = 0;
+    long long total = 0;
+    for (int i = 0; i < g.n; ++i) {
+        int bn; long long blocks;
+        const int rc = pw_prepare<T>(g.p[i], bn, blocks);
+        if (rc) return rc;
+        if (i == 0) bn0 = bn; else if (bn != bn0) return EFFDET_EINVAL;       // one tile shape per launch
+        g.first[i] = (int)total;
+        total += blocks;
+        if (total > 0x7fffffffLL) return EFFDET_EINVAL;
+    }
+    g.first[g.n] = (int)total;
+    dim3 grid((unsigned)total);
+    const bool small = total < 512;
+#define PWG_LAUNCH(BN_) do { if (small && BN_ != 128) hipLaunchKernelGGL((pw_gemm_group_kernel<T, BN_ == 128 ? 96 : BN_, 1, 512>), grid, dim3(512), 0, st, g); \
+                             else hipLaunchKernelGGL((pw_gemm_group_kernel<T, BN_, 2, 256>), grid, dim3(256), 0, st, g); } while (0)
+    switch (bn0) {
+        case 32:  PWG_LAUNCH(32); break;
+        case 64:  PWG_LAUNCH(64); break;
+        case 96:  PWG_LAUNCH(96); break;
+        default: return EFFDET_EINVAL;                                          // lateral convs are 64-88 wide (d0-d2); wider: one launch each
+    }
+#undef PWG_LAUNCH
+    return effdet_check_launch();
+}
+
+template <typename T>
+int launch_pw(hipStream_t st, PwArgs& a) {
+    // output-channel tile: the smallest of {32, 64, 96, 128, 160, 192} that covers N, else equal tiles <= 192
+    int bn; long long blocks;
+    const int rc0 = pw_prepare<T>(a, bn, blocks);
+    if (rc0) return rc0;
     dim3 grid((unsigned)blocks);
     const bool small = blocks < 512;                 // fewer than two workgroups per CU: 8 waves x 16 pixels each
 #define PW_LAUNCH(BN_) do { if (small && BN_ != 128) hipLaunchKernelGGL((pw_gemm_kernel<T, BN_ == 128 ? 96 : BN_, 1, 512>), grid, dim3(512), 0, st, a); /* the (128, 1, 512) instantiation spills */ \
@@ -295,5 +349,24 @@ extern "C" int effdet_pw_gemm_bn_act(void* stream, int dtype,
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == 0) return launch_pw<float>(st, a);
     if (dtype == 1) return launch_pw<bf16_t>(st, a);
+    return EFFDET_EINVAL;
+}
+
+// n independent GEMMs (no gate, no residual, dense outputs) in one launch; all N must select the same output tile (<= 96).
+// Arrays are per problem.  Used for the BiFPN's lateral 1x1 convs (effdet/efficientdet.py:155-158 via ResampleFeatureMap).
+extern "C" int effdet_pw_gemm_group(void* stream, int dtype, int n, const void* const* A, const long long* M, const int* K,
+                                    const void* const* W, const int* N, const float* const* scale, const float* const* shift,
+                                    int act, void* const* C) {
+    EFFDET_ENTER();
+    if (n < 1 || n > PW_GROUP_MAX || !A || !M || !K || !W || !N || !scale || !shift || !C || act < 0 || act > 2) return EFFDET_EINVAL;
+    PwGroupArgs g;
+    g.n = n;
+    for (int i = 0; i < n; ++i) {
+        if (!A[i] || !W[i] || !C[i] || !shift[i] || M[i] <= 0 || M[i] > 0x7fffffffLL || K[i] <= 0 || K[i] % 8 || N[i] <= 0) return EFFDET_EINVAL;
+        g.p[i] = PwArgs{A[i], M[i], K[i], W[i], N[i], scale[i], shift[i], act, nullptr, nullptr, (int)M[i], C[i], M[i] * N[i], N[i], 0, 0, 0};
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == 0) return launch_pw_group<float>(st, g);
+    if (dtype == 1) return launch_pw_group<bf16_t>(st, g);
     return EFFDET_EINVAL;
 }

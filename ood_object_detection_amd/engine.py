@@ -349,6 +349,7 @@ class Engine(object):
     def _build_fpn(self, fpn):
         lib, B, dt, F, cfg = self.lib, self.B, self.dt, self.F, self.cfg
         plan = []
+        lateral = []                            # 1x1 convs of backbone features (all depend on the backbone only): grouped below
         in_info = fpn.in_feature_info
         nbb = len(in_info)
         # level geometry
@@ -387,9 +388,8 @@ class Engine(object):
                 else:
                     t = self._f32(conv.conv.bias)
                     sp = None
-                plan.append((lib.effdet_pw_gemm_bn_act,
-                             (dt, prev.data_ptr(), B * ph * pw_, prev_c, wq.data_ptr(), F, sp, t.data_ptr(), 0, None, None, 0,
-                              tmp.data_ptr(), 0, 0), 'fpn.resample.%d.conv' % level, self._gemm_meta(B * ph * pw_, prev_c, F)))
+                lateral.append((prev.data_ptr(), B * ph * pw_, prev_c, wq.data_ptr(), sp, t.data_ptr(), tmp.data_ptr(),
+                                'fpn.resample.%d.conv' % level))
                 src = tmp
             out = dense(level)
             plan.append((lib.effdet_maxpool_same, (dt, src.data_ptr(), 0, out.data_ptr(), 0, B, ph, pw_, F),
@@ -436,11 +436,8 @@ class Engine(object):
                         else:
                             t = self._f32(conv.conv.bias)
                             sp = None
-                        plan.append((lib.effdet_pw_gemm_bn_act,
-                                     (dt, src['t'].data_ptr(), B * sh * sw, src['chs'], wq.data_ptr(), F, sp, t.data_ptr(), 0,
-                                      None, None, 0, lat.data_ptr(), 0, 0),
-                                     'fpn.cell.%d.fnode.%d.combine.resample.%d.conv' % (ci, ni, off),
-                                     self._gemm_meta(B * sh * sw, src['chs'], F)))
+                        lateral.append((src['t'].data_ptr(), B * sh * sw, src['chs'], wq.data_ptr(), sp, t.data_ptr(), lat.data_ptr(),
+                                        'fpn.cell.%d.fnode.%d.combine.resample.%d.conv' % (ci, ni, off)))
                         src = dict(raw=False, ptr=lat.data_ptr(), stride=sh * sw * F, level=src['level'])
                     d = src['level'] - lvl
                     mode = 0 if d == 0 else (1 if d == 1 else (2 if d == -1 else None))
@@ -474,7 +471,26 @@ class Engine(object):
                     [out_ptr], [out_stride], 'fpn.cell.%d.fnode.%d' % (ci, ni)))
                 x.append(dict(raw=False, ptr=out_ptr, stride=out_stride, level=lvl))
             x = x[-self.L:]
-        self._fpn_plan = plan
+        # the lateral convs read backbone features only, so they can all run first - in ONE launch when they share the output
+        # tile (F <= 96), else one launch each
+        head = []
+        if lateral and F <= 96 and len(lateral) <= 8:
+            n = len(lateral)
+            c_a = _arr(ctypes.c_void_p, [l[0] for l in lateral]); c_m = _arr(ctypes.c_longlong, [l[1] for l in lateral])
+            c_k = _arr(ctypes.c_int, [l[2] for l in lateral]); c_w = _arr(ctypes.c_void_p, [l[3] for l in lateral])
+            c_n = _arr(ctypes.c_int, [F] * n); c_s = _arr(ctypes.c_void_p, [l[4] for l in lateral])
+            c_t = _arr(ctypes.c_void_p, [l[5] for l in lateral]); c_c = _arr(ctypes.c_void_p, [l[6] for l in lateral])
+            self._keep += [c_a, c_m, c_k, c_w, c_n, c_s, c_t, c_c]
+            es = self.pyr_es
+            meta = dict(kind='pw_gemm', bytes=sum((l[1] * l[2] + l[1] * F + F * l[2]) * es for l in lateral),
+                        flops=sum(2 * l[1] * l[2] * F for l in lateral))
+            head.append((lib.effdet_pw_gemm_group, (dt, n, c_a, c_m, c_k, c_w, c_n, c_s, c_t, 0, c_c),
+                         'fpn lateral 1x1 convs (%s)' % ', '.join(l[7].replace('fpn.', '').replace('.combine.resample', '').replace('.conv', '') for l in lateral), meta))
+        else:
+            for l in lateral:
+                head.append((lib.effdet_pw_gemm_bn_act, (dt, l[0], l[1], l[2], l[3], F, l[4], l[5], 0, None, None, 0, l[6], 0, 0),
+                             l[7], self._gemm_meta(l[1], l[2], F)))
+        self._fpn_plan = head + plan
 
     def _sepconv_call(self, level_hw, level_inputs, fuse_mode, fw, den, pre_act, taps, wq, scale, shift, affine_rows,
                       post_act, F, N, out_ptrs, out_strides, what, ood=None, out_f32=False):

@@ -41,6 +41,47 @@ def test_pw_gemm(dtype, M, K, N):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_pw_gemm_group_equals_single_launches(dtype):
+    """effdet_pw_gemm_group (the BiFPN's lateral convs in one launch) is bit-identical to one effdet_pw_gemm_bn_act per problem"""
+    import ctypes
+    import _hip
+    from ood_object_detection_amd import _lib
+    lib = _lib.load()
+    st = _hip.stream(DEV)
+    N = 64
+    probs = [(2 * 400, 320), (2 * 1600, 112), (2 * 6400, 40), (2 * 100, 320), (77, 8)]
+    keep, single, grouped = [], [], []
+    for i, (M, K) in enumerate(probs):
+        A = _rand(M, K, seed=30 + i).to(dtype).to(DEV)
+        W = _rand(N, K, seed=40 + i, scale=K ** -0.5).to(dtype).to(DEV)
+        sc = (torch.rand(N) + 0.5).to(DEV) if i % 2 == 0 else None
+        sh = _rand(N, seed=50 + i, scale=0.1).to(DEV)
+        c0, c1 = torch.empty(M, N, dtype=dtype, device=DEV), torch.empty(M, N, dtype=dtype, device=DEV)
+        assert lib.effdet_pw_gemm_bn_act(st, _hip.DT[dtype], A.data_ptr(), M, K, W.data_ptr(), N, None if sc is None else sc.data_ptr(),
+                                         sh.data_ptr(), 0, None, None, 0, c0.data_ptr(), 0, 0) == 0
+        keep.append((A, W, sc, sh))
+        single.append(c0)
+        grouped.append(c1)
+    n = len(probs)
+    arr = lambda ct, v: (ct * n)(*v)
+    rc = lib.effdet_pw_gemm_group(st, _hip.DT[dtype], n, arr(ctypes.c_void_p, [k[0].data_ptr() for k in keep]),
+                                  arr(ctypes.c_longlong, [p[0] for p in probs]), arr(ctypes.c_int, [p[1] for p in probs]),
+                                  arr(ctypes.c_void_p, [k[1].data_ptr() for k in keep]), arr(ctypes.c_int, [N] * n),
+                                  arr(ctypes.c_void_p, [None if k[2] is None else k[2].data_ptr() for k in keep]),
+                                  arr(ctypes.c_void_p, [k[3].data_ptr() for k in keep]), 0,
+                                  arr(ctypes.c_void_p, [c.data_ptr() for c in grouped]))
+    assert rc == 0
+    torch.cuda.synchronize()
+    for a, b in zip(single, grouped):
+        assert torch.equal(a, b)
+    # mixed output tiles are refused
+    assert lib.effdet_pw_gemm_group(st, _hip.DT[dtype], 2, arr(ctypes.c_void_p, [keep[0][0].data_ptr()] * n), arr(ctypes.c_longlong, [800] * n),
+                                    arr(ctypes.c_int, [320] * n), arr(ctypes.c_void_p, [keep[0][1].data_ptr()] * n), arr(ctypes.c_int, [64, 24, 0, 0, 0]),
+                                    arr(ctypes.c_void_p, [None] * n), arr(ctypes.c_void_p, [keep[0][3].data_ptr()] * n), 0,
+                                    arr(ctypes.c_void_p, [grouped[0].data_ptr()] * n)) != 0
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_pw_gemm_gate_and_strided_out(dtype):
     import _hip
     from ood_object_detection_amd import _lib
