@@ -280,7 +280,7 @@ int effdet_train_dwconv_bwd_dw(void* stream, const float* dY, const float* X, fl
  *  0 silu(a)   1 b*silu'(a)   2 a+b   3 a*v0[c]+v1[c] (v1 optional)   4 a*v0[img,c]   5 a*v0[img,c]+v1[img,c]*s0
  *  6 v0[c]*(a - v1[c] - (b - v2[c])*v3[c])  (batch-statistics BN backward)
  *  7 (a*s0)/s3 + (b*s1)/s3 [+ (c*s2)/s3]  (FpnCombine 'fastattn', effdet/efficientdet.py:240-242)   8 a*s0
- *  9 a*s0 + b*s1 [+ c*s2]
+ *  9 a*s0 + b*s1 [+ c*s2]   10 a*b   11 a*b*silu''(c)  (double backward of SiLU: the MetaHead's second-order MAML terms)
  * sdev (optional): device float[4] that replaces s0..s3 at run time, so that a captured hipGraph of the training step
  * sees the current BiFPN edge weights.  out2 (optional): silu(out), written in the same pass. */
 int effdet_train_ew(void* stream, int op, float* out, const float* a, const float* b, const float* c,

@@ -445,6 +445,8 @@ struct EwArgs {
 };
 
 DEV float silu_grad(float z) { const float s = sigmoid_f(z); return s * (1.0f + z * (1.0f - s)); }
+// second derivative of z * sigmoid(z): sigma (1 - sigma) (2 + z (1 - 2 sigma))   (double backward of the MetaHead, infer.py:658)
+DEV float silu_grad2(float z) { const float s = sigmoid_f(z); return s * (1.0f - s) * (2.0f + z * (1.0f - 2.0f * s)); }
 
 __global__ __launch_bounds__(256) void ew_kernel(EwArgs p) {
     const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -497,6 +499,16 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs p) {
     case 8:                                             // a * s0
         o = a * p.s0;
         break;
+    case 10: {                                          // a * b
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.b + i);
+        o = a * b;
+        break; }
+    case 11: {                                          // a * b * silu''(c)
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.b + i);
+        const f32x4 z = *reinterpret_cast<const f32x4*>(p.c + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = a[j] * b[j] * silu_grad2(z[j]);
+        break; }
     default:                                            // 9: weighted sum without the division ('attn' / 'sum')
     {
         const f32x4 b = *reinterpret_cast<const f32x4*>(p.b + i);
@@ -944,9 +956,10 @@ extern "C" int effdet_train_ew(void* stream, int op, float* out, const float* a,
                                const float* v0, const float* v1, const float* v2, const float* v3,
                                float s0, float s1, float s2, float s3, long long n, int C, long long hw, const float* sdev, float* out2) {
     EFFDET_ENTER();
-    if (!out || !a || n <= 0 || n % 4 || C <= 0 || C % 4 || op < 0 || op > 9) return EFFDET_EINVAL;
-    const bool need_b = op == 1 || op == 2 || op == 6 || op == 7 || op == 9;
+    if (!out || !a || n <= 0 || n % 4 || C <= 0 || C % 4 || op < 0 || op > 11) return EFFDET_EINVAL;
+    const bool need_b = op == 1 || op == 2 || op == 6 || op == 7 || op == 9 || op == 10 || op == 11;
     if (need_b && !b) return EFFDET_EINVAL;
+    if (op == 11 && !c) return EFFDET_EINVAL;
     if ((op == 3 || op == 4 || op == 5 || op == 6) && !v0) return EFFDET_EINVAL;
     if ((op == 5 || op == 6) && !v1) return EFFDET_EINVAL;
     if (op == 6 && (!v2 || !v3)) return EFFDET_EINVAL;

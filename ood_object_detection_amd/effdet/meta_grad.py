@@ -6,8 +6,9 @@ with respect to the BiFPN activations.
 `MetaHeadFn` is one autograd node: forward keeps the activations, backward runs depthwise / pointwise / batch-statistics-BN /
 SiLU backward kernels (csrc/train_net.hip, the operators of the pretrain step) and returns d loss / d (every weight in the
 reference's fast-weight order) and d loss / d (every input level).  float32 only, like the rest of the training path.
-FIRST ORDER: the backward itself is not differentiable, so with `create_graph=True` the second-order terms of MAML (the
-dependence of the inner gradient on the parameters) are dropped - the outer gradient is that of first-order MAML.
+FIRST ORDER: this node's backward is not itself differentiable, so with `create_graph=True` it would drop the second-order
+terms of MAML.  `MetaHead.first_order = True` selects it (one node, fewer launches); the default differentiable path is the
+composition of primitives in effdet/meta_ops.py, which autograd differentiates twice like the reference.
 """
 import warnings
 
@@ -148,9 +149,16 @@ def meta_head_train_forward(mh, x, conv_dw_rep, conv_pw_rep, conv_pb_rep, bn_rep
         raise RuntimeError('the differentiable MetaHead path is float32 (the reference trains in fp32); use torch.no_grad() for '
                            'bfloat16 inference')
     xs = [x[l].permute(0, 2, 3, 1) for l in levels]
-    meta = dict(R=mh.num_layers, L=mh.num_levels, levels=list(levels), both=both, running_mu=mh.running_mu, running_std=mh.running_std)
-    res = MetaHeadFn.apply(meta, *(xs + tens))
     nl = len(levels)
+    if not getattr(mh, 'first_order', False):
+        from . import meta_ops
+        o, a, c = meta_ops.meta_head_forward([t.contiguous() for t in xs], conv_dw_rep, conv_pw_rep, conv_pb_rep, bn_rep_w, bn_rep_b,
+                                             predict, predict_class if both else None, list(levels), mh.num_layers,
+                                             mh.running_mu, mh.running_std)
+        res = tuple(o) + tuple(a) + (tuple(c) if both else ())
+    else:
+        meta = dict(R=mh.num_layers, L=mh.num_levels, levels=list(levels), both=both, running_mu=mh.running_mu, running_std=mh.running_std)
+        res = MetaHeadFn.apply(meta, *(xs + tens))
     nchw = lambda t: t.permute(0, 3, 1, 2)
     outputs = [nchw(t) for t in res[:nl]]
     activs = [nchw(t) for t in res[nl:2 * nl]]

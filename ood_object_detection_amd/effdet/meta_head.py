@@ -7,8 +7,9 @@ module's own parameters in the reference's list order; `ret_activs` returns the 
 
 HIP path: one `effdet_sepconv_meta` launch per layer for all levels, `effdet_bn_batch_stats` in between (the batch
 statistics are folded into a per-level scale / shift that the next layer applies while loading its halo tile).
-With grad mode on and trainable weights / inputs the forward is the differentiable float32 path of effdet/meta_grad.py
-(first-order gradients w.r.t. every fast weight and input level: the inner-loop update of infer.py:658-681)."""
+With grad mode on and trainable weights / inputs the forward is the differentiable float32 path (effdet/meta_ops.py: autograd
+primitives on the training kernels, differentiable twice - the `create_graph=True` inner gradient of infer.py:658 and the outer
+backward through it; `first_order = True` selects the single-node backward of effdet/meta_grad.py instead)."""
 import math
 from typing import List, Optional
 
@@ -21,6 +22,8 @@ _DT = {torch.float32: 0, torch.bfloat16: 1}
 
 
 class MetaHead(nn.Module):
+    first_order = False     # True: single-node backward (effdet/meta_grad.py), drops MAML's second-order terms; default: meta_ops.py
+
     def __init__(self, config, pretrain_init=None, num_channels_flag=None):
         super().__init__()
         self.num_layers = config.box_class_repeats
@@ -94,8 +97,8 @@ class MetaHead(nn.Module):
             raise RuntimeError('MetaHead runs on the GPU in float32 / bfloat16 only (no CPU fallback)')
         if torch.is_grad_enabled() and any(t.requires_grad for t in list(x) + list(conv_dw_rep) + list(conv_pw_rep) + list(conv_pb_rep) +
                                            list(predict) + list(bn_rep_w) + list(bn_rep_b)):
-            # the MAML inner / outer loop (infer.py:561-681): differentiable float32 path on the training kernels, first-order
-            # gradients with respect to every (fast) weight and every input level
+            # the MAML inner / outer loop (infer.py:561-681): differentiable float32 path on the training kernels, gradients
+            # (to second order) with respect to every (fast) weight and every input level
             from .meta_grad import meta_head_train_forward
             return meta_head_train_forward(self, x, conv_dw_rep, conv_pw_rep, conv_pb_rep, bn_rep_w, bn_rep_b, predict,
                                            self.predict_class if both else None, levels, ret_activs, both)

@@ -163,7 +163,8 @@ def test_infer_training_iteration_inner_and_outer_gradients():
     `torch.autograd.grad(..., model.class_net.parameters(), allow_unused=True, only_inputs=True, create_graph=True)` (:658),
     fast weights `par - par_lr * inner_grad` (:660-678), query pass `mode='qry_cls'` with them (:681), `loss_fn` (:683),
     `final_loss.backward()` (:687) - the outer gradient reaches the head's parameters and the learnable inner learning rates.
-    (First-order MAML: the HIP backward is not itself differentiable, see effdet/meta_grad.py.)"""
+    (The inner gradient is itself differentiable - effdet/meta_ops.py - so this is the reference's second-order MAML; values are
+    checked against the oracle in test_model_gpu.py::test_meta_head_second_order_matches_oracle_autograd.)"""
     import torch.nn.functional as F
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, 'ood_object_detection_amd'))

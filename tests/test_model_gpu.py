@@ -686,8 +686,8 @@ def test_nested_fork_inside_capture_is_refused():
     assert torch.equal(out, ref)
 
 
-@pytest.mark.parametrize('both,offset', [(False, 0), (True, 2)])
-def test_meta_head_gradients_match_oracle_autograd(golden, both, offset):
+@pytest.mark.parametrize('both,offset,first_order', [(False, 0, False), (True, 2, False), (False, 0, True), (True, 2, True)])
+def test_meta_head_gradients_match_oracle_autograd(golden, both, offset, first_order):
     """the MAML inner loop's gradients (infer.py:658: autograd.grad of a loss on the MetaHead outputs w.r.t. the head's
     parameters; :681 the query pass with fast weights): d loss / d (every weight, every input level) from the HIP training
     kernels against torch autograd through the oracle's MetaHead restatement (itself pinned to the reference class)"""
@@ -705,6 +705,7 @@ def test_meta_head_gradients_match_oracle_autograd(golden, both, offset):
         mh.add_head()
         mh.predict_pw_sep.data.copy_(c['extra']['predict_pw_sep']); mh.predict_pb_sep.data.copy_(c['extra']['predict_pb_sep'])
     mh = mh.to(DEV)
+    mh.first_order = first_order             # True: the single-node backward (effdet/meta_grad.py); default: primitives (meta_ops.py)
     xs = [t.clone().to(DEV).requires_grad_() for t in c['x']]
     nlev = L - offset
     # a loss that reaches every output: random cotangents for outputs, x_pred activations (and the separate class head)
@@ -767,3 +768,97 @@ def test_meta_head_gradients_match_oracle_autograd(golden, both, offset):
         fw2 = [w - 0.1 * (gg if gg is not None else torch.zeros_like(w)) for w, gg in zip(fw, gf)]
         out_q = mh([t.detach() for t in xs], fast_weights=fw2)
         assert not torch.equal(out_q[0], out_f[0].detach())
+
+
+@pytest.mark.parametrize('offset', [0, 2])
+def test_meta_head_second_order_matches_oracle_autograd(golden, offset):
+    """MAML as the reference runs it (infer.py:658-687): the inner gradient is taken with create_graph=True and the outer loss
+    is differentiated THROUGH it.  Here: g = d L1 / d params (create_graph), then d <g, v> / d (params, inputs) - a
+    Hessian-vector product with random v - from the HIP primitives (effdet/meta_ops.py) against torch autograd through the
+    oracle's MetaHead on the CPU; and the full inner-step / query-loss composition of infer.py:660-687."""
+    from _seeded import meta_lists, meta_nets_case, seeded_tensor
+    from ood_object_detection_amd.effdet.config import get_efficientdet_config
+    from ood_object_detection_amd.effdet.meta_head import MetaHead
+    g = golden('meta_nets')
+    c = meta_nets_case(g)
+    cfg = get_efficientdet_config('tf_efficientdet_d0')
+    L, R = c['L'], c['R']
+    mh = MetaHead(cfg, pretrain_init=c['init'])
+    with torch.no_grad():
+        mh.predict_pw.copy_(c['extra']['predict_pw']); mh.predict_pb.copy_(c['extra']['predict_pb'])
+    mh = mh.to(DEV)
+    xs = [t.clone().to(DEV).requires_grad_() for t in c['x']]
+    go = [seeded_tensor(71, 'go%d' % i, (c['B'], 9, s, s)) for i, s in enumerate(c['sizes'][offset:])]
+
+    def inner_loss(outs):                      # non-linear in the outputs, like the BCE of infer.py:656
+        return sum(torch.nn.functional.binary_cross_entropy_with_logits(o, torch.sigmoid(w.to(o.device))) for o, w in zip(outs, go))
+    names = [n for n, _ in mh.named_parameters()]
+    params = list(mh.parameters())
+    vs = [seeded_tensor(72, 'v_' + n, tuple(p.shape)) for n, p in zip(names, params)]
+    # ---- HIP
+    outs = mh(xs, level_offset=offset)
+    g1 = torch.autograd.grad(inner_loss(outs), params, create_graph=True, allow_unused=True)
+    assert all(gi is None or gi.requires_grad for gi in g1)
+    dot = sum((gi * v.to(DEV)).sum() for gi, v in zip(g1, vs) if gi is not None)
+    hv = torch.autograd.grad(dot, params + xs[offset:], allow_unused=True)
+    # ---- oracle on the CPU
+    dw, pw, pb, pred, bw, bb = meta_lists(c['init'], c['extra'], L, R)
+    leaf = lambda ts: [t.clone().requires_grad_() for t in ts]
+    dw, pw, pb, pred, bw, bb = leaf(dw), leaf(pw), leaf(pb), leaf(pred), leaf(bw), leaf(bb)
+    xr = [t.clone().requires_grad_() for t in c['x']]
+    ro = om.meta_head_forward(dw, pw, pb, bw, bb, pred, xr, level_offset=offset)[0]
+    ref_named = {}
+    for r in range(R):
+        ref_named['conv_dw%d' % r], ref_named['conv_pw%d' % r], ref_named['conv_pb%d' % r] = dw[r], pw[r], pb[r]
+    ref_named['predict_dw'], ref_named['predict_pw'], ref_named['predict_pb'] = pred
+    for lev in range(L):
+        for r in range(R):
+            ref_named['bn_w%d%d' % (r, lev)], ref_named['bn_b%d%d' % (r, lev)] = bw[lev * R + r], bb[lev * R + r]
+    rparams = [ref_named[n] for n in names]
+    r1 = torch.autograd.grad(inner_loss(ro), rparams, create_graph=True, allow_unused=True)
+    rdot = sum((gi * v).sum() for gi, v in zip(r1, vs) if gi is not None)
+    rhv = torch.autograd.grad(rdot, rparams + xr[offset:], allow_unused=True)
+    hmax = max(float(r.abs().max()) for r in rhv if r is not None)
+    worst = []
+    for n, a, r in zip(names + ['x%d' % i for i in range(offset, L)], hv, rhv):
+        if r is None:
+            assert a is None or float(a.abs().max()) == 0.0, n
+            continue
+        assert a is not None, n
+        worst.append((float((a.cpu() - r).abs().max()) / max(float(r.abs().max()), 1e-3 * hmax), n))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 5e-3, worst[:6]
+    # ---- the inner step + query loss of infer.py:660-687: outer gradient w.r.t. the parameters and the inner learning rate
+    def outer(params_, x_, fwd, lr):
+        o = fwd(x_, None)
+        gi = torch.autograd.grad(inner_loss(o), params_, create_graph=True, allow_unused=True)
+        fast = [p if (gq is None or n.startswith('bn_')) else p - lr * gq for n, p, gq in zip(names, params_, gi)]
+        q = fwd(x_, fast)
+        return sum((t * w.to(t.device)).sum() for t, w in zip(q, go))
+    lr_h = torch.tensor(0.05, device=DEV, requires_grad=True)
+    fwd_h = lambda x_, fast: mh([t.detach() for t in x_], fast_weights=fast, level_offset=offset)
+    lo = outer(params, xs, fwd_h, lr_h)
+    gh = torch.autograd.grad(lo, params + [lr_h], allow_unused=True)
+    lr_r = torch.tensor(0.05, requires_grad=True)
+
+    def fwd_r(x_, fast):
+        if fast is None:
+            return om.meta_head_forward(dw, pw, pb, bw, bb, pred, [t.detach() for t in x_], level_offset=offset)[0]
+        f = dict(zip(names, fast))
+        return om.meta_head_forward([f['conv_dw%d' % r] for r in range(R)], [f['conv_pw%d' % r] for r in range(R)],
+                                    [f['conv_pb%d' % r] for r in range(R)],
+                                    [f['bn_w%d%d' % (r, lev)] for lev in range(L) for r in range(R)],
+                                    [f['bn_b%d%d' % (r, lev)] for lev in range(L) for r in range(R)],
+                                    [f['predict_dw'], f['predict_pw'], f['predict_pb']], [t.detach() for t in x_], level_offset=offset)[0]
+    lr_ = outer(rparams, xr, fwd_r, lr_r)
+    gr = torch.autograd.grad(lr_, rparams + [lr_r], allow_unused=True)
+    assert abs(float(lo) - float(lr_)) <= 2e-4 * max(1.0, abs(float(lr_)))
+    gmax = max(float(r.abs().max()) for r in gr if r is not None)
+    worst = []
+    for n, a, r in zip(names + ['inner_lr'], gh, gr):
+        if r is None:
+            continue
+        assert a is not None, n
+        worst.append((float((a.cpu() - r).abs().max()) / max(float(r.abs().max()), 1e-3 * gmax), n))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 5e-3, worst[:6]
