@@ -88,12 +88,13 @@ def cpu_baseline(model_cpu_sd, cfg, image, num_classes, budget_s=20.0, gpu_check
     B = 1
     x = torch.randn(B, 3, image, image, generator=torch.Generator().manual_seed(5))
 
-    def step():
+    def step(xb=None):
+        xb = x if xb is None else xb
         with torch.no_grad():
-            cls_o, box_o = om.efficientdet_forward(model_cpu_sd, cfg, x, nodes)
+            cls_o, box_o = om.efficientdet_forward(model_cpu_sd, cfg, xb, nodes)
             om.ood_scores(cls_o, num_classes)
             c, b, idx, cl = op.post_process(cls_o, box_o, cfg.num_levels, num_classes, cfg.max_detection_points)
-            for i in range(B):
+            for i in range(xb.shape[0]):
                 op.generate_detections(c[i], b[i], anchors, idx[i], cl[i], None, torch.tensor(image), cfg.max_det_per_image, False)
 
     parity = None
@@ -106,18 +107,26 @@ def cpu_baseline(model_cpu_sd, cfg, image, num_classes, budget_s=20.0, gpu_check
                   'class_logits_linf': float(max((a - b.cpu()).abs().max() for a, b in zip(cls_o, gc))),
                   'box_outputs_linf': float(max((a - b.cpu()).abs().max() for a, b in zip(box_o, gb))),
                   'ood_energy_linf': float((energy - ge.cpu()).abs().max())}
-    t0 = time.time()
-    step()                                    # first pass: warm-up, and the measurement itself if it is very slow
-    first = time.time() - t0
-    n, dt = 1, first
-    if first < budget_s / 2:
-        n, t1 = 0, time.time()
-        while (time.time() - t1) < (budget_s - first) and n < 50:
-            step()
-            n += 1
-        dt = time.time() - t1
-    out = {'value': round(B * n / dt, 3), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
-           'sample': '%d x batch-%d fp32 oracle passes of the same d0/%d workload (forward+OOD+top-k+decode+hard NMS)' % (n, B, image)}
+    def timed(xb, budget):
+        t0 = time.time()
+        step(xb)                              # first pass: warm-up, and the measurement itself if it is very slow
+        first = time.time() - t0
+        n, dt = 1, first
+        if first < budget / 2:
+            n, t1 = 0, time.time()
+            while (time.time() - t1) < (budget - first) and n < 50:
+                step(xb)
+                n += 1
+            dt = time.time() - t1
+        return xb.shape[0] * n / dt, n
+    # batch 1 and batch 8 (the larger batch gives the host's GEMMs more rows per call)
+    r1, n1 = timed(x, budget_s * 0.6)
+    x8 = torch.randn(8, 3, image, image, generator=torch.Generator().manual_seed(6))
+    r8, n8 = timed(x8, budget_s * 0.4)
+    out = {'value': round(max(r1, r8), 3), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+           'sample': '%d x batch-1 and %d x batch-8 fp32 oracle passes of the same %d px workload (forward+OOD+top-k+decode+hard NMS); '
+                     'value = the faster of the two' % (n1, n8, image),
+           'batch1_images_per_sec': round(r1, 3), 'batch8_images_per_sec': round(r8, 3)}
     if parity is not None:
         out['parity_vs_hip_f32'] = parity
     return out
