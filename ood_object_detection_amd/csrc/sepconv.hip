@@ -640,7 +640,14 @@ int launch_sep(hipStream_t st, SepArgs& a, int B) {
 
 template <typename T, int TH, int TW, int NTH, int FT>
 int dispatch_sep_f(hipStream_t st, SepArgs& a, int B) {
-    if (a.ood_classes > 0) return launch_sep<T, TH, TW, 96, true, NTH, FT>(st, a, B);
+    if (a.ood_classes > 0) {
+        // class predict: one 96-channel chunk per anchor; widths whose 96-row W chunk no longer fits beside the A tile (float32
+        // d5, 288 channels) take 64-row chunks - two sub-chunks per anchor, the running max / sum-exp carries over
+        if constexpr (FT == 0) {
+            if (sep_lds_bytes<T, TH, TW, 96>(a.F) > 160 * 1024) return launch_sep<T, TH, TW, 64, true, NTH, FT>(st, a, B);
+        }
+        return launch_sep<T, TH, TW, 96, true, NTH, FT>(st, a, B);
+    }
     // head layers read one input: a variant without the registers of the other two
     if (FT == 64 && a.n_in == 1) return launch_sep<T, TH, TW, 64, false, NTH, FT, false, 1>(st, a, B);
     return launch_sep<T, TH, TW, 64, false, NTH, FT>(st, a, B);

@@ -54,9 +54,9 @@ class Engine(object):
         self.input_std = tuple(getattr(model, 'input_std', (0.229, 0.224, 0.225)))
         self.pyr_es = torch.empty(0, dtype=self.dtype).element_size()
         H, W = self.image_size
-        if cfg.fpn_channels > 224:
+        if cfg.fpn_channels > 288:
             raise NotImplementedError('BiFPN / head width %d: the fused separable-conv kernel keeps a tile of all channels in LDS and is '
-                                      'built for widths up to 224 (tf_efficientdet_d0 ... d4); d5 and larger are not built' % cfg.fpn_channels)
+                                      'built for widths up to 288 (tf_efficientdet_d0 ... d5); d6 / d7 are not built' % cfg.fpn_channels)
         if H % (2 ** cfg.max_level) or W % (2 ** cfg.max_level):
             raise ValueError('image size must be divisible by 2**max_level (reference: effdet/anchors.py:229-230)')
         with torch.no_grad():
