@@ -139,10 +139,13 @@ __global__ __launch_bounds__(512, 4) void stem_roll_kernel(SrArgs p) {
     // One input row = 3 planes x 2 lane-halves raw values, fetched one output row ahead.  bfloat16 input: lanes 0 .. 32 load a
     // DWORD = two pixels per plane (ix0, W and pad_l are even, so a pair never straddles the image border): 6 loads per step
     // instead of 12 two-byte ones, and one 16-byte LDS store per lane.
-    float raw[2][3][2];
-    unsigned rawd[2][3];
+    // three steps of input rows wait in registers: an HBM round trip is several output rows of work long, one row ahead is not enough
+    constexpr int PFD = IN == 1 ? 3 : 1;                              // (float32 / uint8 inputs hold twice the registers per row: one step)
+    float raw[PFD][2][3][2];
+    unsigned rawd[PFD][2][3];
     const int dvoff = (lane < 33 && ix0 + 2 * lane >= 0 && ix0 + 2 * lane < p.W) ? (ix0 + 2 * lane) * 2 : OOB;
-    auto fetch_rows = [&](int iy0) {                                  // input rows iy0, iy0 + 1
+    auto fetch_rows = [&](int iy0, auto SLC) {                        // input rows iy0, iy0 + 1 -> register slot SL
+        constexpr int SL = decltype(SLC)::value;
         if constexpr (IN == 1) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(512, 4) void stem_roll_kernel(SrArgs p) {
 #pragma unroll
                 for (int ci = 0; ci < 3; ++ci) {
                     const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(xrs, dvoff, ci * plane + iy * p.W * 2, 0);
-                    rawd[r][ci] = rin ? v : 0u;
+                    rawd[SL][r][ci] = rin ? v : 0u;
                 }
             }
             return;
@@ -173,18 +176,19 @@ __global__ __launch_bounds__(512, 4) void stem_roll_kernel(SrArgs p) {
                     else v = ((float)__builtin_amdgcn_raw_buffer_load_b8(xrs, ivoff[h], so, 0) - (ci == 0 ? p.nmean[0] : ci == 1 ? p.nmean[1] : p.nmean[2])) /
                              (ci == 0 ? p.nstd[0] : ci == 1 ? p.nstd[1] : p.nstd[2]);
                     // rows / columns outside the image are TF-SAME zero padding of the INPUT (uint8: zero after normalisation too)
-                    raw[r][ci][h] = (rin && ivoff[h] != OOB) ? v : 0.f;
+                    raw[SL][r][ci][h] = (rin && ivoff[h] != OOB) ? v : 0.f;
                 }
         }
     };
-    auto commit_rows = [&](int iy0) {                                 // raw -> interleaved bf16 pixels in ring slots (iy & 3)
+    auto commit_rows = [&](int iy0, auto SLC) {                       // raw -> interleaved bf16 pixels in ring slots (iy & 3)
+        constexpr int SL = decltype(SLC)::value;
         if constexpr (IN == 1) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 char* dst = irows + ((iy0 + r) & 3) * SR_IROW;
                 // {c0 c1} | {c2 0} of pixel 2*lane, then of pixel 2*lane + 1
-                const u32x4 v = {(rawd[r][0] & 0xFFFFu) | (rawd[r][1] << 16), rawd[r][2] & 0xFFFFu,
-                                 (rawd[r][0] >> 16) | (rawd[r][1] & 0xFFFF0000u), rawd[r][2] >> 16};
+                const u32x4 v = {(rawd[SL][r][0] & 0xFFFFu) | (rawd[SL][r][1] << 16), rawd[SL][r][2] & 0xFFFFu,
+                                 (rawd[SL][r][0] >> 16) | (rawd[SL][r][1] & 0xFFFF0000u), rawd[SL][r][2] >> 16};
                 if (lane < 36) *reinterpret_cast<u32x4*>(dst + lane * 16) = v;
             }
             return;
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(512, 4) void stem_roll_kernel(SrArgs p) {
                 const int c = lane + 64 * h;
                 if (c < SR_IPX) {
                     typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
-                    *reinterpret_cast<bf16x4_*>(dst + c * 8) = bf16x4_{(bf16_t)raw[r][0][h], (bf16_t)raw[r][1][h], (bf16_t)raw[r][2][h], (bf16_t)0.f};
+                    *reinterpret_cast<bf16x4_*>(dst + c * 8) = bf16x4_{(bf16_t)raw[SL][r][0][h], (bf16_t)raw[SL][r][1][h], (bf16_t)raw[SL][r][2][h], (bf16_t)0.f};
                 }
             }
         }
@@ -231,24 +235,30 @@ __global__ __launch_bounds__(512, 4) void stem_roll_kernel(SrArgs p) {
     const int s_first = oy_b - 1;
     {
         const int iyA = 2 * s_first - p.pad_t;
-        fetch_rows(iyA); commit_rows(iyA);
-        fetch_rows(iyA + 2); commit_rows(iyA + 2);
+        fetch_rows(iyA, IntS<0>{}); commit_rows(iyA, IntS<0>{});
+        fetch_rows(iyA + 2, IntS<0>{}); commit_rows(iyA + 2, IntS<0>{});
         stem_row(s_first, 0);
-        fetch_rows(iyA + 3); commit_rows(iyA + 3);                    // (row iyA + 3 again with iyA + 4: rows are committed in pairs)
+        fetch_rows(iyA + 3, IntS<0>{}); commit_rows(iyA + 3, IntS<0>{});   // (row iyA + 3 again with iyA + 4: rows are committed in pairs)
         stem_row(s_first + 1, 1024);
     }
     int snext = s_first + 2;                                          // next stem row to compute
-    fetch_rows(2 * snext - p.pad_t + 1);                              // its two new input rows (the first was committed already)
+    // the two new input rows of the next three stem rows (the first row of each was committed with its predecessor)
+    fetch_rows(2 * snext - p.pad_t + 1, IntS<0>{});
+    if constexpr (PFD == 3) {
+        fetch_rows(2 * (snext + 1) - p.pad_t + 1, IntS<1>{});
+        fetch_rows(2 * (snext + 2) - p.pad_t + 1, IntS<2>{});
+    }
     int yrow = oy_b * p.Wo * C * 2;
     const int ypitch = p.Wo * C * 2;
     int oy = oy_b;
     auto step = [&](auto PHC) {
         constexpr int PH = decltype(PHC)::value;                      // ring slot of stem row oy - 1
         const int iyn = 2 * snext - p.pad_t + 1;
-        commit_rows(iyn);
+        constexpr int SLOT = PFD == 3 ? PH : 0;
+        commit_rows(iyn, IntS<SLOT>{});                              // fetched PFD steps ago into register slot SLOT
         stem_row(snext, ((PH + 2) % 3) * 1024);
         ++snext;
-        fetch_rows(2 * snext - p.pad_t + 1);
+        fetch_rows(2 * (snext + PFD - 1) - p.pad_t + 1, IntS<SLOT>{});   // rows of the step PFD ahead, into the slot just emptied
         __builtin_amdgcn_sched_barrier(0);
         int hsel = hi;
         asm volatile("" : "+v"(hsel));
