@@ -42,8 +42,13 @@ int effdet_stem_conv(void* stream, int in_dtype, int out_dtype, const void* X, c
 
 /* Fused conv_stem + bn1 + SiLU -> blocks.0.0 depthwise 3x3/s1 + BN + SiLU (+ SE pool partials); the stem
  * output stays in LDS.  Wk: [C][32] im2col weights (dtype), k = (ky*3+kx)*3+ci zero-padded from 27 to 32;
- * taps [9][C] fp32; Y NHWC [B,ceil(H/2),ceil(W/2),C]; pool_partial [B][effdet_stem_dw_tiles_per_image][C]
- * or NULL.  C <= 64. */
+ * taps [9][C] fp32; Y NHWC [B,ceil(H/2),ceil(W/2),C]; pool_partial [B][effdet_stem_dw_parts(dtype,H,W,C)][C]
+ * or NULL: the launch writes exactly that many rows per image (bf16 with C = 32 and an even width takes the
+ * rolling-window form, whose row count differs from the tile form's) - size AND sum the buffer by
+ * effdet_stem_dw_parts, never by effdet_stem_dw_tiles_per_image (the float32 tile form's count, kept for
+ * callers that run float32 only).  The same rule holds for effdet_mbconv_expand_dw[_gated]: its pool_partial
+ * has effdet_mbconv[_gated]_tiles_per_image(dtype, ...) rows per image, which already answers for the form
+ * the given dtype will run.  C <= 64. */
 int effdet_stem_dw_fused(void* stream, int in_dtype, int dtype, const void* X, const void* Wk,
                          const float* s1, const float* t1, const float* taps, const float* s2, const float* t2,
                          void* Y, float* pool_partial, int B, int H, int W, int C);
@@ -365,7 +370,9 @@ int effdet_eval_ap(void* stream, const float* scores, const int* classes, const 
  * embds [n,d] fp32 = ProjectionNet outputs (normalised inside, F.normalize p=2), confs [n] = anchor confidences (logits),
  * proto_idx [m] int64 = rows of embds that form the cluster (`max_idxs` of the episode code).
  * soft_thresh = sigmoid(dot_mult * (conf + dot_add)); sim = mean_j (use_max = 0) or max_j (use_max = 1) of the cosine
- * similarity to the prototypes; score = soft_thresh * sim.  m * d <= 16384. */
+ * similarity to the prototypes; score = soft_thresh * sim.  m * d <= 16384.
+ * A proto_idx entry outside [0, n) is never dereferenced: every row of `score` and `sim` then comes back NaN (checked on
+ * the device, no host synchronisation; `soft_thresh` stays valid). */
 int effdet_novelty_score(void* stream, const float* embds, const float* confs, const long long* proto_idx, int n, int d, int m,
                          float dot_mult, float dot_add, int use_max, float* score, float* soft_thresh, float* sim);
 

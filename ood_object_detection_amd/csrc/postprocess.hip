@@ -848,15 +848,22 @@ __global__ __launch_bounds__(256) void novelty_score_kernel(const float* embds, 
                                                             float* score, float* soft_thresh, float* sim) {
     extern __shared__ float pl_[];                     // [m][d] normalised prototypes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int bad_;                               // a prototype index outside [0, n): never dereferenced (stale max_idxs, an
+    if (tid == 0) bad_ = 0;                            // index into another concatenation); every output row is poisoned with NaN
+    __syncthreads();
     for (int j = wave; j < m; j += 4) {
-        const float* row = embds + proto[j] * (long long)d;
+        const long long pj = proto[j];
+        const bool ok = pj >= 0 && pj < (long long)n;                 // wave-uniform
+        const float* row = embds + (ok ? pj : 0) * (long long)d;
+        if (!ok && lane == 0) bad_ = 1;
         float ss = 0.f;
         for (int c = lane; c < d; c += 64) { const float v = row[c]; ss += v * v; }
         ss = wave_reduce_sum(ss);
-        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        const float inv = ok ? 1.0f / fmaxf(sqrtf(ss), 1e-12f) : 0.f;
         for (int c = lane; c < d; c += 64) pl_[j * d + c] = row[c] * inv;
     }
     __syncthreads();
+    const float poison = bad_ ? __builtin_nanf("") : 0.f;
     for (long long i = (long long)blockIdx.x * 4 + wave; i < n; i += (long long)gridDim.x * 4) {
         const float* row = embds + i * d;
         float ss = 0.f;
@@ -873,7 +880,7 @@ __global__ __launch_bounds__(256) void novelty_score_kernel(const float* embds, 
         if (lane == 0) {
             const float st = 1.0f / (1.0f + expf(-(dot_mult * (confs[i] + dot_add))));
             const float sv = use_max ? acc_max : acc_sum / (float)m;
-            soft_thresh[i] = st; sim[i] = sv; score[i] = st * sv;
+            soft_thresh[i] = st; sim[i] = sv + poison; score[i] = st * sv + poison;
         }
     }
 }

@@ -93,3 +93,55 @@ class PipelinedPredict(object):
         out = self._out[k]
         self._out[k] = self._done[k] = self._ticket_of[k] = None
         return out
+
+
+class MixedPrecisionEfficientDet(torch.nn.Module):
+    """bfloat16 backbone, float32 BiFPN + heads: the point between the bf16 throughput mode and the float32 parity mode.
+
+    The backbone is ~76 % of the MACs and ~78 % of the per-layer bytes and runs on the bf16 kernels; its three
+    feature maps (P3 / P4 / P5, 0.56 M values per image at d0 / 640) are widened to float32 while they are copied into the
+    float32 engine's input buffers, and BiFPN, class / box heads, the OOD epilogue and everything behind them run in float32
+    from float32 master weights.  Built from ONE float32 model (the reference's `create_model(...)` result): the bf16 copy
+    keeps only what the backbone needs.  Behaves like an `EfficientDet` for `DetBenchPredict` (`config`, `ood_energy`,
+    `ood_max_logit`, `weights_token`, `prepare`); `forward(x)` = reference `mode='full_net'` (effdet/efficientdet.py:895-933).
+    """
+
+    def __init__(self, model_f32):
+        super().__init__()
+        p0 = model_f32.backbone.conv_stem.weight
+        if p0.dtype != torch.float32:
+            raise ValueError('MixedPrecisionEfficientDet is built from a float32 model')
+        self.tail = model_f32                                   # float32: BiFPN + heads (its backbone copy stays unused)
+        self.front = copy.deepcopy(model_f32).to(torch.bfloat16)  # bfloat16: backbone
+        self.config = model_f32.config
+        self.ood_energy = None
+        self.ood_max_logit = None
+
+    @property
+    def _engine(self):
+        return self.tail._engine
+
+    def weights_token(self):
+        return (self.front.weights_token(), self.tail.weights_token())
+
+    def prepare(self, batch_size, image_size=None, ood_out=None):
+        self.front.prepare(batch_size, image_size)
+        return self.tail.prepare(batch_size, image_size, ood_out=ood_out)
+
+    def __copy__(self):
+        # shallow copies share the parameters and get their own engines (what DetBenchPredict / PipelinedPredict rely on)
+        new = MixedPrecisionEfficientDet.__new__(MixedPrecisionEfficientDet)
+        torch.nn.Module.__init__(new)
+        new.tail, new.front, new.config = copy.copy(self.tail), copy.copy(self.front), self.config
+        new.ood_energy = new.ood_max_logit = None
+        return new
+
+    def forward(self, x, mode='full_net'):
+        if mode != 'full_net':
+            raise ValueError('the mixed-precision wrapper runs mode=\'full_net\' only')
+        with torch.no_grad():
+            feats = self.front(x if x.dtype == torch.uint8 else x.to(torch.bfloat16), mode='bb')
+            # engine_for() keeps an engine prepared for this batch / size / weights (split batches pass ood_out to prepare)
+            cls_o, box_o = self.tail(feats, mode='fpn_and_head')
+        self.ood_energy, self.ood_max_logit = self.tail.ood_energy, self.tail.ood_max_logit
+        return cls_o, box_o

@@ -73,3 +73,69 @@ def allreduce_gradients(tensors, bucket_bytes=32 << 20, average=True):
         bucket.append(t)
         size += nb
     flush()
+
+
+def rank_env(rank, world, port, base_env=None):
+    """Environment of one rank started by `launch_ranks` (the variables torch.distributed's env:// rendezvous reads)."""
+    import os
+    env = dict(os.environ if base_env is None else base_env)
+    env.update({'RANK': str(rank), 'LOCAL_RANK': str(rank), 'WORLD_SIZE': str(world), 'LOCAL_WORLD_SIZE': str(world),
+                'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port)})
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # the host driver only supports dmabuf IPC (RCCL needs it)
+    return env
+
+
+def launch_ranks(world, argv, port=None, timeout=None):
+    """Start `world` fresh processes `argv` (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), wait for all of
+    them and return the worst exit code.  The caller must not have touched the GPU: the children are plain child processes
+    (never an exec of this one), and this parent only waits.  If one rank fails the others are terminated (a rank that died
+    before the rendezvous would leave the rest waiting for it)."""
+    import socket
+    import subprocess
+    import time
+    if world < 1:
+        raise ValueError('world size must be >= 1')
+    if port is None:
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+    procs = [subprocess.Popen(list(argv), env=rank_env(r, world, port)) for r in range(world)]
+    t0, worst = time.time(), 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0:
+                worst = rc if worst == 0 else worst
+                for q in live:                                  # exact PIDs we started, nothing else
+                    q.terminate()
+        if timeout is not None and time.time() - t0 > timeout:
+            for q in live:
+                q.kill()
+            worst = worst or 124
+            break
+        time.sleep(0.05)
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except Exception:
+            p.kill()
+    return worst
+
+
+def resolve_world(gpus_arg, environ=None):
+    """(rank, local_rank, world, must_launch) for a `--gpus N` benchmark process.  WORLD_SIZE set (torchrun or `launch_ranks`
+    started us): it must equal --gpus, else ValueError.  WORLD_SIZE unset and --gpus N > 1: this process is the parent that has
+    to start N ranks itself (`must_launch`)."""
+    import os
+    env = os.environ if environ is None else environ
+    if 'WORLD_SIZE' in env:
+        world = int(env['WORLD_SIZE'])
+        if world != int(gpus_arg):
+            raise ValueError('--gpus %d but WORLD_SIZE=%d: start exactly --gpus ranks' % (gpus_arg, world))
+        return int(env.get('RANK', '0')), int(env.get('LOCAL_RANK', '0')), world, False
+    return 0, 0, int(gpus_arg), int(gpus_arg) > 1

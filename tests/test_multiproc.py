@@ -2,6 +2,8 @@
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -74,3 +76,42 @@ def test_two_ranks_gloo():
     assert all(o[3] and o[4] for o in out)
     assert all(o[5] == 2.0 for o in out)           # max over ranks of (1.0, 2.0)
     assert all(o[6] for o in out)                  # bucketed gradient all-reduce (mean)
+
+
+def _run_bench_parent(extra_args, env_extra=None, script='bench.py'):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env['EFFDET_BENCH_WORKER'] = os.path.join(root, 'tests', '_fake_bench_worker.py')
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, script)] + extra_args, env=env, capture_output=True, text=True, timeout=300)
+
+
+@pytest.mark.parametrize('script', ['bench.py', os.path.join('tools', 'pretrain_bench.py')])
+def test_bench_gpus_n_launches_n_ranks_itself(script):
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts two rank processes (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set) BEFORE touching the GPU - here a GPU-free worker over gloo - waits, and exits with the worst child code"""
+    import json
+    r = _run_bench_parent(['--gpus', '2', '--steps', '1', '--warmup', '0'], script=script)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['ranks']['answered_all_reduce'] == 2 and line['ranks']['world_size'] == 2
+    assert line['ranks']['per_rank_images_per_sec'] == [100.0, 101.0]
+    # a rank that dies takes the job down with its exit code (the other rank would wait for it in the rendezvous for ever)
+    r = _run_bench_parent(['--gpus', '2'], env_extra={'EFFDET_FAKE_FAIL_RANK': '1'}, script=script)
+    assert r.returncode == 7
+    # started by a launcher with the wrong number of ranks: refuse
+    r = _run_bench_parent(['--gpus', '2'], env_extra={'WORLD_SIZE': '3', 'RANK': '0', 'LOCAL_RANK': '0'}, script=script)
+    assert r.returncode != 0 and 'WORLD_SIZE=3' in (r.stderr + r.stdout)
+
+
+def test_resolve_world():
+    from ood_object_detection_amd.sharding import resolve_world
+    assert resolve_world(1, {}) == (0, 0, 1, False)
+    assert resolve_world(4, {}) == (0, 0, 4, True)
+    assert resolve_world(4, {'WORLD_SIZE': '4', 'RANK': '3', 'LOCAL_RANK': '3'}) == (3, 3, 4, False)
+    with pytest.raises(ValueError):
+        resolve_world(8, {'WORLD_SIZE': '1'})

@@ -4,6 +4,7 @@ synthetic ground truth (M ~ U{1..20} boxes per image, min side 16 px,
 the GPU, DDP = one RCCL all-reduce of the flat gradient buffer per step.
 
     python tools/pretrain_bench.py --steps 10 --warmup 3
+    python tools/pretrain_bench.py --gpus N            (starts N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/pretrain_bench.py --gpus N
 
 Rank 0 prints one JSON line: steps/s, images/s (whole job), ms per step (max over ranks), all-reduce ms."""
@@ -43,7 +44,16 @@ def main():
     ap.add_argument('--model', default='tf_efficientdet_d0')
     ap.add_argument('--graph', action='store_true', help='replay the iteration from one captured hipGraph')
     args = ap.parse_args()
-    rank, local_rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+    # --gpus N > 1 without a launcher: this process is the parent, starts N rank processes of this command before any
+    # torch.cuda call and exits with the worst child code; under a launcher WORLD_SIZE must equal --gpus (sharding.resolve_world)
+    from ood_object_detection_amd.sharding import launch_ranks, resolve_world
+    try:
+        rank, local_rank, world, must_launch = resolve_world(args.gpus)
+    except ValueError as e:
+        raise SystemExit('pretrain_bench.py: %s' % e)
+    if must_launch:
+        worker = os.environ.get('EFFDET_BENCH_WORKER', os.path.abspath(__file__))
+        sys.exit(launch_ranks(world, [sys.executable, worker] + sys.argv[1:]))
     if not torch.cuda.is_available():
         raise SystemExit('needs an MI355X: the product path has no CPU fallback')
     backend = os.environ.get('EFFDET_DIST_BACKEND', 'nccl')
@@ -83,10 +93,18 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     losses.append(out['loss'].item())
+    ranks_seen, per_rank = 1, [round(B * args.steps / elapsed, 2)]
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
+        cdev = dev if backend == 'nccl' else 'cpu'
+        rates = torch.zeros(world, device=cdev, dtype=torch.float64)
+        rates[rank] = B * args.steps / elapsed
+        t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        ones = torch.ones(1, device=cdev, dtype=torch.float64)
+        dist.all_reduce(ones)
+        dist.all_reduce(rates)
+        ranks_seen, per_rank = int(round(float(ones.item()))), [round(float(v), 2) for v in rates.tolist()]
     if rank == 0:
         print(json.dumps({
             'metric': 'pretrain steps/sec, %s %dpx float32 (forward + loss + backward + grad all-reduce + clip + Adam)' % (args.model, args.image),
@@ -98,6 +116,7 @@ def main():
                 args.model, args.image, args.image, B, args.classes), 'global_batch': world * B,
                 'parallelism': 'dp%d, one flat-gradient all-reduce per step' % world,
                 'launch': 'hipgraph' if args.graph else 'eager'},
+            'ranks': {'world_size': world, 'answered_all_reduce': ranks_seen, 'per_rank_images_per_sec': per_rank},
             'loss_first_last': [round(losses[0], 4), round(losses[-1], 4)],
             'peak_mem_GB': round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)}), flush=True)
     if dist is not None:
