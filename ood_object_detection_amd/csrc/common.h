@@ -169,6 +169,13 @@ __attribute__((visibility("hidden"))) int effdet_mbconv_roll_launch(hipStream_t 
                               const float* taps, const float* s2, const float* t2, float* pool_partial,
                               int B, int H, int W, int Cin, int mid, int k, int stride);
 
+// mbconv_wide.hip (internal): rolling-window form for inputs wider than 64 channels (X rows shared by a workgroup through an
+// LDS ring), bf16 only; parts = SE pool partial rows per image when the form applies to the geometry, 0 otherwise
+__attribute__((visibility("hidden"))) int effdet_mbconv_wide_parts(int H, int W, int Cin, int mid, int k, int stride);
+__attribute__((visibility("hidden"))) int effdet_mbconv_wide_launch(hipStream_t st, const void* X, void* Y, const void* W1, const float* s1, const float* t1,
+                              const float* taps, const float* s2, const float* t2, float* pool_partial,
+                              int B, int H, int W, int Cin, int mid, int k, int stride);
+
 // stem_roll.hip (internal): rolling-window form of the fused stem + stage-0 depthwise, bf16 only; parts = SE pool partial rows
 // per image when the form applies, 0 otherwise
 __attribute__((visibility("hidden"))) int effdet_stem_roll_parts(int H, int W, int C);

@@ -817,6 +817,10 @@ int launch_mb(hipStream_t st, MbArgs& a) {
         if (effdet_mbconv_roll_parts(a.H, a.W, a.Cin, a.mid, a.k, a.stride) > 0)
             return effdet_mbconv_roll_launch(st, a.X, a.in_gate, a.Y, a.W1, a.s1, a.t1, a.taps, a.s2, a.t2, a.pool_partial,
                                              a.B, a.H, a.W, a.Cin, a.mid, a.k, a.stride);
+        // wider inputs: the rolling-window form with the X rows shared through LDS (mbconv_wide.hip)
+        if (!a.in_gate && effdet_mbconv_wide_parts(a.H, a.W, a.Cin, a.mid, a.k, a.stride) > 0)
+            return effdet_mbconv_wide_launch(st, a.X, a.Y, a.W1, a.s1, a.t1, a.taps, a.s2, a.t2, a.pool_partial,
+                                             a.B, a.H, a.W, a.Cin, a.mid, a.k, a.stride);
     }
     const DeepGeometry dg = pick_deep<T>(a.H, a.W, a.Cin, a.mid, a.k, a.stride);
     if (dg.use && !a.in_gate) return launch_deep<T>(st, a, dg);                    // gated inputs always take the spatial form
@@ -847,7 +851,9 @@ extern "C" int effdet_mbconv_tiles_per_image(int dtype, int H, int W, int Cin, i
     if (H <= 0 || W <= 0 || Cin <= 0 || mid <= 0 || (k != 3 && k != 5) || (stride != 1 && stride != 2) || (dtype & ~1)) return EFFDET_EINVAL;
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
     if (dtype == 1) {
-        const int parts = effdet_mbconv_roll_parts(H, W, Cin, mid, k, stride);
+        int parts = effdet_mbconv_roll_parts(H, W, Cin, mid, k, stride);
+        if (parts > 0) return parts;
+        parts = effdet_mbconv_wide_parts(H, W, Cin, mid, k, stride);
         if (parts > 0) return parts;
     }
     const DeepGeometry dg = dtype == 0 ? pick_deep<float>(H, W, Cin, mid, k, stride) : pick_deep<bf16_t>(H, W, Cin, mid, k, stride);

@@ -145,7 +145,11 @@ def test_dwconv_se(dtype, C, H, W, k, s):
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('Cin,mid,H,W,k,s', [(16, 96, 40, 36, 3, 2), (24, 144, 22, 30, 3, 1), (24, 144, 33, 21, 5, 2),
                                              (40, 240, 20, 20, 5, 1), (112, 672, 10, 12, 5, 2), (192, 1152, 5, 5, 3, 1),
-                                             (80, 480, 40, 40, 3, 1), (112, 672, 40, 40, 5, 2), (192, 1152, 20, 20, 5, 1), (112, 680, 23, 17, 5, 1)])
+                                             (80, 480, 40, 40, 3, 1), (112, 672, 40, 40, 5, 2), (192, 1152, 20, 20, 5, 1), (112, 680, 23, 17, 5, 1),
+                                             # wide inputs on the shared-X rolling-window form (mbconv_wide.hip): every d0 late-stage shape, odd
+                                             # sizes, two column strips, several bands
+                                             (80, 480, 40, 40, 5, 1), (112, 672, 40, 40, 5, 1), (192, 1152, 20, 20, 3, 1), (112, 672, 37, 41, 5, 1),
+                                             (80, 480, 33, 40, 3, 2), (80, 480, 24, 64, 3, 1), (192, 1152, 13, 19, 5, 2)])
 def test_mbconv_expand_dw_fused(dtype, Cin, mid, H, W, k, s):
     """fused expand 1x1 + BN + SiLU -> depthwise + BN + SiLU + SE pool partials vs the oracle's separate ops"""
     import _hip
