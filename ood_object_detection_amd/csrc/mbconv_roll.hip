@@ -137,12 +137,14 @@ __global__ __launch_bounds__(512, (NKC <= 2 ? 4 : 3)) void mbconv_roll_kernel(Ro
         xoffl[t] = (inside && (NKC - 1) * 64 + kg * 16 < cbytes) ? ix * cbytes + (NKC - 1) * 64 + kg * 16 : OOB;
     }
     const char* dl[OTN];
+    const char* dlh[KS == 5 ? OTN : 1];                          // 5 x 5: base of a tap pair inside one window row (second tap = next pixel)
     int yoff[OTN];
 #pragma unroll
     for (int u = 0; u < OTN; ++u) {
         const int oxl = 16 * u + frow;
         const bool ok = oxl < tw;
         dl[u] = ring + (ok ? oxl * S * 32 : 0) + (kg & 1) * 16;   // invalid lanes read pixel 0 (finite), dropped at the store
+        if constexpr (KS == 5) dlh[u] = dl[u] + hi * 32;
         yoff[u] = ok ? ((ox0 + oxl) * mid + c0 + 4 * kg) * 2 : OOB;
     }
     // buffer descriptors of this image's X and Y (wave-uniform: kernel arguments and blockIdx only)
@@ -207,6 +209,59 @@ __global__ __launch_bounds__(512, (NKC <= 2 ? 4 : 3)) void mbconv_roll_kernel(Ro
         // them out of the row loop and spills; an opaque copy of the lane's tap selector keeps them (1 + NO adds per pair) here
         int hsel = hi;
         asm volatile("" : "+v"(hsel));
+        if constexpr (KS == 5) {
+            // 5 x 5 (round 3, as in mbconv_wide.hip): every tap pair is expanded ONCE per row and applied to all NO tiles (the row used
+            // to be walked in groups of two tiles, each re-expanding the 13 diagonal operands); the B operands of a batch of G pairs x
+            // NO tiles are requested before the batch's first MFMA and the operands are expanded while they travel; pairs whose two
+            // taps lie in one window row read at an immediate offset from `dl + hi * 32` (the second tap is the next pixel), only the
+            // two pairs that straddle rows select between two offsets
+            f32x4 acc[OTN];
+#pragma unroll
+            for (int u = 0; u < OTN; ++u) acc[u] = t2v;
+            constexpr int G = 8 / OTN < NPAIR ? 8 / OTN : NPAIR;      // 8 B-operand fragments in flight: the X rows prefetched for the next step keep 24 - 32 registers
+#pragma unroll
+            for (int p0 = 0; p0 < NPAIR; p0 += G) {
+                Frag<T> bq[G][OTN];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int pr = p0 + g;
+                    if (pr < NPAIR) {
+                        const int ta = 2 * pr, tb = 2 * pr + 1 < NTAP ? 2 * pr + 1 : 2 * pr;        // constants after unrolling
+                        const int offa = ((PH + ta / KS) % KS) * rowbytes + (ta % KS) * 32;
+                        const int offb = ((PH + tb / KS) % KS) * rowbytes + (tb % KS) * 32;
+                        const bool same_row = ta / KS == tb / KS;
+#pragma unroll
+                        for (int u = 0; u < OTN; ++u)
+                            bq[g][u] = ld_frag<T>(same_row ? dlh[u] + offa : dl[u] + offa + hsel * (offb - offa));
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int pr = p0 + g;
+                    if (pr < NPAIR) {
+                        unsigned bits = abits[pr];
+                        asm volatile("" : "+v"(bits));          // expanded at use: 13 resident operands (52 registers) do not fit
+                        const u32x4 fr = {dq == 0 ? bits : 0u, dq == 1 ? bits : 0u, dq == 2 ? bits : 0u, dq == 3 ? bits : 0u};
+                        Frag<T> af; af.v = __builtin_bit_cast(bf16x8, fr);
+#pragma unroll
+                        for (int u = 0; u < OTN; ++u) mma_chunk(af, bq[g][u], acc[u]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);              // batches stay batches: hoisting every read of the row would spill
+            }
+#pragma unroll
+            for (int u = 0; u < OTN; ++u) {
+                const f32x4 ov = silu4_fast(acc[u]);
+                const int yo = yoff[u];
+                const float vm = yo == OOB ? 0.f : 1.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pl[r] += ov[r] * vm;
+                typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+                typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+                const bf16x4_ ob = {(bf16_t)ov[0], (bf16_t)ov[1], (bf16_t)ov[2], (bf16_t)ov[3]};
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, ob), yrs, yo, yrow, 0);
+            }
+        } else {
 #pragma unroll
         for (int u0 = 0; u0 < OTN; u0 += OT) {
             {
@@ -244,6 +299,7 @@ __global__ __launch_bounds__(512, (NKC <= 2 ? 4 : 3)) void mbconv_roll_kernel(Ro
                     }
                 }
             }
+        }
         }
         yrow += ypitch;
         ++oy;
