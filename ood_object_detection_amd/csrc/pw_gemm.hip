@@ -32,13 +32,15 @@ struct PwArgs {
     int tiles_per_image, n_tiles, vec_ok;
 };
 
+template <int V> struct PwInt { static constexpr int value = V; };
+
 constexpr int PW_PIX = 128;                      // pixels per workgroup: 4 waves x 2 MFMA tiles, or 8 waves x 1 (small maps)
 constexpr int KCH = 2;                           // 64-byte K-chunks per pipeline stage
 
 // PT 16-pixel tiles per wave, NTH threads: (2, 256) normally; (1, 512) when the launch has fewer than two workgroups per
 // CU (20x20 maps) - twice the waves per SIMD to hide the per-stage latencies, at the price of reading each W
 // fragment from LDS once per 16 instead of once per 32 pixels
-template <typename T, int BN, int PT, int NTH>
+template <typename T, int BN, int PT, int NTH, bool GATED>
 DEV void pw_gemm_body(const PwArgs& p, const int bid) {
     constexpr int EPC = VecTraits<T>::EPC;          // elements per 16-byte piece
     constexpr int KPC = 64 / (int)sizeof(T);        // elements per 64-byte K-chunk
@@ -50,6 +52,7 @@ DEV void pw_gemm_body(const PwArgs& p, const int bid) {
     constexpr int ROWB = KCH * 64 + 16;             // bytes per LDS row: one stage of K + 16 pad
     constexpr int W_BYTES = BN * ROWB;
     __shared__ __attribute__((aligned(16))) char lds[2 * W_BYTES];
+    extern __shared__ __attribute__((aligned(16))) float gate_lds[];   // GATED: this image's SE gate, all K channels (dynamic: K floats)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fpiece = lane >> 4;
@@ -82,60 +85,66 @@ DEV void pw_gemm_body(const PwArgs& p, const int bid) {
 #pragma unroll
         for (int sub = 0; sub < KCH; ++sub) {
             const int off = (stg * KCH + sub) * 64 + fpiece * 16;
-            const bool ok = off < kbytes;
-            const int offc = ok ? off : 0;                   // a lane past the end of K re-reads the row start (always in bounds) and is zeroed below
+            // a lane past the end of K re-reads the row start (always in bounds, finite activations): its products meet the zeroed
+            // W pieces of the K tail.  No select on the loaded value here - it would make the stage wait for its own prefetch.
+            const int offc = off < kbytes ? off : 0;
 #pragma unroll
-            for (int i = 0; i < PT; ++i) {
-                Frag<T> f = ld_frag<T>(arow[i] + offc);
-                if (!ok) f.v = decltype(f.v){};
-                areg[slot][sub][i] = f;
-            }
+            for (int i = 0; i < PT; ++i) areg[slot][sub][i] = ld_frag<T>(arow[i] + offc);
         }
     };
 
     // ---- W staging: BN rows x 8 pieces per stage; gate folded in
     const char* Wb = reinterpret_cast<const char*>(p.W);
-    const float* gate = p.gate != nullptr ? p.gate + (long long)img * K : nullptr;
+    const float* gate = GATED ? p.gate + (long long)img * K : nullptr;
     constexpr int PPR = KCH * 4;
     constexpr int W_PER_THREAD = (BN * PPR + NTH - 1) / NTH;
     auto lds_row = [](int co) { return 16 * (2 * (co >> 5) + ((co >> 2) & 1)) + 4 * ((co >> 3) & 3) + (co & 3); };
     u32x4 w_reg[W_PER_THREAD];
-    f32x4 g_reg[W_PER_THREAD][2];
+    if constexpr (GATED) {                          // the gate goes to LDS once (published by the barrier in the prologue)
+        for (int k = tid * 4; k < K; k += NTH * 4) *reinterpret_cast<f32x4*>(gate_lds + k) = *reinterpret_cast<const f32x4*>(gate + k);
+    }
+    // Every load of the stage loop is UNCONDITIONAL (out-of-range pieces read a clamped, valid address and are zeroed by a
+    // select afterwards; stages past the end re-read the last one): with no exec-mask branch around a vector-memory operation
+    // the compiler counts them, and the wait for the W pieces of the next stage (`s_waitcnt vmcnt(N)` in front of their LDS
+    // store) leaves the younger A prefetch in flight.  vmcnt retires in issue order, so the W loads are issued BEFORE the A
+    // loads of the same stage; round 2 had them the other way round behind branches and drained everything (`vmcnt(0)`) once
+    // per stage - the A ring was never more than one stage deep (64 - 76 % of the wave cycles waiting on vector memory).
     auto w_load = [&](int stg) {                     // issues loads only
 #pragma unroll
         for (int q = 0; q < W_PER_THREAD; ++q) {
-            const int idx = tid + NTH * q;
+            const int idx = tid + NTH * q < BN * PPR ? tid + NTH * q : BN * PPR - 1;    // surplus threads duplicate the last piece
             const int co = idx / PPR, piece = idx % PPR;
             const int ke = stg * KCH * KPC + piece * EPC;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            f32x4 g0 = {1.f, 1.f, 1.f, 1.f}, g1 = g0;
-            if (idx < BN * PPR && co < n_count && ke < K) {
-                v = *reinterpret_cast<const u32x4*>(Wb + (long long)(n0 + co) * pitch + (long long)ke * sizeof(T));
-                if (gate != nullptr) {
-                    g0 = *reinterpret_cast<const f32x4*>(gate + ke);
-                    if constexpr (sizeof(T) == 2) g1 = *reinterpret_cast<const f32x4*>(gate + ke + 4);
-                }
-            }
-            w_reg[q] = v; g_reg[q][0] = g0; g_reg[q][1] = g1;
+            const bool ok = co < n_count && ke < K;
+            const int coc = ok ? co : 0, kec = ok ? ke : 0;
+            w_reg[q] = *reinterpret_cast<const u32x4*>(Wb + (long long)(n0 + coc) * pitch + (long long)kec * sizeof(T));
         }
     };
-    auto w_store = [&](int buf) {
+    auto w_store = [&](int buf, int stg) {            // the out-of-range pieces (N tail rows, K tail) become zeros HERE, not at the load
         char* Wd = lds + buf * W_BYTES;
 #pragma unroll
         for (int q = 0; q < W_PER_THREAD; ++q) {
-            const int idx = tid + NTH * q;
-            if (idx < BN * PPR) {
+            const int idx = tid + NTH * q < BN * PPR ? tid + NTH * q : BN * PPR - 1;
+            {
                 u32x4 v = w_reg[q];
-                if (gate != nullptr) {
+                // (a bitwise AND, not a select: a select lets the compiler sink the LOAD into the in-range branch, and a load behind an
+                // exec-mask branch ends every counted wait)
+                const unsigned keep = (idx / PPR < n_count && stg * KCH * KPC + (idx % PPR) * EPC < K) ? 0xFFFFFFFFu : 0u;
+                v = v & u32x4{keep, keep, keep, keep};
+                if constexpr (GATED) {
+                    const int kg_ = stg * KCH * KPC + (idx % PPR) * EPC;
+                    const int kgc = kg_ < K ? kg_ : 0;
+                    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gate_lds + kgc);
                     if constexpr (sizeof(T) == 4) {
                         f32x4 x = __builtin_bit_cast(f32x4, v);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) x[e] *= g_reg[q][0][e];
+                        for (int e = 0; e < 4; ++e) x[e] *= g0[e];
                         v = __builtin_bit_cast(u32x4, x);
                     } else {
+                        const f32x4 g1 = *reinterpret_cast<const f32x4*>(gate_lds + kgc + 4);
                         bf16x8 x = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) x[e] = (bf16_t)((float)x[e] * (e < 4 ? g_reg[q][0][e] : g_reg[q][1][e - 4]));
+                        for (int e = 0; e < 8; ++e) x[e] = (bf16_t)((float)x[e] * (e < 4 ? g0[e] : g1[e - 4]));
                         v = __builtin_bit_cast(u32x4, x);
                     }
                 }
@@ -150,39 +159,46 @@ DEV void pw_gemm_body(const PwArgs& p, const int bid) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // prologue: PF stages of A in flight, W stage 0 in LDS
-#pragma unroll
-    for (int s = 0; s < PF; ++s) if (s < nst) a_load(s, s);
+    // prologue: W stage 0 in LDS, PF stages of A in flight
     w_load(0);
-    w_store(0);
+#pragma unroll
+    for (int s = 0; s < PF; ++s) a_load(s < nst ? s : nst - 1, s);
+    if constexpr (GATED) __syncthreads();           // the gate's LDS copy is complete before the first W stage is folded with it
+    w_store(0, 0);
     __syncthreads();
 
     const int njp = (n_count + 31) / 32;               // 32-channel groups that hold real channels
-    for (int stg0 = 0; stg0 < nst; stg0 += PF + 1) {
+    // One pipeline stage; u = stage % (PF + 1) is the A ring slot (compile-time).  Branch-free: W pieces of stage + 1 first, then
+    // the A prefetch of stage + PF (in-order vmcnt: the wait for the former leaves the latter in flight), the MFMAs of this
+    // stage, the LDS copy of the next W stage, one barrier.
+    auto stage = [&](int stg, auto UC) {
+        constexpr int u = decltype(UC)::value;
+        w_load(stg + 1 < nst ? stg + 1 : nst - 1);
+        a_load(stg + PF < nst ? stg + PF : nst - 1, (u + PF) % (PF + 1));
+        const char* Ws = lds + (stg & 1) * W_BYTES;
 #pragma unroll
-        for (int u = 0; u < PF + 1; ++u) {              // slot index = stage % (PF + 1), compile-time per unrolled step
-            const int stg = stg0 + u;
-            if (stg < nst) {
-                if (stg + PF < nst) a_load(stg + PF, (u + PF) % (PF + 1));
-                if (stg + 1 < nst) w_load(stg + 1);
-                const char* Ws = lds + (stg & 1) * W_BYTES;
+        for (int sub = 0; sub < KCH; ++sub) {
 #pragma unroll
-                for (int sub = 0; sub < KCH; ++sub) {
-                    if (stg * KCH + sub < nkc) {
+            for (int j = 0; j < NT; ++j) {
+                const Frag<T> wf = ld_frag<T>(Ws + (16 * j + frow) * ROWB + sub * 64 + fpiece * 16);
 #pragma unroll
-                        for (int j = 0; j < NT; ++j) {
-                            if (j < 2 * njp) {
-                                const Frag<T> wf = ld_frag<T>(Ws + (16 * j + frow) * ROWB + sub * 64 + fpiece * 16);
-#pragma unroll
-                                for (int i = 0; i < PT; ++i) mma_chunk(wf, areg[u][sub][i], acc[i][j]);
-                            }
-                        }
-                    }
-                }
-                if (stg + 1 < nst) w_store((stg + 1) & 1);
-                __syncthreads();
+                for (int i = 0; i < PT; ++i) mma_chunk(wf, areg[u][sub][i], acc[i][j]);
             }
         }
+        w_store((stg + 1) & 1, stg + 1 < nst ? stg + 1 : nst - 1);   // (after the last stage: a copy nobody reads)
+        __syncthreads();
+    };
+    // whole groups of PF + 1 stages without a single guard (so every wait in them is counted), then at most PF tail stages
+    static_assert(PF == 2, "the stage groups below are written out for a three-slot A ring");
+    int stg = 0;
+    for (; stg + 3 <= nst; stg += 3) {
+        stage(stg, PwInt<0>{});
+        stage(stg + 1, PwInt<1>{});
+        stage(stg + 2, PwInt<2>{});
+    }
+    if (stg < nst) {
+        stage(stg, PwInt<0>{});
+        if (stg + 1 < nst) stage(stg + 1, PwInt<1>{});
     }
 
     // ---- epilogue in registers: per 32-channel group J this lane holds channels [32J + 8*fpiece, +8) of its pixels
@@ -244,9 +260,9 @@ DEV void pw_gemm_body(const PwArgs& p, const int bid) {
     }
 }
 
-template <typename T, int BN, int PT, int NTH>
+template <typename T, int BN, int PT, int NTH, bool GATED>
 __global__ __launch_bounds__(NTH, 2) void pw_gemm_kernel(PwArgs p) {
-    pw_gemm_body<T, BN, PT, NTH>(p, blockIdx.x);
+    pw_gemm_body<T, BN, PT, NTH, GATED>(p, blockIdx.x);
 }
 
 // Several independent GEMMs of one tile shape in ONE launch (the BiFPN's lateral 1x1 convs of the backbone features: six
@@ -259,7 +275,7 @@ __global__ __launch_bounds__(NTH, 2) void pw_gemm_group_kernel(PwGroupArgs g) {
     int i = 0;
 #pragma unroll
     for (int q = 1; q < PW_GROUP_MAX; ++q) if (q < g.n && (int)blockIdx.x >= g.first[q]) i = q;
-    pw_gemm_body<T, BN, PT, NTH>(g.p[i], (int)blockIdx.x - g.first[i]);
+    pw_gemm_body<T, BN, PT, NTH, false>(g.p[i], (int)blockIdx.x - g.first[i]);
 }
 
 template <typename T>
@@ -313,8 +329,11 @@ int launch_pw(hipStream_t st, PwArgs& a) {
     if (rc0) return rc0;
     dim3 grid((unsigned)blocks);
     const bool small = blocks < 512;                 // fewer than two workgroups per CU: 8 waves x 16 pixels each
-#define PW_LAUNCH(BN_) do { if (small && BN_ != 128) hipLaunchKernelGGL((pw_gemm_kernel<T, BN_ == 128 ? 96 : BN_, 1, 512>), grid, dim3(512), 0, st, a); /* the (128, 1, 512) instantiation spills */ \
-                            else hipLaunchKernelGGL((pw_gemm_kernel<T, BN_, 2, 256>), grid, dim3(256), 0, st, a); } while (0)
+    const bool gated = a.gate != nullptr;
+    const size_t dyn = gated ? ((size_t)a.K * 4 + 15) / 16 * 16 : 0;          // the SE gate's LDS copy
+#define PW_LAUNCH_G(BN_, G_) do { if (small && BN_ != 128) hipLaunchKernelGGL((pw_gemm_kernel<T, BN_ == 128 ? 96 : BN_, 1, 512, G_>), grid, dim3(512), dyn, st, a); /* the (128, 1, 512) instantiation spills */ \
+                            else hipLaunchKernelGGL((pw_gemm_kernel<T, BN_, 2, 256, G_>), grid, dim3(256), dyn, st, a); } while (0)
+#define PW_LAUNCH(BN_) do { if (gated) PW_LAUNCH_G(BN_, true); else PW_LAUNCH_G(BN_, false); } while (0)
     switch (bn) {
         case 32:  PW_LAUNCH(32); break;
         case 64:  PW_LAUNCH(64); break;
@@ -325,6 +344,7 @@ int launch_pw(hipStream_t st, PwArgs& a) {
         default: return EFFDET_EINVAL;
     }
 #undef PW_LAUNCH
+#undef PW_LAUNCH_G
     return effdet_check_launch();
 }
 
