@@ -97,23 +97,29 @@ template <typename T> DEV Raw8<T> pack8(const F8& f) {
     return r;
 }
 
-// 8 channels of input `in` (already offset to the image) at output-grid position (y, x)
+// 8 channels of input `in` (already offset to the image) at output-grid position (y, x), which the caller has clamped into the
+// map.  Every load here is UNCONDITIONAL: same-size and nearest-upsampled inputs differ by a shift only, and the 3x3/s2 max pool
+// reads clamped taps and replaces the out-of-map ones by -inf afterwards.  (Loads behind exec-mask branches made the compiler
+// wait for each one on the spot - `s_waitcnt vmcnt(0)` after every 16 bytes of the halo; rounds 1 - 2.)
 template <typename T>
 DEV Raw8<T> fetch_input(const T* base, const SepInput& in, int y, int x, int F, int c) {
-    if (in.mode == 0) return load_raw8<T>(base + (y * in.W + x) * F + c);
-    if (in.mode == 1) return load_raw8<T>(base + ((y >> 1) * in.W + (x >> 1)) * F + c);
+    if (in.mode != 2) {                                           // uniform per input
+        const int sh = in.mode == 1 ? 1 : 0;
+        return load_raw8<T>(base + ((y >> sh) * in.W + (x >> sh)) * F + c);
+    }
     F8 m = f8_fill(-INFINITY);
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
         const int iy = 2 * y + ky - in.pad_t;
-        if (iy < 0 || iy >= in.H) continue;
+        const int iyc = iy < 0 ? 0 : (iy >= in.H ? in.H - 1 : iy);
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int ix = 2 * x + kx - in.pad_l;
-            if (ix < 0 || ix >= in.W) continue;
-            const F8 v = load8<T>(base + (iy * in.W + ix) * F + c);
+            const int ixc = ix < 0 ? 0 : (ix >= in.W ? in.W - 1 : ix);
+            const F8 v = load8<T>(base + (iyc * in.W + ixc) * F + c);
+            const bool inside = iy == iyc && ix == ixc;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) m.v[e] = fmaxf(m.v[e], v.v[e]);
+            for (int e = 0; e < 8; ++e) m.v[e] = fmaxf(m.v[e], inside ? v.v[e] : -INFINITY);
         }
     }
     return pack8<T>(m);                          // a maximum of stored values: exactly representable
@@ -204,11 +210,13 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META ? 8 : 
     }
     const T* ib[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-        ib[i] = i < p.n_in ? reinterpret_cast<const T*>(L.in[i].ptr) + (long long)b * L.in[i].image_stride : nullptr;
+    for (int i = 0; i < 3; ++i) {                         // inputs a node does not have alias input 0 with weight 0 (their loads stay unconditional)
+        const int ii = i < p.n_in ? i : 0;
+        ib[i] = reinterpret_cast<const T*>(L.in[ii].ptr) + (long long)b * L.in[ii].image_stride;
+    }
     float fwm[3];                                         // per-input multiplier of the fused sum
 #pragma unroll
-    for (int i = 0; i < 3; ++i) fwm[i] = (sizeof(T) == 2 && p.fuse_mode == 1) ? p.fwn[i] : p.fw[i];
+    for (int i = 0; i < 3; ++i) fwm[i] = i < p.n_in ? ((sizeof(T) == 2 && p.fuse_mode == 1) ? p.fwn[i] : p.fw[i]) : 0.f;
     const bool divide = sizeof(T) == 4 && p.fuse_mode == 1;   // parity mode keeps the reference's (x*w)/sum order
 
     // ------------------------------------------------------------------ phases 1 + 2 per 64 channels
@@ -220,44 +228,49 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META ? 8 : 
         // trip count, so the compiler would otherwise expose one memory round trip per item)
         // bf16 tile: all 1440 items of a 64-channel pass in one batch; the 64-register variant (four workgroups per CU) keeps two
         // batches when a node fuses several inputs
-        constexpr int HU = NTH == 512 ? ((FT == 64 && !OOD && !META && NIN > 1) ? 2 : 3) : 2;
+        constexpr int HU = NTH == 512 ? ((FT == 64 && !OOD && !META && NIN > 1) ? 1 : ((FT == 0 && NIN > 1) ? 2 : 3)) : 2;
         for (int it0 = tid; it0 < HW_ * fcg; it0 += HU * NTH) {
             Raw8<T> xin[HU][NIN];
-            bool ok[HU];
+            unsigned okm[HU];
 #pragma unroll
             for (int u = 0; u < HU; ++u) {
-                const int it = it0 + NTH * u;
+                // every item loads - pixels outside the map from the clamped position, surplus items the last item again - and
+                // is masked afterwards: no exec-mask branch around a load, so all HU x NIN loads of the batch are in flight together
+                const int it_ = it0 + NTH * u;
+                const int it = it_ < HW_ * fcg ? it_ : HW_ * fcg - 1;
                 const int cgh = it % fcg, hp = it / fcg;
                 const int y = y0 + hp / (TW + 2) - 1, x = x0 + hp % (TW + 2) - 1;
-                ok[u] = it < HW_ * fcg && y >= 0 && y < H && x >= 0 && x < W;
-                if (ok[u]) {
-                    const int c = fc0 + cgh * 8;
+                const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y), xc = x < 0 ? 0 : (x >= W ? W - 1 : x);
+                okm[u] = (it_ < HW_ * fcg && y == yc && x == xc) ? 0xFFFFFFFFu : 0u;
+                const int c = fc0 + cgh * 8;
 #pragma unroll
-                    for (int i = 0; i < NIN; ++i)
-                        if (i < p.n_in) xin[u][i] = fetch_input<T>(ib[i], L.in[i], y, x, F, c);
-                }
+                for (int i = 0; i < NIN; ++i) xin[u][i] = fetch_input<T>(ib[i], L.in[i < p.n_in ? i : 0], yc, xc, F, c);
             }
 #pragma unroll
             for (int u = 0; u < HU; ++u) {
                 const int it = it0 + NTH * u;
-                if (it >= HW_ * fcg) continue;
                 const int cgh = it % fcg, hp = it / fcg;
+                const u32x4 km = {okm[u], okm[u], okm[u], okm[u]};
                 F8 v = f8_zero();
-                if (ok[u]) {
+                {
                     if (p.fuse_mode == 0) {
-                        v = unpack8<T>(xin[u][0]);
+                        Raw8<T> r0 = xin[u][0];
+                        r0.v[0] = r0.v[0] & km;
+                        if constexpr (sizeof(T) == 4) r0.v[1] = r0.v[1] & km;
+                        v = unpack8<T>(r0);
                     } else {
 #pragma unroll
                         for (int i = 0; i < NIN; ++i) {
-                            if (i < p.n_in) {
-                                const F8 xi = unpack8<T>(xin[u][i]);
-                                if (divide) {
+                            Raw8<T> ri = xin[u][i];
+                            ri.v[0] = ri.v[0] & km;
+                            if constexpr (sizeof(T) == 4) ri.v[1] = ri.v[1] & km;
+                            const F8 xi = unpack8<T>(ri);
+                            if (divide) {
 #pragma unroll
-                                    for (int e = 0; e < 8; ++e) v.v[e] += (xi.v[e] * fwm[i]) / p.fden;
-                                } else {
+                                for (int e = 0; e < 8; ++e) v.v[e] += (xi.v[e] * fwm[i]) / p.fden;
+                            } else {
 #pragma unroll
-                                    for (int e = 0; e < 8; ++e) v.v[e] = fmaf(xi.v[e], fwm[i], v.v[e]);
-                                }
+                                for (int e = 0; e < 8; ++e) v.v[e] = fmaf(xi.v[e], fwm[i], v.v[e]);
                             }
                         }
                     }
@@ -266,7 +279,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META ? 8 : 
                             const F8 is = load8<float>(p.in_scale + (long long)L.in_affine_row * F + fc0 + cgh * 8);
                             const F8 it = load8<float>(p.in_shift + (long long)L.in_affine_row * F + fc0 + cgh * 8);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v.v[e] = v.v[e] * is.v[e] + it.v[e];
+                            for (int e = 0; e < 8; ++e) v.v[e] = okm[u] ? v.v[e] * is.v[e] + it.v[e] : 0.f;
                         }
                     }
                     if (p.pre_act) {
@@ -274,7 +287,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META ? 8 : 
                         for (int e = 0; e < 8; ++e) v.v[e] = silu_t<T>(v.v[e]);
                     }
                 }
-                store8<T>(reinterpret_cast<T*>(halo) + hp * HROW + cgh * 8, v);
+                if (it < HW_ * fcg) store8<T>(reinterpret_cast<T*>(halo) + hp * HROW + cgh * 8, v);
             }
         }
         if (fc0 == 0) {
