@@ -149,7 +149,12 @@ DEV void store_piece(T* dst, const float (&v)[8], int nvalid, bool vec_ok) {
 }
 
 // FT: the channel count when known at compile time (all index arithmetic folds), 0 = read it from the arguments
-template <typename T, int TH, int TW, int BN, bool OOD, int NTH, int FT, bool META = false, int NIN = 3>
+// BST (class predict, bf16, dword-aligned rows): every vector-memory operation of the chunk loop is unconditional - W pieces and
+// affine constants are fetched from clamped addresses and masked at their LDS store, logits and OOD scores leave through buffer
+// stores whose out-of-range lanes / tail dwords get an offset beyond num_records (dropped by the hardware) - so the wait for the
+// next chunk's W prefetch is a counted `vmcnt(N)` that does not drain the chunk's own stores (the exec-mask branches around them
+// made it `vmcnt(0)`: every chunk waited for its 884 MB share to be acknowledged before the next could start).
+template <typename T, int TH, int TW, int BN, bool OOD, int NTH, int FT, bool META = false, int NIN = 3, bool BST = false>
 __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META ? 8 : 4) : 2) void sepconv_kernel(SepArgs p) {
     constexpr int BM = TH * TW;
     constexpr int HW_ = (TH + 2) * (TW + 2);
@@ -399,6 +404,20 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META ? 8 : 
     auto w_fetch = [&](int ch) {                        // global -> registers (in flight across the epilogue)
         int n_begin, n_count;
         chunk_range(ch, n_begin, n_count);
+        if constexpr (BST) {
+#pragma unroll
+            for (int q = 0; q < WPC; ++q) {
+                const int i = tid + NTH * q < BN * ppr ? tid + NTH * q : BN * ppr - 1;
+                const int co = i / ppr, piece = i % ppr;
+                const bool ok = co < n_count && piece * 16 < fbytes;
+                wpre[q] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.pw_w) +
+                                                          (long long)(n_begin + (ok ? co : 0)) * fbytes + (ok ? piece * 16 : 0));
+            }
+            const int tc = tid < n_count ? tid : 0;
+            cpre_t = shift[n_begin + tc];
+            cpre_s = scale ? scale[n_begin + tc] : 1.0f;      // uniform
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < WPC; ++q) {
             const int i = tid + NTH * q;
@@ -428,6 +447,15 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META ? 8 : 
         pix_in[i] = y < H && x < W;
         pix_off[i] = (y * W + x) * N;
     }
+    // BST: buffer descriptors of this image's level rows (logits) and of its OOD score rows
+    __amdgpu_buffer_rsrc_t ors, ers, mrs;
+    if constexpr (BST) {
+        ors = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(out), 0, H * W * N * 2, 0x00020000);
+        ers = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.ood_energy + (long long)b * p.ood_image_stride + L.ood_off), 0,
+                                                H * W * p.num_anchors * 4, 0x00020000);
+        mrs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.ood_maxlogit + (long long)b * p.ood_image_stride + L.ood_off), 0,
+                                                H * W * p.num_anchors * 4, 0x00020000);
+    }
     float run_m[WPT], run_s[WPT];                      // running max / sum-exp over the sub-chunks of an anchor
     constexpr float LOG2E = 1.4426950408889634f;
 
@@ -448,7 +476,17 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META ? 8 : 
                 }
             }
         }
-        if (prefetch) {
+        if (BST) {
+            // the clamped fetch is masked here (a bitwise AND keeps the load unconditional; surplus threads repeat the last piece)
+#pragma unroll
+            for (int q = 0; q < WPC; ++q) {
+                const int i = tid + NTH * q < BN * ppr ? tid + NTH * q : BN * ppr - 1;
+                const int co = i / ppr, piece = i % ppr;
+                const unsigned keep = (co < n_count && piece * 16 < fbytes) ? 0xFFFFFFFFu : 0u;
+                *reinterpret_cast<u32x4*>(Wt + lds_row(co) * arow + piece * 16) = wpre[q] & u32x4{keep, keep, keep, keep};
+            }
+            if (tid < BN) { cs[tid] = tid < n_count ? cpre_s : 1.0f; cs[BN + tid] = tid < n_count ? cpre_t : 0.0f; }
+        } else if (prefetch) {
 #pragma unroll
             for (int q = 0; q < WPC; ++q) {
                 const int i = tid + NTH * q;
@@ -525,7 +563,25 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META ? 8 : 
                     }
                     const bool group_full = 32 * J + 32 <= n_count;     // uniform: only the last group of a chunk has a tail
                     const int nvalid = group_full ? 8 : n_count - cb;
+                    if constexpr (BST) {
+                        // 8 channels = 16 bytes at a dword-aligned offset of this level's rows; a lane outside the map, a piece past
+                        // the chunk's channels or a tail dword gets the out-of-range offset and is dropped
+                        constexpr int OOB = 0x7FFFFFF0;
+                        const int boff = (pix_off[i] + n_begin + cb) * 2;
+                        bf16x8 a8;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) a8[e] = (bf16_t)vals[J][e];
+                        const u32x4 pk = __builtin_bit_cast(u32x4, a8);
+                        __builtin_amdgcn_raw_buffer_store_b128(pk, ors, (pix_in[i] && nvalid >= 8) ? boff : OOB, 0, 0);
+#pragma unroll
+                        for (int d = 0; d < 3; ++d)             // tail of the chunk: up to three whole dwords (the class count is even)
+                            __builtin_amdgcn_raw_buffer_store_b32(pk[d], ors, (pix_in[i] && nvalid < 8 && 2 * d < nvalid) ? boff + 4 * d : OOB, 0, 0);
+                    } else
+#ifndef SEP_ABLATE_NOSTORE            /* variant build for timing only (make variant ... VDEFS=-DSEP_ABLATE_NOSTORE) */
                     if (pix_in[i] && nvalid > 0) {
+#else
+                    if (pix_in[i] && nvalid > 0 && !OOD) {
+#endif
                         if (sizeof(T) == 2 && p.out_f32)
                             store_piece<float>(reinterpret_cast<float*>(L.out) + (long long)b * L.out_image_stride + pix_off[i] + n_begin + cb,
                                                vals[J], nvalid, true);
@@ -578,6 +634,13 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META ? 8 : 
                     pm = nm;
                 }
                 run_m[i] = pm; run_s[i] = ps;
+                if constexpr (BST) {
+                    constexpr int OOB = 0x7FFFFFF0;
+                    const int a = ch / subs;
+                    const int eo = (sc == subs - 1 && pix_in[i] && fpiece == 0) ? ((pix_off[i] / N) * p.num_anchors + a) * 4 : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, -(pm + logf(ps))), ers, eo, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pm), mrs, eo, 0, 0);
+                } else
                 if (sc == subs - 1 && pix_in[i] && fpiece == 0) {
                     const int a = ch / subs;
                     const long long idx = (long long)b * p.ood_image_stride + L.ood_off +
@@ -626,7 +689,7 @@ size_t sep_lds_bytes(int F, bool cp = false) {
     return (halo > wt ? halo : wt) + (size_t)BM * arow + (size_t)9 * F * 4 + (size_t)2 * BN * 4;
 }
 
-template <typename T, int TH, int TW, int BN, bool OOD, int NTH, int FT, bool META = false, int NIN = 3>
+template <typename T, int TH, int TW, int BN, bool OOD, int NTH, int FT, bool META = false, int NIN = 3, bool BST = false>
 int launch_sep(hipStream_t st, SepArgs& a, int B) {
     int tiles = 0;
     for (int i = 0; i < a.nlevels; ++i) {
@@ -638,7 +701,7 @@ int launch_sep(hipStream_t st, SepArgs& a, int B) {
     const size_t lds = sep_lds_bytes<T, TH, TW, BN>(a.F, sizeof(T) == 2 && TW == 16 && NTH == 512 && FT == 64 && !META) + (META ? (size_t)(NTH / 64) * 2 * BN * 4 : 0);   // + statistics scratch
     if (lds > 160 * 1024) return EFFDET_EINVAL;
     a.tiles_total = tiles;
-    auto kern = sepconv_kernel<T, TH, TW, BN, OOD, NTH, FT, META, NIN>;
+    auto kern = sepconv_kernel<T, TH, TW, BN, OOD, NTH, FT, META, NIN, BST>;
     if (lds > 64 * 1024) {
         static bool attr_done = false;           // one per template instantiation
         if (!attr_done) {
@@ -658,6 +721,12 @@ int dispatch_sep_f(hipStream_t st, SepArgs& a, int B) {
         // d5, 288 channels) take 64-row chunks - two sub-chunks per anchor, the running max / sum-exp carries over
         if constexpr (FT == 0) {
             if (sep_lds_bytes<T, TH, TW, 96>(a.F) > 160 * 1024) return launch_sep<T, TH, TW, 64, true, NTH, FT>(st, a, B);
+        }
+        if constexpr (sizeof(T) == 2 && NTH == 512) {
+            // bf16 with dword-aligned class rows (an even class count): the branch-free chunk loop
+            // (and a W chunk every thread can prefetch in two pieces: up to 64 channels - wider heads stay on the general loop)
+            if (a.vec_ok && !a.out_f32 && a.ood_classes % 2 == 0 && a.ood_classes <= 96 && a.F <= 64)
+                return launch_sep<T, TH, TW, 96, true, NTH, FT, false, 3, true>(st, a, B);
         }
         return launch_sep<T, TH, TW, 96, true, NTH, FT>(st, a, B);
     }
