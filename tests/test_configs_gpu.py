@@ -178,9 +178,16 @@ def test_bf16_detection_agreement_on_the_bench_model():
     print('bf16 vs f32 detections on the bench model:', res)
     # this network's logits span +-0.15 (every score ~ 0.5): top-k and NMS decide between near-ties, so only about half of the
     # kept detections coincide; the ones that do, and ALL of them on equal candidates, must agree closely
-    assert res['matched_frac'] >= 0.4
-    assert res['scores_linf'] <= 2e-3 and res['boxes_linf_px'] <= 4.0
-    assert res['same_candidates']['scores_linf'] <= 2e-3 and res['same_candidates']['boxes_linf_px'] <= 4.0
+    # bounds = 1.5 x the values measured on MI355X in round 3 (matched 0.59, boxes 0.46 px, scores 2.1e-4; kept in
+    # profiles/r03_*_bench_line.json as `parity_bf16`): a regression guard derived from measurements, tight enough to fail on a
+    # wrong tile or a dropped rounding
+    assert res['matched_frac'] >= 0.45
+    assert res['scores_linf'] <= 3.2e-4 and res['boxes_linf_px'] <= 0.70
+    assert res['same_candidates']['scores_linf'] <= 3.2e-4 and res['same_candidates']['boxes_linf_px'] <= 0.70
+    # the mixed mode (bfloat16 backbone, float32 BiFPN + heads): measured 0.98 matched, 0.007 px, 1e-6
+    mix = B.parity_bf16(model, x, DEV, candidate='mixed')
+    print('mixed vs f32 detections on the bench model:', mix)
+    assert mix['matched_frac'] >= 0.9 and mix['same_candidates']['boxes_linf_px'] <= 0.02 and mix['same_candidates']['scores_linf'] <= 1e-5
 
 
 def test_bf16_detection_agreement_calibrated_network():
@@ -191,5 +198,6 @@ def test_bf16_detection_agreement_calibrated_network():
     x = torch.from_numpy(seeded_array(12, 'input', (4, 3, 512, 512)))
     res = B.parity_bf16(model, x, DEV)
     print('bf16 vs f32 detections on the calibrated network:', res)
+    # measured in round 3 (bench line `parity_bf16_calibrated`): matched 0.905, boxes 1.25 px, scores 0.0099; bounds = 1.5 x
     assert res['matched_frac'] >= 0.8
-    assert res['same_candidates']['scores_linf'] <= 0.05 and res['same_candidates']['boxes_linf_px'] <= 8.0
+    assert res['same_candidates']['scores_linf'] <= 0.015 and res['same_candidates']['boxes_linf_px'] <= 1.9

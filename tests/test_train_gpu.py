@@ -536,6 +536,79 @@ def test_pretrain_step_hipgraph_matches_eager():
         assert torch.equal(runs[0][2][n], runs[1][2][n]), n
 
 
+def test_pretrain_step_config5_size_640px_8_images():
+    """BASELINE config 5 at its own size (d0, 640 px, 8 images per GPU): the 640-px grids of the training kernels (gemm_tn, column
+    reductions, reduce_mid) meet assertions - the training forward's loss equals the oracle's loss on the same batch to 1e-4
+    relative (BatchNorm in batch-statistics mode for BiFPN / heads, as pretrain.py runs it), every gradient is finite and non-zero
+    somewhere, and the captured hipGraph replays the eager iteration bit for bit."""
+    from oracle import model as om
+    from oracle import train as ot
+    from ood_object_detection_amd.effdet.loss import DetectionLoss
+    from ood_object_detection_amd.pretrain import PretrainStep
+    size, B, C = 640, 8, 90
+    model, cfg, nodes, sd, x = _train_setup(size, B, C, seed=41)
+    rs = np.random.RandomState(12)
+    cls_t, box_t = [], []
+    for l in range(cfg.num_levels):
+        s_ = size // (2 ** (cfg.min_level + l))
+        cls_t.append(torch.from_numpy(rs.choice([-2, -1, -1, -1, -1, -1, 0, 3, C - 1], size=(B, s_, s_, 9)).astype(np.int64)))
+        t = rs.normal(0, 0.2, (B, s_, s_, 36)).astype(np.float32)
+        t[rs.uniform(size=t.shape) < 0.7] = 0.0
+        box_t.append(torch.from_numpy(t))
+    npos = torch.tensor([7.0, 4.0, 9.0, 3.0, 11.0, 6.0, 5.0, 8.0])
+    om.BN_BATCH_STATS_PREFIXES = ('fpn.', 'class_net.', 'box_net.')
+    try:
+        with torch.no_grad():
+            info = om.backbone_feature_info(cfg.backbone_name)
+            feats = om.backbone_forward(sd, cfg.backbone_name, x, pad_type=cfg.pad_type)
+            activs = om.bifpn_forward(sd, cfg, feats, nodes, info)
+            cls_r, box_r = om.head_forward(sd, cfg, activs, 'class_net.'), om.head_forward(sd, cfg, activs, 'box_net.')
+            total_r, _, _ = ot.detection_loss(cls_r, box_r, cls_t, box_t, npos, C, 0.15, 0.1, 50.0)
+    finally:
+        om.BN_BATCH_STATS_PREFIXES = ()
+    model = model.to(DEV).float().train()
+    model.backbone.apply(lambda m: m.eval() if isinstance(m, torch.nn.BatchNorm2d) else None)      # pretrain.py:168-176
+    cfg.alpha, cfg.box_loss_weight = 0.15, 50.0
+    cls_o, box_o = model(x.to(DEV))
+    total, _, _ = DetectionLoss(cfg)(cls_o, box_o, [t.to(DEV) for t in cls_t], [t.to(DEV) for t in box_t], npos.to(DEV))
+    total.backward()
+    torch.cuda.synchronize()
+    rel = abs(total.item() - float(total_r)) / abs(float(total_r))
+    print('config-5 size: loss %.6f (oracle %.6f), rel %.2e' % (total.item(), float(total_r), rel))
+    assert rel <= 1e-4, (total.item(), float(total_r))
+    n_grads = 0
+    for n, p_ in model.named_parameters():
+        assert p_.grad is not None, n
+        assert bool(torch.isfinite(p_.grad).all()), n
+        n_grads += int(float(p_.grad.abs().max()) > 0.0)
+    assert n_grads >= 440                                       # all 460 tensors receive gradient (a few may be exactly 0 by masking)
+    del cls_o, box_o, total
+    model.zero_grad(set_to_none=True)
+    # graph == eager at this size (uint8 input + labels assigned on the device, the benchmarked arrangement)
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randint(0, 256, (B, 3, size, size), generator=g, dtype=torch.uint8).to(DEV) for _ in range(4)]
+    boxes, cls = [], []
+    for i in range(B):
+        m = 1 + i % 5
+        y0 = torch.rand(m, generator=g) * 400; x0 = torch.rand(m, generator=g) * 400
+        boxes.append(torch.stack([y0, x0, y0 + 40 + torch.rand(m, generator=g) * 180, x0 + 40 + torch.rand(m, generator=g) * 180], 1).to(DEV))
+        cls.append(torch.randint(1, C + 1, (m,), generator=g).to(DEV))
+    target = {'bbox': boxes, 'cls': cls}
+    runs = []
+    for graph in (False, True):
+        m2, _, _, _, _ = _train_setup(size, B, C, seed=41)
+        m2 = m2.to(DEV).float()
+        step = PretrainStep(m2, graph=graph, graph_warmup=2)
+        hist = [(o['loss'].item(), o['grad_norm'].item()) for o in (step(xb, target) for xb in xs)]
+        assert all(np.isfinite(v) for h in hist for v in h), hist
+        runs.append((hist, {n: p_.detach().clone() for n, p_ in m2.named_parameters()}))
+        del step, m2
+        torch.cuda.empty_cache()
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    for n in runs[0][1]:
+        assert torch.equal(runs[0][1][n], runs[1][1][n]), n
+
+
 def test_pretrain_ddp_two_ranks_share_gpu():
     """two data-parallel ranks (gloo, sharing this GPU): replicas stay bit-identical, graph path == eager path (tools/ddp_check.py)"""
     import os
