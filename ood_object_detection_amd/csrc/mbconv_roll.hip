@@ -55,7 +55,7 @@ template <int KS, int S, int NKC, int MT, int NO>
 __global__ __launch_bounds__(512, (NKC <= 2 ? 4 : 3)) void mbconv_roll_kernel(RollArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     typedef bf16_t T;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: everything derived from it stays scalar
     const int frow = lane & 15, kg = lane >> 4;
     // blocks are dealt round-robin over the 8 XCDs: image = (round, xcd), so one image's workgroups share an L2
     const int xcd = blockIdx.x & 7, rr_ = blockIdx.x >> 3;

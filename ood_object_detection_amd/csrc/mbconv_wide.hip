@@ -77,7 +77,7 @@ __global__ __launch_bounds__(1024, 4) void mbconv_wide_kernel(WideArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     typedef bf16_t T;
     constexpr int NSX = 2 * S;                                 // X ring slots (rows)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: everything derived from it stays scalar
     const int frow = lane & 15, kg = lane >> 4;
     // blocks are dealt round-robin over the 8 XCDs: image = (round, xcd), so one image's workgroups share an L2
     const int xcd = blockIdx.x & 7, rr_ = blockIdx.x >> 3;

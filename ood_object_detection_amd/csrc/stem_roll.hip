@@ -52,7 +52,11 @@ template <int IN, int NJ>
 __global__ __launch_bounds__(512, 4) void stem_roll_kernel(SrArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     typedef bf16_t T;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // readfirstlane: the wave index is wave-uniform, but the compiler cannot know that of threadIdx.x >> 6 - and this kernel's band
+    // and strip (hence the scalar offsets of every buffer load and store) derive from it.  Left as a vector value each buffer
+    // operation was wrapped in a waterfall loop (readfirstlane + exec mask + branch) and waited for on the spot: the input rows
+    // "fetched three steps ahead" were in fact loaded one dword at a time with `s_waitcnt vmcnt(0)` after each (rounds 1 - 2).
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int frow = lane & 15, kg = lane >> 4;
     const int xcd = blockIdx.x & 7, rr_ = blockIdx.x >> 3;
     const int b = (rr_ / p.per_image) * 8 + xcd;
