@@ -34,6 +34,9 @@ struct PwArgs {
 
 template <int V> struct PwInt { static constexpr int value = V; };
 
+#ifndef PW_PF_SMALL
+#define PW_PF_SMALL 2            /* measured on d0 blocks 5.x: four stages 0.042 ms, two stages 0.035 ms */
+#endif
 constexpr int PW_PIX = 128;                      // pixels per workgroup: 4 waves x 2 MFMA tiles, or 8 waves x 1 (small maps)
 constexpr int KCH = 2;                           // 64-byte K-chunks per pipeline stage
 
@@ -48,7 +51,8 @@ DEV void pw_gemm_body(const PwArgs& p, const int bid) {
     static_assert(NT % 2 == 0, "tile pairs");
     // A stages (128 bytes of K per pixel) in flight ahead of the one being multiplied: as many as the registers
     // left over by the accumulators allow - the late layers are latency bound, not bandwidth bound
-    constexpr int PF = 2;                           // (5 stages for the narrow tiles measured slower: fewer waves fit)
+    // two stages everywhere; PW_PF_SMALL = 4 (a variant build) deepens the ring of the 512-thread small-map form - measured slower
+    constexpr int PF = (PT == 1 && NTH == 512) ? PW_PF_SMALL : 2;
     constexpr int ROWB = KCH * 64 + 16;             // bytes per LDS row: one stage of K + 16 pad
     constexpr int W_BYTES = BN * ROWB;
     __shared__ __attribute__((aligned(16))) char lds[2 * W_BYTES];
@@ -189,16 +193,28 @@ DEV void pw_gemm_body(const PwArgs& p, const int bid) {
         __syncthreads();
     };
     // whole groups of PF + 1 stages without a single guard (so every wait in them is counted), then at most PF tail stages
-    static_assert(PF == 2, "the stage groups below are written out for a three-slot A ring");
+    static_assert(PF == 2 || PF == 4, "the stage groups below are written out for three- and five-slot A rings");
     int stg = 0;
-    for (; stg + 3 <= nst; stg += 3) {
+    for (; stg + PF + 1 <= nst; stg += PF + 1) {
         stage(stg, PwInt<0>{});
         stage(stg + 1, PwInt<1>{});
         stage(stg + 2, PwInt<2>{});
+        if constexpr (PF == 4) {
+            stage(stg + 3, PwInt<3>{});
+            stage(stg + 4, PwInt<4>{});
+        }
     }
     if (stg < nst) {
         stage(stg, PwInt<0>{});
-        if (stg + 1 < nst) stage(stg + 1, PwInt<1>{});
+        if (stg + 1 < nst) {
+            stage(stg + 1, PwInt<1>{});
+            if constexpr (PF == 4) {
+                if (stg + 2 < nst) {
+                    stage(stg + 2, PwInt<2>{});
+                    if (stg + 3 < nst) stage(stg + 3, PwInt<3>{});
+                }
+            }
+        }
     }
 
     // ---- epilogue in registers: per 32-channel group J this lane holds channels [32J + 8*fpiece, +8) of its pixels
