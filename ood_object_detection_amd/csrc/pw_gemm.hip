@@ -38,13 +38,17 @@ template <int V> struct PwInt { static constexpr int value = V; };
 #define PW_PF_SMALL 2            /* measured on d0 blocks 5.x: four stages 0.042 ms, two stages 0.035 ms */
 #endif
 constexpr int PW_PIX = 128;                      // pixels per workgroup: 4 waves x 2 MFMA tiles, or 8 waves x 1 (small maps)
-constexpr int KCH = 2;                           // 64-byte K-chunks per pipeline stage
+#ifndef PW_KCH_SMALL
+#define PW_KCH_SMALL 2
+#endif
 
 // PT 16-pixel tiles per wave, NTH threads: (2, 256) normally; (1, 512) when the launch has fewer than two workgroups per
 // CU (20x20 maps) - twice the waves per SIMD to hide the per-stage latencies, at the price of reading each W
 // fragment from LDS once per 16 instead of once per 32 pixels
 template <typename T, int BN, int PT, int NTH, bool GATED>
 DEV void pw_gemm_body(const PwArgs& p, const int bid) {
+    // 64-byte K-chunks per pipeline stage (PW_KCH_SMALL: the 512-thread small-map form; 4 in a variant build for A/B timing)
+    constexpr int KCH = (PT == 1 && NTH == 512) ? PW_KCH_SMALL : 2;
     constexpr int EPC = VecTraits<T>::EPC;          // elements per 16-byte piece
     constexpr int KPC = 64 / (int)sizeof(T);        // elements per 64-byte K-chunk
     constexpr int NT = BN / 16, NP = NT / 2;

@@ -8,7 +8,7 @@ the profiled command dispatched (bench.py --steps 5 --warmup 2 --no-graph: 7 + 1
 per-launch profiling pass = 16 dispatches per launch site)."""
 import json, sys
 
-FAMILIES = {'mbconv': ('mbconv_front_kernel', 'mbconv_deep_kernel', 'mbconv_roll_kernel'), 'sepconv': ('sepconv_kernel',),
+FAMILIES = {'mbconv': ('mbconv_front_kernel', 'mbconv_deep_kernel', 'mbconv_roll_kernel', 'mbconv_wide_kernel'), 'sepconv': ('sepconv_kernel',),
             'pw_gemm': ('pw_gemm_kernel',), 'stem_dw': ('stem_dw_kernel', 'stem_roll_kernel'), 'se_gate': ('se_gate_kernel',),
             'topk': ('topk_', 'anchor_collect', 'pair_finish', 'row_max'), 'nms': ('nms_', 'decode_threshold', 'gather_ood')}
 
