@@ -332,6 +332,50 @@ int effdet_train_bn_finalize(void* stream, const float* mean, const float* var, 
 int effdet_train_bn_bwd_prep(void* stream, const float* s1, const float* s2c, const float* rstd, int C, float inv_m,
                              float* dgamma, float* dbeta, float* v1, float* v3);
 
+/* ---- the head towers over the whole pyramid in one launch per layer (effdet/efficientdet.py:438-452: conv weights shared by
+ * the levels, BatchNorm per level).  "Packed pyramid" = float32 [sum_l B*Hs[l]*Ws[l]][C], level-major: the NHWC tensors of the L
+ * levels (L <= 8) one behind the other.  A 1x1 conv over it is ONE GEMM: effdet_train_gemm_nt_levels / _tn_levels are
+ * effdet_train_gemm_nt / _tn over those rows, where the side flagged `*_packed` is instead the image-major head tensor of
+ * effdet/loss.py's packing, [B][sum_l Hs[l]*Ws[l]][pk_ld] with pk_img_stride floats per image (a_packed and c_packed exclude each
+ * other; C2 needs a dense C).  Reductions finish inside the launch (the workgroup that arrives last at an agent-scope counter adds
+ * the partial rows in index order: bitwise reproducible).  `counters`: >= 64 zero-initialised 32-bit words per stream in use,
+ * left zero by every call; `workspace`: effdet_train_levels_workspace_floats floats.
+ *   levels_dw          depthwise 3x3 / s1 / TF-SAME, taps [9][C]; flip != 0: taps mirrored = gradient w.r.t. the input
+ *   levels_dw_bwd_dw   out [9][C] = gradient of the (shared) taps, summed over all levels
+ *   levels_col_reduce  out [L][C] (mode 0: sum a; mode 2: sum (a - v[l][c] * vscale[l])^2) or [L][2][C] (mode 4: sum a',
+ *                      sum a' (b - v[l][c]), a' = a * silu'(pre) when pre is given - the SiLU backward of the layer above)
+ *   levels_bn_finalize nn.BatchNorm2d bookkeeping of the L layers (pointer tables of their parameters / buffers; train[l] != 0:
+ *                      batch statistics mean = sum * inv_m, var = sq * inv_m, running stats updated; else running statistics)
+ *                      -> mean, scale = gamma * rstd, shift = beta - mean * scale, rstd, all [L][C]
+ *   levels_bn_bwd_prep sums [L][2][C] of mode 4 -> d gamma, d beta, v1, v3 ([L][C]; as effdet_train_bn_bwd_prep)
+ *   levels_ew          op 3: out = a * v0[l][c] + v1[l][c] (out2 = silu(out) when given); op 6: BatchNorm backward
+ *                      v0 (a' - v1 - (b - v2) v3) for levels with train[l] != 0, a' v0 otherwise; a' as in mode 4 */
+int effdet_train_gemm_nt_levels(void* stream, const float* A, int a_packed, const float* W, const float* bias, float* C,
+                                int c_packed, int B, int L, const int* Hs, const int* Ws, long long pk_img_stride,
+                                long long pk_ld, int K, int N, float* C2);
+int effdet_train_gemm_tn_levels(void* stream, const float* dY, int y_packed, const float* X, int B, int L, const int* Hs,
+                                const int* Ws, long long pk_img_stride, long long pk_ld, int N, int K, float* out,
+                                float* workspace, long long workspace_floats);
+long long effdet_train_levels_workspace_floats(int B, int L, const int* Hs, const int* Ws, int C);
+int effdet_train_levels_dw(void* stream, const float* X, const float* taps, float* Y, int B, int L, const int* Hs,
+                           const int* Ws, int C, int flip);
+int effdet_train_levels_dw_bwd_dw(void* stream, const float* dY, const float* X, float* out, int B, int L,
+                                  const int* Hs, const int* Ws, int C, float* workspace, long long workspace_floats,
+                                  unsigned* counters);
+int effdet_train_levels_col_reduce(void* stream, int mode, const float* a, const float* b, const float* v,
+                                   const float* pre, const float* vscale, int B, int L, const int* Hs, const int* Ws, int C,
+                                   float* out, float* workspace, long long workspace_floats, unsigned* counters);
+int effdet_train_levels_bn_finalize(void* stream, const float* sum, const float* sq, int L, int C, const void* const* gamma,
+                                    const void* const* beta, void* const* running_mean, void* const* running_var,
+                                    void* const* num_batches_tracked, const int* train, const float* inv_m,
+                                    const float* unbias, const float* momentum, const float* eps,
+                                    float* mean, float* scale, float* shift, float* rstd);
+int effdet_train_levels_bn_bwd_prep(void* stream, const float* sums, const float* rstd, const float* inv_m, int L, int C,
+                                    float* dgamma, float* dbeta, float* v1, float* v3);
+int effdet_train_levels_ew(void* stream, int op, float* out, float* out2, const float* a, const float* b, const float* pre,
+                           const float* v0, const float* v1, const float* v2, const float* v3, const int* train,
+                           int B, int L, const int* Hs, const int* Ws, int C);
+
 /* ---- optimizer half of the pretrain step (pretrain.py:272-276) ------------------------------------ */
 
 /* torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.Adam.step() on flat float32 buffers.

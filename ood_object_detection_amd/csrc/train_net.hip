@@ -18,17 +18,48 @@
 
 namespace {
 
-struct RowMap { long long rpi, img_stride, ld; };      // row m -> (m / rpi) * img_stride + (m % rpi) * ld
+// row m -> (m / rpi) * img_stride + (m % rpi) * ld;  with nlev > 0 the rows are those of a level-major packed pyramid (level,
+// image, pixel) and the tensor is the image-major one of the head outputs, [B][sum_l H_l W_l][ld]: row -> image * img_stride +
+// (lq0[level] + pixel) * ld   (effdet_train_gemm_*_levels)
+constexpr int MAXLEV = 8;
+struct RowMap { long long rpi, img_stride, ld; int nlev; long long lrow0[MAXLEV + 1], lq0[MAXLEV], lhw[MAXLEV]; };
 DEV long long row_off(const RowMap& r, long long m) {
+    if (r.nlev > 0) {
+        int l = 0;
+#pragma unroll
+        for (int i = 1; i < MAXLEV; ++i) l = (i < r.nlev && m >= r.lrow0[i]) ? i : l;
+        const long long local = m - r.lrow0[l];
+        const long long b = local / r.lhw[l];
+        return b * r.img_stride + (r.lq0[l] + (local - b * r.lhw[l])) * r.ld;
+    }
     if (r.img_stride == 0) return m * r.ld;
     const long long q = m / r.rpi;
     return q * r.img_stride + (m - q * r.rpi) * r.ld;
 }
 inline RowMap make_rowmap(long long rpi, long long img_stride, long long ld, long long M, long long cols) {
     RowMap r;
+    r.nlev = 0;
+    for (int l = 0; l < MAXLEV; ++l) { r.lrow0[l] = 0; r.lq0[l] = 0; r.lhw[l] = 1; }
+    r.lrow0[MAXLEV] = 0;
     if (rpi <= 0 || img_stride <= 0) { r.rpi = M > 0 ? M : 1; r.img_stride = 0; r.ld = ld > 0 ? ld : cols; }
     else { r.rpi = rpi; r.img_stride = img_stride; r.ld = ld > 0 ? ld : cols; }
     return r;
+}
+// -> number of rows (B * sum H W), or < 0
+inline long long make_levels_rowmap(RowMap& r, int B, int L, const int* Hs, const int* Ws, long long img_stride, long long ld) {
+    if (B <= 0 || L <= 0 || L > MAXLEV || !Hs || !Ws || img_stride <= 0 || ld <= 0) return -1;
+    r = make_rowmap(0, 0, ld, 1, ld);
+    r.nlev = L; r.img_stride = img_stride;
+    long long q = 0;
+    for (int l = 0; l < L; ++l) {
+        if (Hs[l] <= 0 || Ws[l] <= 0) return -1;
+        r.lhw[l] = (long long)Hs[l] * Ws[l];
+        r.lq0[l] = q;
+        q += r.lhw[l];
+        r.lrow0[l + 1] = r.lrow0[l] + (long long)B * r.lhw[l];
+    }
+    if (q * ld > img_stride) return -1;
+    return r.lrow0[L];
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -806,6 +837,25 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(BnBwdArgs p) {
 // ================================================================================================================
 // C ABI
 // ================================================================================================================
+static int launch_gemm_nt(hipStream_t st, GemmNtArgs& p) {
+    const float* A = p.A; const float* W = p.W; const float* bias = p.bias; float* C = p.C; float* C2 = p.C2;
+    const long long M = p.M; const int K = p.K, N = p.N;
+    const long long gx = (M + 127) / 128;                    // 4 waves x 32 rows
+    if (gx > 0x7fffffffLL) return EFFDET_EINVAL;
+    const bool vec = K % 4 == 0 && p.am.ld % 4 == 0 && p.am.img_stride % 4 == 0 &&
+                     reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(W) % 16 == 0;
+    p.vec_out = N % 4 == 0 && p.cm.ld % 4 == 0 && p.cm.img_stride % 4 == 0 && reinterpret_cast<uintptr_t>(C) % 16 == 0 &&
+                (bias == nullptr || reinterpret_cast<uintptr_t>(bias) % 16 == 0) &&
+                (C2 == nullptr || reinterpret_cast<uintptr_t>(C2) % 16 == 0);
+    const dim3 grid((unsigned)gx, (unsigned)((N + 63) / 64));
+    const bool vec2 = K % 2 == 0 && p.am.ld % 2 == 0 && p.am.img_stride % 2 == 0 &&
+                      reinterpret_cast<uintptr_t>(A) % 8 == 0 && reinterpret_cast<uintptr_t>(W) % 8 == 0;
+    if (vec) hipLaunchKernelGGL(gemm_nt_kernel<4>, grid, dim3(256), 0, st, p);
+    else if (vec2) hipLaunchKernelGGL(gemm_nt_kernel<2>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, dim3(256), 0, st, p);
+    return effdet_check_launch();
+}
+
 extern "C" int effdet_train_gemm_nt(void* stream, const float* A, long long a_rpi, long long a_img_stride, long long a_ld,
                                     const float* W, const float* bias, float* C, long long c_rpi, long long c_img_stride,
                                     long long c_ld, long long M, int K, int N, int accumulate, float* C2) {
@@ -815,21 +865,25 @@ extern "C" int effdet_train_gemm_nt(void* stream, const float* A, long long a_rp
     p.A = A; p.W = W; p.bias = bias; p.C = C; p.M = M; p.K = K; p.N = N; p.accumulate = accumulate; p.C2 = C2;
     p.am = make_rowmap(a_rpi, a_img_stride, a_ld, M, K);
     p.cm = make_rowmap(c_rpi, c_img_stride, c_ld, M, N);
-    const long long gx = (M + 127) / 128;                    // 4 waves x 32 rows
-    if (gx > 0x7fffffffLL) return EFFDET_EINVAL;
-    const bool vec = K % 4 == 0 && p.am.ld % 4 == 0 && p.am.img_stride % 4 == 0 &&
-                     reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(W) % 16 == 0;
-    p.vec_out = N % 4 == 0 && p.cm.ld % 4 == 0 && p.cm.img_stride % 4 == 0 && reinterpret_cast<uintptr_t>(C) % 16 == 0 &&
-                (bias == nullptr || reinterpret_cast<uintptr_t>(bias) % 16 == 0) &&
-                (C2 == nullptr || reinterpret_cast<uintptr_t>(C2) % 16 == 0);
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)gx, (unsigned)((N + 63) / 64));
-    const bool vec2 = K % 2 == 0 && p.am.ld % 2 == 0 && p.am.img_stride % 2 == 0 &&
-                      reinterpret_cast<uintptr_t>(A) % 8 == 0 && reinterpret_cast<uintptr_t>(W) % 8 == 0;
-    if (vec) hipLaunchKernelGGL(gemm_nt_kernel<4>, grid, dim3(256), 0, st, p);
-    else if (vec2) hipLaunchKernelGGL(gemm_nt_kernel<2>, grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, dim3(256), 0, st, p);
-    return effdet_check_launch();
+    return launch_gemm_nt(reinterpret_cast<hipStream_t>(stream), p);
+}
+
+// The same GEMM over the rows of a level-major packed pyramid (train_levels.hip); the side flagged `*_packed` is the image-major
+// head tensor [B][sum_l H_l W_l][pk_ld] (pk_img_stride floats per image), the other side is dense level-major rows.
+extern "C" int effdet_train_gemm_nt_levels(void* stream, const float* A, int a_packed, const float* W, const float* bias, float* C,
+                                           int c_packed, int B, int L, const int* Hs, const int* Ws, long long pk_img_stride,
+                                           long long pk_ld, int K, int N, float* C2) {
+    EFFDET_ENTER();
+    if (!A || !W || !C || K <= 0 || N <= 0 || (a_packed && c_packed) || (C2 && c_packed)) return EFFDET_EINVAL;
+    GemmNtArgs p;
+    RowMap lm;
+    const long long M = make_levels_rowmap(lm, B, L, Hs, Ws, pk_img_stride > 0 ? pk_img_stride : 1, pk_ld > 0 ? pk_ld : 1);
+    if (M <= 0) return EFFDET_EINVAL;
+    p.A = A; p.W = W; p.bias = bias; p.C = C; p.M = M; p.K = K; p.N = N; p.accumulate = 0; p.C2 = C2;
+    p.am = a_packed ? lm : make_rowmap(0, 0, 0, M, K);
+    p.cm = c_packed ? lm : make_rowmap(0, 0, 0, M, N);
+    if ((a_packed && pk_ld < K) || (c_packed && pk_ld < N)) return EFFDET_EINVAL;
+    return launch_gemm_nt(reinterpret_cast<hipStream_t>(stream), p);
 }
 
 static int tn_slices(long long M, int N, int K) {
@@ -849,25 +903,18 @@ extern "C" long long effdet_train_gemm_tn_workspace_floats(long long M, int N, i
     return (long long)tn_slices(M, N, K) * N * (K + 1);
 }
 
-extern "C" int effdet_train_gemm_tn(void* stream, const float* dY, long long y_rpi, long long y_img_stride, long long y_ld,
-                                    const float* X, long long x_rpi, long long x_img_stride, long long x_ld,
-                                    long long M, int N, int K, float* out, float* workspace, long long workspace_floats) {
-    EFFDET_ENTER();
-    if (!dY || !X || !out || !workspace || M <= 0 || N <= 0 || K <= 0) return EFFDET_EINVAL;
+static int launch_gemm_tn(hipStream_t st, GemmTnArgs& p, float* out, float* workspace, long long workspace_floats) {
+    const long long M = p.M; const int N = p.N, K = p.K;
     const int S = tn_slices(M, N, K);
     if (workspace_floats < (long long)S * N * (K + 1)) return EFFDET_EINVAL;
-    GemmTnArgs p;
-    p.dY = dY; p.X = X; p.partial = workspace; p.M = M; p.N = N; p.K = K; p.S = S;
-    p.ym = make_rowmap(y_rpi, y_img_stride, y_ld, M, N);
-    p.xm = make_rowmap(x_rpi, x_img_stride, x_ld, M, K);
+    p.partial = workspace; p.S = S;
     long long rps = (M + S - 1) / S;
     rps = (rps + 31) / 32 * 32;
     p.rows_per_slice = rps;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((N + 31) / 32), (unsigned)((K + 1 + 63) / 64), (unsigned)S);
-    const bool vy = p.ym.ld % 4 == 0 && p.ym.img_stride % 4 == 0 && reinterpret_cast<uintptr_t>(dY) % 16 == 0;
-    const bool vx = p.xm.ld % 4 == 0 && p.xm.img_stride % 4 == 0 && reinterpret_cast<uintptr_t>(X) % 16 == 0;
-    const bool vy2 = N % 2 == 0 && p.ym.ld % 2 == 0 && p.ym.img_stride % 2 == 0 && reinterpret_cast<uintptr_t>(dY) % 8 == 0;
+    const bool vy = p.ym.ld % 4 == 0 && p.ym.img_stride % 4 == 0 && reinterpret_cast<uintptr_t>(p.dY) % 16 == 0;
+    const bool vx = p.xm.ld % 4 == 0 && p.xm.img_stride % 4 == 0 && reinterpret_cast<uintptr_t>(p.X) % 16 == 0;
+    const bool vy2 = N % 2 == 0 && p.ym.ld % 2 == 0 && p.ym.img_stride % 2 == 0 && reinterpret_cast<uintptr_t>(p.dY) % 8 == 0;
     if (vy && vx) hipLaunchKernelGGL((gemm_tn_kernel<4, true>), grid, dim3(256), 0, st, p);
     else if (vx) {
         if (vy2) hipLaunchKernelGGL((gemm_tn_kernel<2, true>), grid, dim3(256), 0, st, p);
@@ -882,6 +929,35 @@ extern "C" int effdet_train_gemm_tn(void* stream, const float* dY, long long y_r
     if (rb > 0x7fffffffLL) return EFFDET_EINVAL;
     hipLaunchKernelGGL(reduce_split_kernel, dim3((unsigned)rb), dim3(256), 0, st, r);
     return effdet_check_launch();
+}
+
+extern "C" int effdet_train_gemm_tn(void* stream, const float* dY, long long y_rpi, long long y_img_stride, long long y_ld,
+                                    const float* X, long long x_rpi, long long x_img_stride, long long x_ld,
+                                    long long M, int N, int K, float* out, float* workspace, long long workspace_floats) {
+    EFFDET_ENTER();
+    if (!dY || !X || !out || !workspace || M <= 0 || N <= 0 || K <= 0) return EFFDET_EINVAL;
+    GemmTnArgs p;
+    p.dY = dY; p.X = X; p.M = M; p.N = N; p.K = K;
+    p.ym = make_rowmap(y_rpi, y_img_stride, y_ld, M, N);
+    p.xm = make_rowmap(x_rpi, x_img_stride, x_ld, M, K);
+    return launch_gemm_tn(reinterpret_cast<hipStream_t>(stream), p, out, workspace, workspace_floats);
+}
+
+// weight gradient over the rows of a level-major packed pyramid: X dense level-major rows, dY the image-major head tensor
+// (y_packed) or dense level-major rows.  Workspace: effdet_train_gemm_tn_workspace_floats(B * sum H W, N, K).
+extern "C" int effdet_train_gemm_tn_levels(void* stream, const float* dY, int y_packed, const float* X, int B, int L, const int* Hs,
+                                           const int* Ws, long long pk_img_stride, long long pk_ld, int N, int K, float* out,
+                                           float* workspace, long long workspace_floats) {
+    EFFDET_ENTER();
+    if (!dY || !X || !out || !workspace || N <= 0 || K <= 0) return EFFDET_EINVAL;
+    GemmTnArgs p;
+    RowMap lm;
+    const long long M = make_levels_rowmap(lm, B, L, Hs, Ws, pk_img_stride > 0 ? pk_img_stride : 1, pk_ld > 0 ? pk_ld : 1);
+    if (M <= 0 || (y_packed && pk_ld < N)) return EFFDET_EINVAL;
+    p.dY = dY; p.X = X; p.M = M; p.N = N; p.K = K;
+    p.ym = y_packed ? lm : make_rowmap(0, 0, 0, M, N);
+    p.xm = make_rowmap(0, 0, 0, M, K);
+    return launch_gemm_tn(reinterpret_cast<hipStream_t>(stream), p, out, workspace, workspace_floats);
 }
 
 extern "C" int effdet_train_reduce_mid(void* stream, const float* in, int G, int S, long long L, float* out, int accumulate) {

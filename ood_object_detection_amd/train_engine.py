@@ -27,6 +27,29 @@ def _same_out(n, s):
     return (n + s - 1) // s
 
 
+class _Levels(object):
+    """Geometry of a packed pyramid: the L levels' NHWC tensors [B, h_l, w_l, C] one behind the other (level-major rows)."""
+
+    def __init__(self, B, hw):
+        import ctypes
+        self.B, self.L, self.hw = B, len(hw), list(hw)
+        self.Hs = (ctypes.c_int * self.L)(*[h for h, _ in hw])
+        self.Ws = (ctypes.c_int * self.L)(*[w for _, w in hw])
+        self.rows = [B * h * w for h, w in hw]
+        self.M = sum(self.rows)
+        self.P = sum(h * w for h, w in hw)
+        self.inv_m = (ctypes.c_float * self.L)(*[1.0 / r for r in self.rows])
+        self.unbias = (ctypes.c_float * self.L)(*[float(r / max(r - 1, 1)) for r in self.rows])
+
+    def split(self, t):
+        """packed [M, C] -> per-level NHWC views"""
+        out, o = [], 0
+        for (h, w), r in zip(self.hw, self.rows):
+            out.append(t[o:o + r].view(self.B, h, w, t.shape[-1]))
+            o += r
+        return out
+
+
 class _Ops(object):
     """Thin tensor-level wrappers of the C ABI (float32 NHWC tensors on one GPU)."""
 
@@ -35,6 +58,7 @@ class _Ops(object):
         self.dev = device
         self._ws = None
         self._retired = []
+        self._cnt = None
 
     def st(self):
         return torch.cuda.current_stream(self.dev).cuda_stream
@@ -166,6 +190,95 @@ class _Ops(object):
         _lib.check(self.lib.effdet_maxpool_same(self.st(), 0, x.data_ptr(), 0, y.data_ptr(), 0, B, H, W, C), 'effdet_maxpool_same')
         return y
 
+    # ---- whole-pyramid operators (csrc/train_levels.hip) ------------------------------------------
+    def counters(self):
+        if self._cnt is None:
+            self._cnt = torch.zeros(64, dtype=torch.int32, device=self.dev)   # arrival counters: zero between launches
+        return self._cnt
+
+    def lv_ws(self, lv, C):
+        return self.ws(self.lib.effdet_train_levels_workspace_floats(lv.B, lv.L, lv.Hs, lv.Ws, C))
+
+    def lv_dw(self, lv, x, taps, flip=False):
+        C = x.shape[-1]
+        y = self.new(lv.M, C)
+        _lib.check(self.lib.effdet_train_levels_dw(self.st(), x.data_ptr(), taps.data_ptr(), y.data_ptr(), lv.B, lv.L, lv.Hs, lv.Ws,
+                                                   C, int(flip)), 'effdet_train_levels_dw')
+        return y
+
+    def lv_dw_bwd_dw(self, lv, dy, x):
+        C = x.shape[-1]
+        ws = self.lv_ws(lv, C)
+        out = self.new(9, C)
+        _lib.check(self.lib.effdet_train_levels_dw_bwd_dw(self.st(), dy.data_ptr(), x.data_ptr(), out.data_ptr(), lv.B, lv.L, lv.Hs,
+                                                          lv.Ws, C, ws.data_ptr(), ws.numel(), self.counters().data_ptr()),
+                   'effdet_train_levels_dw_bwd_dw')
+        return out
+
+    def lv_col_reduce(self, lv, mode, a, b=None, v=None, pre=None, vscale=None):
+        C = a.shape[-1]
+        ws = self.lv_ws(lv, C)
+        out = self.new(lv.L, 2, C) if mode == 4 else self.new(lv.L, C)
+        p = lambda t: None if t is None else t.data_ptr()
+        _lib.check(self.lib.effdet_train_levels_col_reduce(self.st(), mode, a.data_ptr(), p(b), p(v), p(pre), vscale, lv.B, lv.L,
+                                                           lv.Hs, lv.Ws, C, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                           self.counters().data_ptr()), 'effdet_train_levels_col_reduce')
+        return out
+
+    def lv_bn_finalize(self, lv, sums, sq, bns, C):
+        """-> [4, L, C]: mean, scale, shift, rstd of the L per-level BatchNorm layers `bns`"""
+        import ctypes
+        L = lv.L
+        vp = ctypes.c_void_p * L
+        out = self.new(4, L, C)
+        nbt = vp(*[None if bn.num_batches_tracked is None else bn.num_batches_tracked.data_ptr() for bn in bns])
+        _lib.check(self.lib.effdet_train_levels_bn_finalize(
+            self.st(), None if sums is None else sums.data_ptr(), None if sq is None else sq.data_ptr(), L, C,
+            vp(*[bn.weight.data_ptr() for bn in bns]), vp(*[bn.bias.data_ptr() for bn in bns]),
+            vp(*[bn.running_mean.data_ptr() for bn in bns]), vp(*[bn.running_var.data_ptr() for bn in bns]), nbt,
+            (ctypes.c_int * L)(*[int(bn.training) for bn in bns]), lv.inv_m, lv.unbias,
+            (ctypes.c_float * L)(*[float(bn.momentum if bn.momentum is not None else 0.1) for bn in bns]),
+            (ctypes.c_float * L)(*[float(bn.eps) for bn in bns]),
+            out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr()), 'effdet_train_levels_bn_finalize')
+        return out
+
+    def lv_bn_bwd_prep(self, lv, sums, rstd, C):
+        """-> [4, L, C]: d gamma, d beta, v1, v3"""
+        out = self.new(4, lv.L, C)
+        _lib.check(self.lib.effdet_train_levels_bn_bwd_prep(self.st(), sums.data_ptr(), rstd.data_ptr(), lv.inv_m, lv.L, C,
+                                                            out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
+                                                            out[3].data_ptr()), 'effdet_train_levels_bn_bwd_prep')
+        return out
+
+    def lv_ew(self, lv, op, a, b=None, pre=None, v=(None, None, None, None), train=None, silu_out=False):
+        C = a.shape[-1]
+        out = torch.empty_like(a)
+        out2 = torch.empty_like(a) if silu_out else None
+        p = lambda t: None if t is None else t.data_ptr()
+        _lib.check(self.lib.effdet_train_levels_ew(self.st(), op, out.data_ptr(), p(out2), a.data_ptr(), p(b), p(pre), p(v[0]), p(v[1]),
+                                                   p(v[2]), p(v[3]), train, lv.B, lv.L, lv.Hs, lv.Ws, C), 'effdet_train_levels_ew(%d)' % op)
+        return (out, out2) if silu_out else out
+
+    def gemm_nt_levels(self, lv, A, W, bias=None, a_packed=False, out_packed=None, pk=(0, 0)):
+        """rows of the packed pyramid x W[N,K]^T + bias; a_packed: A is the image-major head tensor (pk = floats per image, row
+        stride); out_packed: write into that image-major tensor instead of returning dense level-major rows"""
+        N, K = W.shape
+        out = self.new(lv.M, N) if out_packed is None else out_packed
+        _lib.check(self.lib.effdet_train_gemm_nt_levels(self.st(), A.data_ptr(), int(a_packed), W.data_ptr(),
+                                                        None if bias is None else bias.data_ptr(), out.data_ptr(),
+                                                        int(out_packed is not None), lv.B, lv.L, lv.Hs, lv.Ws, pk[0], pk[1], K, N, None),
+                   'effdet_train_gemm_nt_levels')
+        return out
+
+    def gemm_tn_levels(self, lv, dY, X, N, K, y_packed=False, pk=(0, 0)):
+        """-> (dW [N,K], dsum [N]) over the rows of the packed pyramid"""
+        ws = self.ws(self.lib.effdet_train_gemm_tn_workspace_floats(lv.M, N, K))
+        out = self.new(N * K + N)
+        _lib.check(self.lib.effdet_train_gemm_tn_levels(self.st(), dY.data_ptr(), int(y_packed), X.data_ptr(), lv.B, lv.L, lv.Hs, lv.Ws,
+                                                        pk[0], pk[1], N, K, out.data_ptr(), ws.data_ptr(), ws.numel()),
+                   'effdet_train_gemm_tn_levels')
+        return out[:N * K].view(N, K), out[N * K:]
+
     def reduce_rows(self, t):
         """[S, L] -> [L] in row order"""
         S, L = t.shape
@@ -178,7 +291,7 @@ class TrainEngine(object):
     """Stage functions `bb_forward/backward`, `fh_forward/backward` over one model (its parameters are read live, so an
     optimizer step needs no re-preparation)."""
 
-    def __init__(self, model, head_chains=False):
+    def __init__(self, model):
         p0 = model.backbone.conv_stem.weight
         if p0.device.type != 'cuda':
             raise RuntimeError('the training path needs the model on a GPU (cuda:N); there is no CPU fallback')
@@ -194,12 +307,6 @@ class TrainEngine(object):
         self.L = cfg.num_levels
         self.A = model.num_anchors
         self._ones = {}
-        self._main_ops = self.ops
-        self._chain_ops, self._chain_streams = [], []        # one workspace + stream per (head, level) chain
-        # opt-in constructor argument: run the 2 x L independent head towers on parallel streams.  Measured (d0 / 640 / 8
-        # images): no gain - eager launches are CPU-bound, and the captured graph does not run the branches faster
-        # (38.8 vs 37.0 steps/s) - so off by default.
-        self.head_chains = bool(head_chains)
         self.direct_grad = False        # True: parameter gradients are added into existing `.grad`s by one multi-tensor launch
 
     def _const(self, C, v):
@@ -639,59 +746,95 @@ class TrainEngine(object):
             hrec = dict(name=name, NO=NO, levels=[None] * L, out=out_t)
             outs.append(out_t)
             saved['heads'].append(hrec)
-        # The 2 x L towers (head, level) are independent until their gradients meet again in the pyramid: each runs as its own
-        # chain on its own stream (own reduction workspace), forked from / joined to the caller's stream.  Their launches are
-        # tiny (a level of P5-P7 is a few hundred pixels), so run one after the other they leave most of the chip idle.
-        chains = [(hi, l) for hi in range(2) if saved['heads'][hi] is not None for l in range(L)]
-        heads_mods = (model.class_net, model.box_net)
-        self._const(F, 1.0), self._const(F, 0.0)          # shared constants exist before the streams fork
-
-        def run_chain(hi, l):
-            head, hrec = heads_mods[hi], saved['heads'][hi]
-            name, NO, out_t = hrec['name'], hrec['NO'], hrec['out']
-            t = pyr[l]['t']
-            h, w = hw[l]
-            lrec = dict(reps=[])
-            for r in range(len(head.conv_rep)):
-                conv = head.conv_rep[r]
-                d, rdw = self._dw_fwd(t, conv.conv_dw, '%sconv_rep.%d.conv_dw.' % (name, r))
-                c, rpw = self._pw_fwd(d, conv.conv_pw, '%sconv_rep.%d.conv_pw.' % (name, r))
-                (y, t), rbn = self._bn_fwd(c, head.bn_rep[r][l].bn, '%sbn_rep.%d.%d.bn.' % (name, r, l), silu_out=True)
-                lrec['reps'].append((rdw, rpw, rbn, y))
-            d, rdw = self._dw_fwd(t, head.predict.conv_dw, name + 'predict.conv_dw.')
-            cmap = (out_t.data_ptr() + offs[l] * NO * 4, h * w, P * NO, NO)
-            _, rpw = self._pw_fwd(d, head.predict.conv_pw, name + 'predict.conv_pw.', c_map=cmap)
-            lrec['predict'] = (rdw, rpw)
-            lrec['map_off'] = offs[l] * NO
-            hrec['levels'][l] = lrec
-
-        self._for_each_chain(chains, run_chain)
+        # The towers share their conv weights over the levels (only BatchNorm is per level): every layer of a head is ONE launch
+        # over the packed pyramid [B * P, F] (csrc/train_levels.hip) instead of one per level.
+        lv = _Levels(B, hw)
+        saved['lv'] = lv
+        packed = torch.cat([t['t'].reshape(-1, F) for t in pyr], 0)
+        for hi, head in enumerate((model.class_net, model.box_net)):
+            if saved['heads'][hi] is not None:
+                self._head_fwd(lv, packed, head, saved['heads'][hi])
         saved['P'] = P
         return outs[0], outs[1], saved
 
-    def _for_each_chain(self, chains, fn):
-        """Run fn(hi, l) for every chain, each on its own stream with its own workspace, forked from and joined to the current
-        stream (graph capture turns the forks into parallel branches).  `head_chains = False` runs them in launch order."""
-        if not self.head_chains or len(chains) < 2:
-            for hi, l in chains:
-                fn(hi, l)
-            return
-        while len(self._chain_ops) < 2 * self.L:
-            self._chain_ops.append(_Ops(self.dev))
-            self._chain_streams.append(torch.cuda.Stream(self.dev))
-        cur = torch.cuda.current_stream(self.dev)
-        try:
-            for hi, l in chains:
-                k = hi * self.L + l
-                st = self._chain_streams[k]
-                st.wait_stream(cur)
-                self.ops = self._chain_ops[k]
-                with torch.cuda.stream(st):
-                    fn(hi, l)
-        finally:
-            self.ops = self._main_ops
-        for hi, l in chains:
-            cur.wait_stream(self._chain_streams[hi * self.L + l])
+    @staticmethod
+    def _dw_taps(conv):
+        C, k = conv.weight.shape[0], conv.weight.shape[-1]
+        if k != 3 or tuple(conv.stride) != (1, 1):
+            raise NotImplementedError('head depthwise convs other than 3x3 / stride 1')
+        return conv.weight.detach().permute(2, 3, 0, 1).reshape(k * k, C).contiguous()
+
+    def _head_fwd(self, lv, t, head, hrec):
+        """HeadNet.forward (efficientdet.py:438-452) over all levels at once: per repeat dw3x3 -> 1x1 conv (+bias) -> per-level
+        BatchNorm -> SiLU; then the predict SeparableConv2d, written straight into the image-major [B, A*P, K] head tensor."""
+        ops, name, NO, out_t = self.ops, hrec['name'], hrec['NO'], hrec['out']
+        L = lv.L
+        hrec['reps'] = []
+        for r in range(len(head.conv_rep)):
+            conv = head.conv_rep[r]
+            taps = self._dw_taps(conv.conv_dw)
+            d = ops.lv_dw(lv, t, taps)
+            N = conv.conv_pw.weight.shape[0]
+            W = conv.conv_pw.weight.detach().reshape(N, -1).contiguous()
+            bias = None if conv.conv_pw.bias is None else conv.conv_pw.bias.detach().contiguous()
+            c = ops.gemm_nt(d, W, bias)
+            bns = [head.bn_rep[r][l].bn for l in range(L)]
+            sums = sq = None
+            if any(bn.training for bn in bns):
+                sums = ops.lv_col_reduce(lv, 0, c)
+                sq = ops.lv_col_reduce(lv, 2, c, v=sums, vscale=lv.inv_m)
+            st = ops.lv_bn_finalize(lv, sums, sq, bns, N)                  # mean, scale, shift, rstd  [4, L, N]
+            y, tn = ops.lv_ew(lv, 3, c, v=(st[1], st[2], None, None), silu_out=True)
+            import ctypes
+            hrec['reps'].append(dict(x=t, taps=taps, d=d, W=W, c=c, y=y, st=st, has_bias=bias is not None, r=r,
+                                     train=(ctypes.c_int * L)(*[int(bn.training) for bn in bns]),
+                                     wshape=conv.conv_pw.weight.shape, dwshape=conv.conv_dw.weight.shape))
+            t = tn
+        taps = self._dw_taps(head.predict.conv_dw)
+        d = ops.lv_dw(lv, t, taps)
+        Wp = head.predict.conv_pw.weight.detach().reshape(NO, -1).contiguous()
+        bias = None if head.predict.conv_pw.bias is None else head.predict.conv_pw.bias.detach().contiguous()
+        pk = (lv.P * NO, NO)
+        ops.gemm_nt_levels(lv, d, Wp, bias, out_packed=out_t, pk=pk)
+        hrec['predict'] = dict(x=t, taps=taps, d=d, W=Wp, has_bias=bias is not None, pk=pk,
+                               wshape=head.predict.conv_pw.weight.shape, dwshape=head.predict.conv_dw.weight.shape)
+
+    def _head_bwd(self, lv, hrec, g, grads):
+        """-> d packed pyramid [B * P, F]; parameter gradients into `grads` (conv weights: one reduction over all levels)"""
+        ops, name, NO = self.ops, hrec['name'], hrec['NO']
+        L = lv.L
+
+        def dw_grads(rec, dd, prefix):
+            dtaps = ops.lv_dw_bwd_dw(lv, dd, rec['x'])
+            C = dtaps.shape[1]
+            grads[prefix + 'conv_dw.weight'] = dtaps.reshape(3, 3, C, 1).permute(2, 3, 0, 1).reshape(rec['dwshape'])
+            return ops.lv_dw(lv, dd, rec['taps'], flip=True)
+
+        rec = hrec['predict']
+        F = rec['W'].shape[1]
+        dW, dsum = ops.gemm_tn_levels(lv, g, rec['d'], NO, F, y_packed=True, pk=rec['pk'])
+        grads[name + 'predict.conv_pw.weight'] = dW.reshape(rec['wshape'])
+        if rec['has_bias']:
+            grads[name + 'predict.conv_pw.bias'] = dsum
+        dd = ops.gemm_nt_levels(lv, g, rec['W'].t().contiguous(), a_packed=True, pk=rec['pk'])
+        da = dw_grads(rec, dd, name + 'predict.')
+        for rec in reversed(hrec['reps']):
+            r, st = rec['r'], rec['st']
+            N = rec['W'].shape[0]
+            # SiLU backward (pre = y) folded into both passes of the BatchNorm backward
+            sums = ops.lv_col_reduce(lv, 4, da, b=rec['c'], v=st[0], pre=rec['y'])
+            pb = ops.lv_bn_bwd_prep(lv, sums, st[3], N)                    # d gamma, d beta, v1, v3  [4, L, N]
+            for l in range(L):
+                grads['%sbn_rep.%d.%d.bn.weight' % (name, r, l)] = pb[0, l]
+                grads['%sbn_rep.%d.%d.bn.bias' % (name, r, l)] = pb[1, l]
+            dc = ops.lv_ew(lv, 6, da, b=rec['c'], pre=rec['y'], v=(st[1], pb[2], st[0], pb[3]), train=rec['train'])
+            dW, dsum = ops.gemm_tn(dc, rec['d'], N, rec['W'].shape[1])
+            grads['%sconv_rep.%d.conv_pw.weight' % (name, r)] = dW.reshape(rec['wshape'])
+            if rec['has_bias']:
+                grads['%sconv_rep.%d.conv_pw.bias' % (name, r)] = dsum
+            dd = ops.gemm_nt(dc, rec['W'].t().contiguous())
+            da = dw_grads(rec, dd, '%sconv_rep.%d.' % (name, r))
+        return da
 
     def fh_backward(self, g_cls, g_box, saved, need_dfeats=True):
         """-> (d feats list (NHWC), {param name: grad})"""
@@ -705,32 +848,16 @@ class TrainEngine(object):
             dt[i] = g if dt[i] is None else ops.add(dt[i], g)
 
         gs = [None if g is None else g.contiguous() for g in (g_cls, g_box)]
-        chains = [(hi, l) for hi in range(2) if saved['heads'][hi] is not None and gs[hi] is not None for l in range(L)]
-        chain_out = {}
-
-        def run_chain(hi, l):
-            hrec, g = saved['heads'][hi], gs[hi]
-            NO = hrec['NO']
-            cg = {}                                            # this chain's parameter gradients (merged after the join)
-            lrec = hrec['levels'][l]
-            h, w = hw[l]
-            ymap = (g.data_ptr() + lrec['map_off'] * 4, h * w, P * NO, NO)
-            rdw, rpw = lrec['predict']
-            dd = self._pw_bwd(rpw, None, cg, y_map=ymap)
-            da = self._dw_bwd(rdw, dd, cg)
-            for (rdw, rpw, rbn, y) in reversed(lrec['reps']):
-                dy = self.ops.silu_bwd(y, da)
-                dc = self._bn_bwd(rbn, dy, cg)
-                dd = self._pw_bwd(rpw, dc, cg)
-                da = self._dw_bwd(rdw, dd, cg)
-            chain_out[(hi, l)] = (da, cg)
-
-        self._for_each_chain(chains, run_chain)
-        for (hi, l) in chains:                                 # fixed merge order: bitwise reproducible
-            da, cg = chain_out[(hi, l)]
-            for k, v in cg.items():
-                self._acc(grads, k, v)
-            add_to(saved['pyr_ids'][l], da)
+        lv = saved['lv']
+        dpyr = None
+        for hi in range(2):
+            if saved['heads'][hi] is None or gs[hi] is None:
+                continue
+            da = self._head_bwd(lv, saved['heads'][hi], gs[hi], grads)
+            dpyr = da if dpyr is None else ops.add(dpyr, da)
+        if dpyr is not None:
+            for l, d in enumerate(lv.split(dpyr)):
+                add_to(saved['pyr_ids'][l], d)
         for nrec in reversed(saved['nodes']):
             dy = dt[nrec['out_id']]
             if dy is None:
