@@ -337,9 +337,8 @@ int effdet_train_bn_bwd_prep(void* stream, const float* s1, const float* s2c, co
  * levels (L <= 8) one behind the other.  A 1x1 conv over it is ONE GEMM: effdet_train_gemm_nt_levels / _tn_levels are
  * effdet_train_gemm_nt / _tn over those rows, where the side flagged `*_packed` is instead the image-major head tensor of
  * effdet/loss.py's packing, [B][sum_l Hs[l]*Ws[l]][pk_ld] with pk_img_stride floats per image (a_packed and c_packed exclude each
- * other; C2 needs a dense C).  Reductions finish inside the launch (the workgroup that arrives last at an agent-scope counter adds
- * the partial rows in index order: bitwise reproducible).  `counters`: >= 64 zero-initialised 32-bit words per stream in use,
- * left zero by every call; `workspace`: effdet_train_levels_workspace_floats floats.
+ * other; C2 needs a dense C).  Reductions are two-stage in a fixed order (bitwise reproducible); `workspace`:
+ * effdet_train_levels_workspace_floats floats.
  *   levels_dw          depthwise 3x3 / s1 / TF-SAME, taps [9][C]; flip != 0: taps mirrored = gradient w.r.t. the input
  *   levels_dw_bwd_dw   out [9][C] = gradient of the (shared) taps, summed over all levels
  *   levels_col_reduce  out [L][C] (mode 0: sum a; mode 2: sum (a - v[l][c] * vscale[l])^2) or [L][2][C] (mode 4: sum a',
@@ -360,11 +359,10 @@ long long effdet_train_levels_workspace_floats(int B, int L, const int* Hs, cons
 int effdet_train_levels_dw(void* stream, const float* X, const float* taps, float* Y, int B, int L, const int* Hs,
                            const int* Ws, int C, int flip);
 int effdet_train_levels_dw_bwd_dw(void* stream, const float* dY, const float* X, float* out, int B, int L,
-                                  const int* Hs, const int* Ws, int C, float* workspace, long long workspace_floats,
-                                  unsigned* counters);
+                                  const int* Hs, const int* Ws, int C, float* workspace, long long workspace_floats);
 int effdet_train_levels_col_reduce(void* stream, int mode, const float* a, const float* b, const float* v,
                                    const float* pre, const float* vscale, int B, int L, const int* Hs, const int* Ws, int C,
-                                   float* out, float* workspace, long long workspace_floats, unsigned* counters);
+                                   float* out, float* workspace, long long workspace_floats);
 int effdet_train_levels_bn_finalize(void* stream, const float* sum, const float* sq, int L, int C, const void* const* gamma,
                                     const void* const* beta, void* const* running_mean, void* const* running_var,
                                     void* const* num_batches_tracked, const int* train, const float* inv_m,

@@ -124,9 +124,9 @@ SIGNATURES = {
     'effdet_train_levels_workspace_floats': (c_ll, [c_int, c_int, P(c_int), P(c_int), c_int]),
     'effdet_train_levels_dw': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, P(c_int), P(c_int), c_int, c_int]),
     'effdet_train_levels_dw_bwd_dw': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, P(c_int), P(c_int), c_int,
-                                              c_void_p, c_ll, c_void_p]),
+                                              c_void_p, c_ll]),
     'effdet_train_levels_col_reduce': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, P(c_float), c_int, c_int,
-                                               P(c_int), P(c_int), c_int, c_void_p, c_void_p, c_ll, c_void_p]),
+                                               P(c_int), P(c_int), c_int, c_void_p, c_void_p, c_ll]),
     'effdet_train_levels_bn_finalize': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, P(c_void_p), P(c_void_p), P(c_void_p),
                                                 P(c_void_p), P(c_void_p), P(c_int), P(c_float), P(c_float), P(c_float), P(c_float),
                                                 c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -183,6 +183,10 @@ __attribute__((visibility("hidden"))) int effdet_stem_roll_launch(hipStream_t st
                             const void* Wk, const float* s1, const float* t1, const float* taps, const float* s2, const float* t2,
                             void* Y, float* pool_partial, int B, int H, int W, int C);
 
+// train_net.hip (internal): out[g][l] (+)= alpha * sum_s in[g][s][l], summed in a fixed order
+__attribute__((visibility("hidden"))) int effdet_launch_reduce_mid(hipStream_t st, const float* in, int G, int S, long long L, float* out,
+                                                                   int accumulate, float alpha);
+
 // TF "SAME" padding: amount in front (reference semantics live in timm)
 static inline int same_pad_before(int size, int k, int s) {
     int out = (size + s - 1) / s;

@@ -10,9 +10,9 @@
 //   effdet_train_levels_bn_finalize   nn.BatchNorm2d bookkeeping of the L per-level layers in one launch
 //   effdet_train_levels_bn_bwd_prep   d gamma / d beta and the vectors of the BN backward, per level
 //   effdet_train_levels_ew            per-level per-channel affine (+ SiLU) and the BN (batch statistics) backward
-// Reductions are two-stage inside ONE launch: every workgroup writes its partial row; the workgroup that arrives last at an
-// agent-scope counter adds the rows in index order, so the result does not depend on which workgroup that was (bitwise
-// reproducible), and no second launch is needed.  The counter returns to zero for the next launch.
+// Reductions are two-stage with a fixed order (partial rows, then effdet_launch_reduce_mid): bitwise reproducible.  Measured and
+// dropped: finishing the reduction inside the first launch (the workgroup that arrives last at an agent-scope counter adds the
+// partial rows) - with the 150 - 770 partial rows these shapes need, that one workgroup's serial pass cost 120 - 560 us.
 #include "common.h"
 
 namespace {
@@ -45,30 +45,6 @@ DEV int level_of(const Levels& lv, long long row) {
 #pragma unroll
     for (int i = 1; i < MAXL; ++i) l = (i < lv.n && row >= lv.row0[i]) ? i : l;
     return l;
-}
-
-// The workgroup's partial stores are complete and visible at agent scope, then one lane counts the workgroup in; returns true
-// in every thread of the workgroup that arrived last (which may then read every workgroup's partials with plain loads).
-// Form: MI355X_MICROARCH.md "Valid forms" - producer: stores, every wave's vmcnt(0), barrier, lane-0 release fence, vmcnt(0),
-// agent atomic add; consumer: the adding lane's acquire fence, vmcnt(0), barrier, plain loads.
-DEV bool arrive_last(unsigned* counter, unsigned total) {
-    __shared__ int last_;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = prev == total - 1;
-        if (last) {
-            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // armed for the next launch
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        last_ = last;
-    }
-    __syncthreads();
-    return last_ != 0;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -106,8 +82,8 @@ __global__ __launch_bounds__(256) void lv_dw_kernel(LvDwArgs p) {
 }
 
 // d taps[t][c] = sum over every row of every level of dY[row][c] * X[row + tap t][c].  Workgroup = 64 channels x 4 row lanes
-// over a chunk of rows; partial [chunk][9][C]; the last workgroup of a channel group adds the chunks in order.
-struct LvDwWArgs { const float* dY; const float* X; float* partial; float* out; unsigned* counter; Levels lv; int C; long long rows_per_chunk; int chunks; };
+// over a chunk of rows; partial [chunk][9][C].
+struct LvDwWArgs { const float* dY; const float* X; float* partial; Levels lv; int C; long long rows_per_chunk; int chunks; };
 
 __global__ __launch_bounds__(256) void lv_dw_bwd_dw_kernel(LvDwWArgs p) {
     __shared__ float sm[4][9][64];
@@ -152,15 +128,6 @@ __global__ __launch_bounds__(256) void lv_dw_bwd_dw_kernel(LvDwWArgs p) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) dst[(long long)t * p.C + c] = ((sm[0][t][cl] + sm[1][t][cl]) + sm[2][t][cl]) + sm[3][t][cl];
     }
-    if (!arrive_last(p.counter + blockIdx.y, (unsigned)p.chunks)) return;
-    // 9 x 64 sums of this channel group over `chunks` partial rows, in chunk order
-    for (int e = threadIdx.x; e < 9 * 64; e += 256) {
-        const int t = e / 64, cc = blockIdx.y * 64 + (e & 63);
-        if (cc >= p.C) continue;
-        float s = 0.f;
-        for (int k = 0; k < p.chunks; ++k) s += p.partial[((long long)k * 9 + t) * p.C + cc];
-        p.out[(long long)t * p.C + cc] = s;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -168,7 +135,7 @@ __global__ __launch_bounds__(256) void lv_dw_bwd_dw_kernel(LvDwWArgs p) {
 // pre (mode 4): a is first multiplied by silu'(pre) - the SiLU backward of the layer above, not stored
 // ------------------------------------------------------------------------------------------------------------
 struct LvColArgs {
-    int mode; const float* a; const float* b; const float* v; const float* pre; float* partial; float* out; unsigned* counter;
+    int mode; const float* a; const float* b; const float* v; const float* pre; float* partial;
     Levels lv; float vscale[MAXL]; int C, S;
 };
 
@@ -206,14 +173,6 @@ __global__ __launch_bounds__(256) void lv_col_reduce_kernel(LvColArgs p) {
         float* dst = p.partial + ((long long)l * p.S + s) * Wd * p.C + c;
         dst[0] = ((sm[0][cl] + sm[1][cl]) + sm[2][cl]) + sm[3][cl];
         if (Wd == 2) dst[p.C] = ((sm2[0][cl] + sm2[1][cl]) + sm2[2][cl]) + sm2[3][cl];
-    }
-    if (!arrive_last(p.counter + blockIdx.z * gridDim.y + blockIdx.y, (unsigned)p.S)) return;
-    for (int e = threadIdx.x; e < Wd * 64; e += 256) {
-        const int w = e / 64, cc = blockIdx.y * 64 + (e & 63);
-        if (cc >= p.C) continue;
-        float t = 0.f;
-        for (int k = 0; k < p.S; ++k) t += p.partial[(((long long)l * p.S + k) * Wd + w) * p.C + cc];
-        p.out[((long long)l * Wd + w) * p.C + cc] = t;
     }
 }
 
@@ -333,7 +292,6 @@ inline long long lv_dw_chunks(const Levels& lv, int C, long long* per) {
 
 }  // namespace
 
-// counters: >= 64 zero-initialised 32-bit words owned by the caller (one buffer per stream in use); the kernels leave them zero.
 extern "C" int effdet_train_levels_dw(void* stream, const float* X, const float* taps, float* Y, int B, int L, const int* Hs,
                                       const int* Ws, int C, int flip) {
     EFFDET_ENTER();
@@ -356,36 +314,39 @@ extern "C" long long effdet_train_levels_workspace_floats(int B, int L, const in
 }
 
 extern "C" int effdet_train_levels_dw_bwd_dw(void* stream, const float* dY, const float* X, float* out, int B, int L,
-                                             const int* Hs, const int* Ws, int C, float* workspace, long long workspace_floats,
-                                             unsigned* counters) {
+                                             const int* Hs, const int* Ws, int C, float* workspace, long long workspace_floats) {
     EFFDET_ENTER();
     LvDwWArgs p;
-    if (!dY || !X || !out || !workspace || !counters || C <= 0 || C > 64 * 64 || fill_levels(p.lv, B, L, Hs, Ws)) return EFFDET_EINVAL;
+    if (!dY || !X || !out || !workspace || C <= 0 || fill_levels(p.lv, B, L, Hs, Ws)) return EFFDET_EINVAL;
     long long per;
     const long long chunks = lv_dw_chunks(p.lv, C, &per);
     if (workspace_floats < chunks * 9 * C || chunks > 65535) return EFFDET_EINVAL;
-    p.dY = dY; p.X = X; p.partial = workspace; p.out = out; p.counter = counters; p.C = C; p.rows_per_chunk = per; p.chunks = (int)chunks;
-    hipLaunchKernelGGL(lv_dw_bwd_dw_kernel, dim3((unsigned)chunks, (unsigned)((C + 63) / 64)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), p);
-    return effdet_check_launch();
+    p.dY = dY; p.X = X; p.partial = workspace; p.C = C; p.rows_per_chunk = per; p.chunks = (int)chunks;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(lv_dw_bwd_dw_kernel, dim3((unsigned)chunks, (unsigned)((C + 63) / 64)), dim3(256), 0, st, p);
+    const int rc = effdet_check_launch();
+    if (rc) return rc;
+    return effdet_launch_reduce_mid(st, workspace, 1, (int)chunks, 9LL * C, out, 0, 1.0f);
 }
 
 extern "C" int effdet_train_levels_col_reduce(void* stream, int mode, const float* a, const float* b, const float* v,
                                               const float* pre, const float* vscale, int B, int L, const int* Hs, const int* Ws, int C, float* out,
-                                              float* workspace, long long workspace_floats, unsigned* counters) {
+                                              float* workspace, long long workspace_floats) {
     EFFDET_ENTER();
     LvColArgs p;
-    if (!a || !out || !workspace || !counters || C <= 0 || (mode != 0 && mode != 2 && mode != 4) || fill_levels(p.lv, B, L, Hs, Ws))
+    if (!a || !out || !workspace || C <= 0 || (mode != 0 && mode != 2 && mode != 4) || fill_levels(p.lv, B, L, Hs, Ws))
         return EFFDET_EINVAL;
     if ((mode == 4 && !b) || (mode >= 2 && !v)) return EFFDET_EINVAL;
     const int S = lv_col_slices(p.lv, C);
     const int cg = (C + 63) / 64;
-    if (workspace_floats < (long long)S * L * 2 * C || (long long)cg * L > 64) return EFFDET_EINVAL;
-    p.mode = mode; p.a = a; p.b = b; p.v = v; p.pre = mode == 4 ? pre : nullptr; p.partial = workspace; p.out = out; p.counter = counters; p.C = C; p.S = S;
+    if (workspace_floats < (long long)S * L * 2 * C) return EFFDET_EINVAL;
+    p.mode = mode; p.a = a; p.b = b; p.v = v; p.pre = mode == 4 ? pre : nullptr; p.partial = workspace; p.C = C; p.S = S;
     for (int l = 0; l < MAXL; ++l) p.vscale[l] = (vscale && l < L) ? vscale[l] : 1.0f;
-    hipLaunchKernelGGL(lv_col_reduce_kernel, dim3((unsigned)S, (unsigned)cg, (unsigned)L), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), p);
-    return effdet_check_launch();
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(lv_col_reduce_kernel, dim3((unsigned)S, (unsigned)cg, (unsigned)L), dim3(256), 0, st, p);
+    const int rc = effdet_check_launch();
+    if (rc) return rc;
+    return effdet_launch_reduce_mid(st, workspace, L, S, (long long)C * (mode == 4 ? 2 : 1), out, 0, 1.0f);
 }
 
 extern "C" int effdet_train_levels_bn_finalize(void* stream, const float* sum, const float* sq, int L, int C, const void* const* gamma,

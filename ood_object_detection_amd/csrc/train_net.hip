@@ -344,12 +344,18 @@ __global__ __launch_bounds__(256) void reduce_split_kernel(ReduceSplitArgs p) {
     }
 }
 
-int launch_reduce_mid(hipStream_t st, const float* in, int G, int S, long long L, float* out, int accumulate, float alpha = 1.0f) {
+}  // namespace
+// out[g][l] (+)= alpha * sum_s in[g][s][l] in fixed order (declared in common.h: the second stage of every two-stage reduction)
+int effdet_launch_reduce_mid(hipStream_t st, const float* in, int G, int S, long long L, float* out, int accumulate, float alpha) {
     ReduceMidArgs a{in, out, L, G, S, accumulate, alpha};
     const long long blocks = (L + 15) / 16;
     if (blocks > 0x7fffffffLL || G > 65535) return EFFDET_EINVAL;
     hipLaunchKernelGGL(reduce_mid_kernel, dim3((unsigned)blocks, (unsigned)G), dim3(256), 0, st, a);
     return effdet_check_launch();
+}
+namespace {
+inline int launch_reduce_mid(hipStream_t st, const float* in, int G, int S, long long L, float* out, int accumulate, float alpha = 1.0f) {
+    return effdet_launch_reduce_mid(st, in, G, S, L, out, accumulate, alpha);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -58,7 +58,6 @@ class _Ops(object):
         self.dev = device
         self._ws = None
         self._retired = []
-        self._cnt = None
 
     def st(self):
         return torch.cuda.current_stream(self.dev).cuda_stream
@@ -191,11 +190,6 @@ class _Ops(object):
         return y
 
     # ---- whole-pyramid operators (csrc/train_levels.hip) ------------------------------------------
-    def counters(self):
-        if self._cnt is None:
-            self._cnt = torch.zeros(64, dtype=torch.int32, device=self.dev)   # arrival counters: zero between launches
-        return self._cnt
-
     def lv_ws(self, lv, C):
         return self.ws(self.lib.effdet_train_levels_workspace_floats(lv.B, lv.L, lv.Hs, lv.Ws, C))
 
@@ -211,8 +205,7 @@ class _Ops(object):
         ws = self.lv_ws(lv, C)
         out = self.new(9, C)
         _lib.check(self.lib.effdet_train_levels_dw_bwd_dw(self.st(), dy.data_ptr(), x.data_ptr(), out.data_ptr(), lv.B, lv.L, lv.Hs,
-                                                          lv.Ws, C, ws.data_ptr(), ws.numel(), self.counters().data_ptr()),
-                   'effdet_train_levels_dw_bwd_dw')
+                                                          lv.Ws, C, ws.data_ptr(), ws.numel()), 'effdet_train_levels_dw_bwd_dw')
         return out
 
     def lv_col_reduce(self, lv, mode, a, b=None, v=None, pre=None, vscale=None):
@@ -221,8 +214,8 @@ class _Ops(object):
         out = self.new(lv.L, 2, C) if mode == 4 else self.new(lv.L, C)
         p = lambda t: None if t is None else t.data_ptr()
         _lib.check(self.lib.effdet_train_levels_col_reduce(self.st(), mode, a.data_ptr(), p(b), p(v), p(pre), vscale, lv.B, lv.L,
-                                                           lv.Hs, lv.Ws, C, out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                                           self.counters().data_ptr()), 'effdet_train_levels_col_reduce')
+                                                           lv.Hs, lv.Ws, C, out.data_ptr(), ws.data_ptr(), ws.numel()),
+                   'effdet_train_levels_col_reduce')
         return out
 
     def lv_bn_finalize(self, lv, sums, sq, bns, C):
