@@ -374,6 +374,24 @@ int effdet_train_levels_ew(void* stream, int op, float* out, float* out2, const 
                            const float* v0, const float* v1, const float* v2, const float* v3, const int* train,
                            int B, int L, const int* Hs, const int* Ws, int C);
 
+/* ---- one BiFPN node's FpnCombine without materialising the resampled inputs (effdet/efficientdet.py:180-245).  The n (2 or 3)
+ * source tensors are float32 NHWC [B][hs[i]][ws[i]][C]; each is the node's size (identity), half of it (nearest x2 upsample) or
+ * about twice it (3x3 / s2 TF-SAME max-pool) - told from the shapes.  method: 0 'fastattn', 1 'attn', 2 'sum'.
+ *   fpn_weights   edge_weights -> wdev = {w0, w1, w2, den}: relu and den = sum + 1e-4 | softmax, den 1 | ones, den 1
+ *   fpn_combine   fused = sum_i (R_i(x_i) * w_i) / den ('fastattn' arithmetic; else sum_i R_i(x_i) * w_i), act = silu(fused)
+ *   fpn_wgrad     dots [n][C] = sum over pixels of dfused * R_i(x_i), dfused = dact * silu'(fused); grad [n] = d edge_weights
+ *                 (workspace: effdet_train_fpn_dots_workspace_floats floats; method 2: dots only)
+ *   fpn_input_bwd out = (w_idx / den) * R_idx^T(dfused) + acc (acc optional): gradient of source tensor idx, [B][h][w][C] */
+int effdet_train_fpn_weights(void* stream, const float* edge_weights, int n, int method, float* wdev);
+int effdet_train_fpn_combine(void* stream, int n, const void* const* srcs, const int* hs, const int* ws, int method,
+                             const float* wdev, float* fused, float* act, int B, int H, int W, int C);
+long long effdet_train_fpn_dots_workspace_floats(int B, int H, int W, int C);
+int effdet_train_fpn_wgrad(void* stream, int n, const void* const* srcs, const int* hs, const int* ws, int method,
+                           const float* wdev, const float* edge_weights, const float* dact, const float* fused,
+                           float* dots, float* grad, int B, int H, int W, int C, float* workspace, long long workspace_floats);
+int effdet_train_fpn_input_bwd(void* stream, int idx, const float* src, int h, int w, const float* wdev, const float* dact,
+                               const float* fused, const float* acc, float* out, int B, int H, int W, int C);
+
 /* ---- optimizer half of the pretrain step (pretrain.py:272-276) ------------------------------------ */
 
 /* torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.Adam.step() on flat float32 buffers.

@@ -134,6 +134,14 @@ SIGNATURES = {
                                                 c_void_p]),
     'effdet_train_levels_ew': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, P(c_int), c_int, c_int, P(c_int), P(c_int), c_int]),
+    'effdet_train_fpn_weights': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    'effdet_train_fpn_combine': (c_int, [c_void_p, c_int, P(c_void_p), P(c_int), P(c_int), c_int, c_void_p, c_void_p, c_void_p,
+                                         c_int, c_int, c_int, c_int]),
+    'effdet_train_fpn_dots_workspace_floats': (c_ll, [c_int, c_int, c_int, c_int]),
+    'effdet_train_fpn_wgrad': (c_int, [c_void_p, c_int, P(c_void_p), P(c_int), P(c_int), c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_ll]),
+    'effdet_train_fpn_input_bwd': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_int, c_int, c_int, c_int]),
     'effdet_gather_ood': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_int, c_int, c_int,
                                   c_void_p, c_void_p, c_void_p]),
 }

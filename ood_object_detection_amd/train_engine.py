@@ -27,6 +27,9 @@ def _same_out(n, s):
     return (n + s - 1) // s
 
 
+_FPN_METHODS = {'fastattn': 0, 'attn': 1, 'sum': 2}
+
+
 class _Levels(object):
     """Geometry of a packed pyramid: the L levels' NHWC tensors [B, h_l, w_l, C] one behind the other (level-major rows)."""
 
@@ -271,6 +274,47 @@ class _Ops(object):
                                                         pk[0], pk[1], N, K, out.data_ptr(), ws.data_ptr(), ws.numel()),
                    'effdet_train_gemm_tn_levels')
         return out[:N * K].view(N, K), out[N * K:]
+
+    # ---- FpnCombine without materialised resampled inputs (csrc/train_fpn.hip) ------------------------
+    @staticmethod
+    def _fpn_srcs(ins):
+        import ctypes
+        n = len(ins)
+        return ((ctypes.c_void_p * n)(*[t.data_ptr() for t in ins]), (ctypes.c_int * n)(*[t.shape[1] for t in ins]),
+                (ctypes.c_int * n)(*[t.shape[2] for t in ins]))
+
+    def fpn_weights(self, ewp, n, method):
+        wdev = self.new(4)
+        _lib.check(self.lib.effdet_train_fpn_weights(self.st(), None if ewp is None else ewp.data_ptr(), n, method, wdev.data_ptr()),
+                   'effdet_train_fpn_weights')
+        return wdev
+
+    def fpn_combine(self, ins, wdev, method, H, W):
+        B, C = ins[0].shape[0], ins[0].shape[-1]
+        fused, act = self.new(B, H, W, C), self.new(B, H, W, C)
+        sp, hs, ws_ = self._fpn_srcs(ins)
+        _lib.check(self.lib.effdet_train_fpn_combine(self.st(), len(ins), sp, hs, ws_, method, wdev.data_ptr(), fused.data_ptr(),
+                                                     act.data_ptr(), B, H, W, C), 'effdet_train_fpn_combine')
+        return fused, act
+
+    def fpn_wgrad(self, ins, wdev, method, ewp, dact, fused):
+        B, H, W, C = fused.shape
+        n = len(ins)
+        ws = self.ws(self.lib.effdet_train_fpn_dots_workspace_floats(B, H, W, C))
+        out = self.new(n * C + n)
+        sp, hs, ws_ = self._fpn_srcs(ins)
+        _lib.check(self.lib.effdet_train_fpn_wgrad(self.st(), n, sp, hs, ws_, method, wdev.data_ptr(), ewp.data_ptr(), dact.data_ptr(),
+                                                   fused.data_ptr(), out.data_ptr(), out[n * C:].data_ptr(), B, H, W, C,
+                                                   ws.data_ptr(), ws.numel()), 'effdet_train_fpn_wgrad')
+        return out[n * C:]
+
+    def fpn_input_bwd(self, idx, src, wdev, dact, fused, acc=None):
+        B, H, W, C = fused.shape
+        out = torch.empty_like(src)
+        _lib.check(self.lib.effdet_train_fpn_input_bwd(self.st(), idx, src.data_ptr(), src.shape[1], src.shape[2], wdev.data_ptr(),
+                                                       dact.data_ptr(), fused.data_ptr(), None if acc is None else acc.data_ptr(),
+                                                       out.data_ptr(), B, H, W, C), 'effdet_train_fpn_input_bwd')
+        return out
 
     def reduce_rows(self, t):
         """[S, L] -> [L] in row order"""
@@ -666,6 +710,7 @@ class TrainEngine(object):
             x.append(dict(t=y, level=level))
             chs.append(F)
         nodes = fpn.fpn_config.nodes
+        lvl_hw = [(t['t'].shape[1], t['t'].shape[2]) for t in x]              # level -> (H, W)
         # x grows by 8 nodes per cell and is cut back to the last L; `ids` tracks global tensor ids for the backward pass
         tensors = list(x)
         ids = list(range(len(x)))
@@ -678,38 +723,31 @@ class TrainEngine(object):
                 ins, recs, src_ids = [], [], []
                 for off in node['inputs_offsets']:
                     src = tensors[ids[off]]
-                    y, rec = self._resample_fwd(src['t'], fn.combine.resample[str(off)], '%scombine.resample.%d.' % (p, off),
-                                                src['level'] - lvl)
-                    ins.append(y)
+                    rs = fn.combine.resample[str(off)]
+                    if abs(src['level'] - lvl) > 1:
+                        raise NotImplementedError('BiFPN edge spanning %d levels' % (src['level'] - lvl))
+                    t_in, rec = src['t'], dict(conv=None)
+                    if hasattr(rs, 'conv'):                      # channel-matching 1x1 conv + BN first (conv_after_downsample=False)
+                        t_in, rec['conv'] = self._convbn_fwd(t_in, rs.conv, '%scombine.resample.%d.conv.' % (p, off))
+                    ins.append(t_in)                             # max-pool / nearest x2 happen inside the combine kernel
                     recs.append(rec)
                     src_ids.append(ids[off])
                 method = node['weight_method']
-                ew_param = fn.combine.edge_weights
-                n_in = len(ins)
-                third = ins[2] if n_in > 2 else None
-                # fusion weights stay on the device (a float[4] = w0, w1, w2, den read by the kernel): no host read-back
-                if method == 'fastattn':
-                    wv = torch.relu(ew_param.detach())                            # efficientdet.py:238-242
-                    den = wv.sum() + 0.0001
-                    sdev = torch.cat([wv, wv.new_zeros(3 - n_in), den.reshape(1)]).contiguous()
-                    fused, act = ops.ew(7, ins[0], ins[1], third, sdev=sdev, silu_out=True)
-                elif method == 'attn':
-                    wv = torch.softmax(ew_param.detach(), 0)
-                    den = wv.new_ones(())
-                    sdev = torch.cat([wv, wv.new_zeros(3 - n_in), den.reshape(1)]).contiguous()
-                    fused, act = ops.ew(9, ins[0], ins[1], third, sdev=sdev, silu_out=True)
-                else:
-                    wv = torch.ones(n_in, dtype=torch.float32, device=self.dev)
-                    den = wv.new_ones(())
-                    sdev = torch.cat([wv, wv.new_zeros(3 - n_in), den.reshape(1)]).contiguous()
-                    fused, act = ops.ew(9, ins[0], ins[1], third, sdev=sdev, silu_out=True)
+                if method not in _FPN_METHODS:
+                    raise ValueError('unknown weight_method %r' % (method,))
+                mid = _FPN_METHODS[method]
+                ewp = fn.combine.edge_weights.detach() if mid < 2 else None
+                # fusion weights stay on the device (a float[4] = w0, w1, w2, den read by the kernels): no host read-back
+                wdev = ops.fpn_weights(ewp, len(ins), mid)
+                H_, W_ = lvl_hw[lvl]
+                fused, act = ops.fpn_combine(ins, wdev, mid, H_, W_)
                 sc = fn.after_combine.conv
                 d, rdw = self._dw_fwd(act, sc.conv_dw, p + 'after_combine.conv.conv_dw.')
                 c, rpw = self._pw_fwd(d, sc.conv_pw, p + 'after_combine.conv.conv_pw.')
                 y, rbn = self._bn_fwd(c, sc.bn, p + 'after_combine.conv.bn.')
                 tensors.append(dict(t=y, level=lvl))
                 ids.append(len(tensors) - 1)
-                saved['nodes'].append(dict(p=p, ins=ins, recs=recs, src_ids=src_ids, method=method, w=wv, den=den, fused=fused,
+                saved['nodes'].append(dict(p=p, ins=ins, recs=recs, src_ids=src_ids, method=mid, wdev=wdev, ewp=ewp, fused=fused,
                                            dw=rdw, pw=rpw, bn=rbn, out_id=len(tensors) - 1, n_in=len(ins)))
             ids = ids[-L:]
         pyr = [tensors[i] for i in ids]
@@ -859,24 +897,16 @@ class TrainEngine(object):
             dc = self._bn_bwd(nrec['bn'], dy, grads)
             dd = self._pw_bwd(nrec['pw'], dc, grads)
             dact = self._dw_bwd(nrec['dw'], dd, grads)
-            dfused = ops.silu_bwd(nrec['fused'], dact)
-            if getattr(self, 'keep_debug', False):
-                nrec['_dfused'], nrec['_dact'] = dfused, dact
-            n = nrec['n_in']
-            wt, den = nrec['w'], nrec['den']                                  # device tensors [n], []
-            if nrec['method'] in ('fastattn', 'attn'):
-                S = torch.stack([ops.col_reduce(1, dfused, nrec['ins'][i]).sum() for i in range(n)])
-                ewp = self.model.get_parameter(p + 'combine.edge_weights').detach()
-                if nrec['method'] == 'fastattn':
-                    dw = S / den - (S * wt).sum() / (den * den)
-                    grads[p + 'combine.edge_weights'] = dw * (ewp > 0).to(dw.dtype)
+            # SiLU backward, the edge-weight gradient and every input's gradient read dact / fused directly (csrc/train_fpn.hip)
+            fused, wdev, ins = nrec['fused'], nrec['wdev'], nrec['ins']
+            if nrec['method'] < 2:
+                grads[p + 'combine.edge_weights'] = ops.fpn_wgrad(ins, wdev, nrec['method'], nrec['ewp'], dact, fused)
+            for i in range(nrec['n_in']):
+                sid, rec = nrec['src_ids'][i], nrec['recs'][i]
+                if rec['conv'] is None:
+                    dt[sid] = ops.fpn_input_bwd(i, ins[i], wdev, dact, fused, acc=dt[sid])
                 else:
-                    grads[p + 'combine.edge_weights'] = wt * (S - (wt * S).sum())
-            coef = torch.cat([wt / den, wt.new_zeros(4 - n)]).contiguous()
-            for i in range(n):
-                di = ops.ew(8, dfused, sdev=coef[i:i + 1].repeat(4))
-                di = self._resample_bwd(nrec['recs'][i], di, grads)
-                add_to(nrec['src_ids'][i], di)
+                    add_to(sid, self._convbn_bwd(rec['conv'], ops.fpn_input_bwd(i, ins[i], wdev, dact, fused), grads))
         nbb = saved['nbb']
         for k in range(len(saved['extra']) - 1, -1, -1):
             rec, src = saved['extra'][k]
@@ -884,7 +914,6 @@ class TrainEngine(object):
             if dy is None:
                 continue
             add_to(src, self._resample_bwd(rec, dy, grads))
-        self._debug_dt = dt if getattr(self, 'keep_debug', False) else None
         return dt[:nbb], grads
 
 
