@@ -142,6 +142,14 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_ll]),
     'effdet_train_fpn_input_bwd': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_int, c_int, c_int, c_int]),
+    'effdet_train_dwconv_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_int, c_int, c_int, c_int, c_int, c_int]),
+    'effdet_train_se_gate': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_int, c_int]),
+    'effdet_train_gemm_nt_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_ll, c_int, c_int]),
+    'effdet_train_gemm_tn_scaled': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_ll, c_int, c_int, c_void_p, c_void_p, c_ll]),
+    'effdet_train_dwconv_bwd_dx_silu': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
     'effdet_gather_ood': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_int, c_int, c_int,
                                   c_void_p, c_void_p, c_void_p]),
 }

@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs p) {
 // ---------------------------------------------------------------------------------------- dwconv
 struct DwArgs {
     const void* X; void* Y;
+    void* Y2;                               // training forward: Y keeps the pre-activation, Y2 = silu(Y) (pool sums of Y2); else null
     const float* Wt;                        // [k*k][C] tap-major, fp32
     const float* scale; const float* shift;
     float* pool_partial;                    // [B, blocks_per_image, C] or null
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs p) {
     const int c0 = cbase + cg * 8;
     const T* X = reinterpret_cast<const T*>(p.X) + (long long)b * p.H * p.W * p.C;
     T* Y = reinterpret_cast<T*>(p.Y) + (long long)b * npix * p.C;
+    T* Y2 = p.Y2 ? reinterpret_cast<T*>(p.Y2) + (long long)b * npix * p.C : nullptr;
 
     F8 sc = load8<float>(p.scale + c0), sh = load8<float>(p.shift + c0);
     F8 pool = f8_zero();
@@ -121,6 +123,16 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs p) {
             }
         }
         F8 o;
+        if (Y2) {
+            F8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z.v[e] = acc.v[e] * sc.v[e] + sh.v[e];
+            store8<T>(Y + (long long)pix * p.C + c0, z);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { o.v[e] = to_f<T>(from_f<T>(silu_t<T>(z.v[e]))); pool.v[e] += o.v[e]; }
+            store8<T>(Y2 + (long long)pix * p.C + c0, o);
+            continue;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float v = acc.v[e] * sc.v[e] + sh.v[e];
@@ -150,6 +162,7 @@ struct SeArgs {
     const float* W2t; const float* b2;      // [R][C] (conv_expand weight transposed: coalesced over channels), [C]
     float* gate;                            // [B, C]
     int C, R, S;                            // S: slices that split the partial-sum rows
+    float* pool_out;                        // optional [B, C]: the pooled SUMS (the training backward reads them)
 };
 
 // One workgroup per image.  Every step is a short dependent chain, so the kernel is all latency: loads are
@@ -182,6 +195,7 @@ __global__ __launch_bounds__(1024) void se_gate_kernel(SeArgs p) {
         float s = 0.f;
         for (int w = 0; w < S; ++w) s += wsum[w * C + c];
         pooled[c] = s * p.inv_hw;
+        if (p.pool_out) p.pool_out[(long long)b * C + c] = s;
     }
     __syncthreads();
     for (int j = wave; j < p.R; j += 16) {
@@ -356,16 +370,14 @@ extern "C" int effdet_dwconv_blocks_per_image(int Ho, int Wo, int C) {
     return (npix + ppb - 1) / ppb;
 }
 
-extern "C" int effdet_dwconv_bn_act(void* stream, int dtype, const void* X, void* Y, const float* Wt,
-                                    const float* scale, const float* shift, int act,
-                                    float* pool_partial,
-                                    int B, int H, int W, int C, int k, int stride) {
-    EFFDET_ENTER();
+static int launch_dwconv(void* stream, int dtype, const void* X, void* Y, void* Y2, const float* Wt,
+                         const float* scale, const float* shift, int act, float* pool_partial,
+                         int B, int H, int W, int C, int k, int stride) {
     if (!X || !Y || !Wt || !scale || !shift || B <= 0 || H <= 0 || W <= 0) return EFFDET_EINVAL;
     if (C <= 0 || C % 8 || (k != 3 && k != 5) || (stride != 1 && stride != 2)) return EFFDET_EINVAL;
     if ((dtype & ~1) || (act & ~1)) return EFFDET_EINVAL;
     DwArgs a;
-    a.X = X; a.Y = Y; a.Wt = Wt; a.scale = scale; a.shift = shift; a.pool_partial = pool_partial;
+    a.X = X; a.Y = Y; a.Y2 = Y2; a.Wt = Wt; a.scale = scale; a.shift = shift; a.pool_partial = pool_partial;
     a.B = B; a.H = H; a.W = W; a.C = C; a.k = k; a.stride = stride; a.act = act;
     a.Ho = same_out(H, stride); a.Wo = same_out(W, stride);
     a.pad_t = same_pad_before(H, k, stride); a.pad_l = same_pad_before(W, k, stride);
@@ -389,18 +401,49 @@ extern "C" int effdet_dwconv_bn_act(void* stream, int dtype, const void* X, void
     return effdet_check_launch();
 }
 
-extern "C" int effdet_se_gate(void* stream, const float* partial, int nblk, int hw,
-                              const float* W1, const float* b1, const float* W2t, const float* b2,
-                              float* gate, int B, int C, int R) {
+extern "C" int effdet_dwconv_bn_act(void* stream, int dtype, const void* X, void* Y, const float* Wt,
+                                    const float* scale, const float* shift, int act,
+                                    float* pool_partial,
+                                    int B, int H, int W, int C, int k, int stride) {
     EFFDET_ENTER();
+    return launch_dwconv(stream, dtype, X, Y, nullptr, Wt, scale, shift, act, pool_partial, B, H, W, C, k, stride);
+}
+
+// training forward of conv_dw + folded BN + SiLU: Z = pre-activation (kept for the backward), A = silu(Z), and the SE pool
+// partial rows of A ([B][effdet_dwconv_blocks_per_image][C], optional) from the same pass
+extern "C" int effdet_train_dwconv_fwd(void* stream, const float* X, float* Z, float* A, const float* Wt, const float* scale,
+                                       const float* shift, float* pool_partial, int B, int H, int W, int C, int k, int stride) {
+    EFFDET_ENTER();
+    if (!A) return EFFDET_EINVAL;
+    return launch_dwconv(stream, 0, X, Z, A, Wt, scale, shift, 1, pool_partial, B, H, W, C, k, stride);
+}
+
+static int launch_se_gate(void* stream, const float* partial, int nblk, int hw,
+                          const float* W1, const float* b1, const float* W2t, const float* b2,
+                          float* gate, float* pool_out, int B, int C, int R) {
     if (!partial || !W1 || !b1 || !W2t || !b2 || !gate || nblk <= 0 || hw <= 0 || B <= 0 || C <= 0 || R <= 0) return EFFDET_EINVAL;
     int S = 1024 / C; if (S < 1) S = 1; if (S > 16) S = 16; if (S > nblk) S = nblk;
     while (S > 1 && (size_t)((S + 1) * C + R) * sizeof(float) > 64 * 1024) --S;
-    SeArgs a{partial, nblk, 1.0f / (float)hw, W1, b1, W2t, b2, gate, C, R, S};
+    SeArgs a{partial, nblk, 1.0f / (float)hw, W1, b1, W2t, b2, gate, C, R, S, pool_out};
     const size_t sh = (size_t)((S + 1) * C + R) * sizeof(float);
     if (sh > 64 * 1024) return EFFDET_EINVAL;
     hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(1024), sh, reinterpret_cast<hipStream_t>(stream), a);
     return effdet_check_launch();
+}
+
+extern "C" int effdet_se_gate(void* stream, const float* partial, int nblk, int hw,
+                              const float* W1, const float* b1, const float* W2t, const float* b2,
+                              float* gate, int B, int C, int R) {
+    EFFDET_ENTER();
+    return launch_se_gate(stream, partial, nblk, hw, W1, b1, W2t, b2, gate, nullptr, B, C, R);
+}
+
+// the same gate, also writing the pooled sums [B][C] that effdet_train_se_bwd reads
+extern "C" int effdet_train_se_gate(void* stream, const float* partial, int nblk, int hw, const float* W1, const float* b1,
+                                    const float* W2t, const float* b2, float* gate, float* pool_sum, int B, int C, int R) {
+    EFFDET_ENTER();
+    if (!pool_sum) return EFFDET_EINVAL;
+    return launch_se_gate(stream, partial, nblk, hw, W1, b1, W2t, b2, gate, pool_sum, B, C, R);
 }
 
 extern "C" int effdet_maxpool_same(void* stream, int dtype, const void* X, long long x_image_stride,

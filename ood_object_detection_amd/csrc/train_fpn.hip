@@ -68,53 +68,46 @@ __global__ __launch_bounds__(256) void fpn_combine_kernel(FpnArgs p) {
     *reinterpret_cast<f32x4*>(p.out2 + i * 4) = q;
 }
 
-// partial[slice][i][c] = sum over the slice's pixels of dfused * R_i(x_i); workgroup = 64 channels x 4 pixel lanes
+// partial[slice][i][c] = sum over the slice's pixels of dfused * R_i(x_i); workgroup = 64 channels (16 threads x 4 channels,
+// 16-byte loads) x 16 pixel lanes, the pixel lanes' sums added in lane order
 __global__ __launch_bounds__(256) void fpn_dots_kernel(FpnArgs p) {
-    __shared__ float sm[4][3][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.y * 64 + cl;
+    __shared__ float sm[16][3][64];
+    const int ct = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + ct * 4;
     const bool cv = c < p.C;
     const long long R = (long long)p.B * p.H * p.W;
     const long long rb = (long long)blockIdx.x * p.rows_per_slice;
     long long re = rb + p.rows_per_slice;
     if (re > R) re = R;
-    float acc[3] = {0.f, 0.f, 0.f};
+    f32x4 acc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (cv) {
-        for (long long r = rb + rl; r < re; r += 4) {
+        for (long long r = rb + rl; r < re; r += 16) {
             const int x = (int)(r % p.W);
             const long long t = r / p.W;
             const int y = (int)(t % p.H);
             const long long b = t / p.H;
-            const float d = p.dact[r * p.C + c] * fpn_silu_grad(p.fused[r * p.C + c]);
+            f32x4 d = *reinterpret_cast<const f32x4*>(p.dact + r * p.C + c);
+            const f32x4 z = *reinterpret_cast<const f32x4*>(p.fused + r * p.C + c);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                if (i >= p.n) break;
-                const FpnIn& in = p.in[i];
-                float v;
-                if (in.delta == 0) v = in.p[((b * in.h + y) * in.w + x) * p.C + c];
-                else if (in.delta > 0) v = in.p[((b * in.h + (y >> 1)) * in.w + (x >> 1)) * p.C + c];
-                else {
-                    v = -INFINITY;
-                    for (int ky = 0; ky < 3; ++ky) {
-                        const int yy = y * 2 + ky - in.pad_t;
-                        if (yy < 0 || yy >= in.h) continue;
-                        for (int kx = 0; kx < 3; ++kx) {
-                            const int xx = x * 2 + kx - in.pad_l;
-                            if (xx < 0 || xx >= in.w) continue;
-                            v = fmaxf(v, in.p[((b * in.h + yy) * in.w + xx) * p.C + c]);
-                        }
-                    }
-                }
-                acc[i] += d * v;
-            }
+            for (int j = 0; j < 4; ++j) d[j] *= fpn_silu_grad(z[j]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (i < p.n) acc[i] += d * fpn_sample(p.in[i], b, y, x, c, p.C);
         }
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) sm[rl][i][cl] = acc[i];
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sm[rl][i][ct * 4 + j] = acc[i][j];
     __syncthreads();
-    if (rl == 0 && cv) {
-        float* dst = p.partial + (long long)blockIdx.x * p.n * p.C + c;
-        for (int i = 0; i < p.n; ++i) dst[(long long)i * p.C] = ((sm[0][i][cl] + sm[1][i][cl]) + sm[2][i][cl]) + sm[3][i][cl];
+    const int cl = threadIdx.x & 63, i = threadIdx.x >> 6;
+    if (i < p.n && blockIdx.y * 64 + cl < p.C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sm[k][i][cl];
+        p.partial[((long long)blockIdx.x * p.n + i) * p.C + blockIdx.y * 64 + cl] = t;
     }
 }
 
@@ -287,7 +280,7 @@ extern "C" int effdet_train_fpn_wgrad(void* stream, int n, const void* const* sr
                                       long long workspace_floats) {
     EFFDET_ENTER();
     if (n < 2 || n > 3 || !srcs || !hs || !ws || !wdev || !dact || !fused || !dots || !workspace || B <= 0 || H <= 0 || W <= 0 ||
-        C <= 0 || method < 0 || method > 2 || (method < 2 && (!grad || !edge_weights))) return EFFDET_EINVAL;
+        C <= 0 || C % 4 || method < 0 || method > 2 || (method < 2 && (!grad || !edge_weights))) return EFFDET_EINVAL;
     FpnArgs p{};
     for (int i = 0; i < 3; ++i)
         if (fpn_fill_in(p.in[i], static_cast<const float*>(srcs[i < n ? i : 0]), hs[i < n ? i : 0], ws[i < n ? i : 0], H, W)) return EFFDET_EINVAL;

@@ -81,30 +81,30 @@ __global__ __launch_bounds__(256) void lv_dw_kernel(LvDwArgs p) {
     *reinterpret_cast<f32x4*>(p.Y + row * p.C + c) = acc;
 }
 
-// d taps[t][c] = sum over every row of every level of dY[row][c] * X[row + tap t][c].  Workgroup = 64 channels x 4 row lanes
-// over a chunk of rows; partial [chunk][9][C].
+// d taps[t][c] = sum over every row of every level of dY[row][c] * X[row + tap t][c].  Workgroup = 64 channels (16 threads x 4
+// channels, 16-byte loads) x 16 row lanes over a chunk of rows; partial [chunk][9][C].
 struct LvDwWArgs { const float* dY; const float* X; float* partial; Levels lv; int C; long long rows_per_chunk; int chunks; };
 
 __global__ __launch_bounds__(256) void lv_dw_bwd_dw_kernel(LvDwWArgs p) {
-    __shared__ float sm[4][9][64];
-    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const int c = blockIdx.y * 64 + cl;
+    __shared__ float sm[16][9][64];
+    const int ct = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + ct * 4;
     const bool cv = c < p.C;
-    float acc[9];
+    f32x4 acc[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const long long rb = (long long)blockIdx.x * p.rows_per_chunk;
     long long re = rb + p.rows_per_chunk;
     const long long R = p.lv.row0[p.lv.n];
     if (re > R) re = R;
     if (cv) {
-        for (long long row = rb + pl; row < re; row += 4) {
+        for (long long row = rb + rl; row < re; row += 16) {
             const int l = level_of(p.lv, row);
             const int H = p.lv.H[l], W = p.lv.W[l];
             const long long local = row - p.lv.row0[l];
             const int x = (int)(local % W);
             const int y = (int)((local / W) % H);
-            const float d = p.dY[row * p.C + c];
+            const f32x4 d = *reinterpret_cast<const f32x4*>(p.dY + row * p.C + c);
             const float* xb = p.X + (row - ((long long)y * W + x)) * p.C + c;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
@@ -113,20 +113,24 @@ __global__ __launch_bounds__(256) void lv_dw_bwd_dw_kernel(LvDwWArgs p) {
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int xx = x + kx - 1;
-                    const bool v = yv && xx >= 0 && xx < W;
-                    const float xv = v ? xb[((long long)yy * W + xx) * p.C] : 0.f;
-                    acc[ky * 3 + kx] += d * xv;
+                    if (yv && xx >= 0 && xx < W)
+                        acc[ky * 3 + kx] += d * *reinterpret_cast<const f32x4*>(xb + ((long long)yy * W + xx) * p.C);
                 }
             }
         }
     }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) sm[pl][t][cl] = acc[t];
-    __syncthreads();
-    if (pl == 0 && cv) {
-        float* dst = p.partial + (long long)blockIdx.x * 9 * p.C;
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) dst[(long long)t * p.C + c] = ((sm[0][t][cl] + sm[1][t][cl]) + sm[2][t][cl]) + sm[3][t][cl];
+        for (int j = 0; j < 4; ++j) sm[rl][t][ct * 4 + j] = acc[t][j];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 9 * 64; e += 256) {
+        const int t = e >> 6, cl = e & 63;
+        if (blockIdx.y * 64 + cl >= p.C) continue;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += sm[k][t][cl];
+        p.partial[((long long)blockIdx.x * 9 + t) * p.C + blockIdx.y * 64 + cl] = s;
     }
 }
 
@@ -139,11 +143,12 @@ struct LvColArgs {
     Levels lv; float vscale[MAXL]; int C, S;
 };
 
+// workgroup = 64 channels (16 threads x 4 channels, 16-byte loads) x 16 row lanes; the row lanes' sums are added in lane order
 __global__ __launch_bounds__(256) void lv_col_reduce_kernel(LvColArgs p) {
-    __shared__ float sm[4][64];
-    __shared__ float sm2[4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.y * 64 + cl;
+    __shared__ float sm[16][64];
+    __shared__ float sm2[16][64];
+    const int ct = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + ct * 4;
     const int l = blockIdx.z, s = blockIdx.x;
     const bool cv = c < p.C;
     const long long R = p.lv.row0[l + 1] - p.lv.row0[l];
@@ -152,27 +157,38 @@ __global__ __launch_bounds__(256) void lv_col_reduce_kernel(LvColArgs p) {
     const long long rb = p.lv.row0[l] + (long long)s * per;
     long long re = rb + per;
     if (re > p.lv.row0[l + 1]) re = p.lv.row0[l + 1];
-    float acc = 0.f, acc2 = 0.f;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (cv) {
-        const float vc = p.mode >= 2 ? p.v[(long long)l * p.C + c] * p.vscale[l] : 0.f;
-        for (long long r = rb + rl; r < re; r += 4) {
-            const float a = p.a[r * p.C + c];
+        f32x4 vc = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.mode >= 2) vc = *reinterpret_cast<const f32x4*>(p.v + (long long)l * p.C + c) * p.vscale[l];
+        for (long long r = rb + rl; r < re; r += 16) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p.a + r * p.C + c);
             if (p.mode == 0) acc += a;
-            else if (p.mode == 2) { const float d = a - vc; acc += d * d; }
+            else if (p.mode == 2) { const f32x4 d = a - vc; acc += d * d; }
             else {
-                const float ad = p.pre ? a * lv_silu_grad(p.pre[r * p.C + c]) : a;
-                acc += ad; acc2 += ad * (p.b[r * p.C + c] - vc);
+                f32x4 ad = a;
+                if (p.pre) {
+                    const f32x4 z = *reinterpret_cast<const f32x4*>(p.pre + r * p.C + c);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ad[j] = a[j] * lv_silu_grad(z[j]);
+                }
+                acc += ad;
+                acc2 += ad * (*reinterpret_cast<const f32x4*>(p.b + r * p.C + c) - vc);
             }
         }
     }
-    sm[rl][cl] = acc;
-    sm2[rl][cl] = acc2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sm[rl][ct * 4 + j] = acc[j]; sm2[rl][ct * 4 + j] = acc2[j]; }
     __syncthreads();
     const int Wd = p.mode == 4 ? 2 : 1;
-    if (rl == 0 && cv) {
-        float* dst = p.partial + ((long long)l * p.S + s) * Wd * p.C + c;
-        dst[0] = ((sm[0][cl] + sm[1][cl]) + sm[2][cl]) + sm[3][cl];
-        if (Wd == 2) dst[p.C] = ((sm2[0][cl] + sm2[1][cl]) + sm2[2][cl]) + sm2[3][cl];
+    const int cl = threadIdx.x;
+    if (cl < 64 && blockIdx.y * 64 + cl < p.C) {
+        float* dst = p.partial + ((long long)l * p.S + s) * Wd * p.C + blockIdx.y * 64 + cl;
+        float t = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { t += sm[k][cl]; t2 += sm2[k][cl]; }
+        dst[0] = t;
+        if (Wd == 2) dst[p.C] = t2;
     }
 }
 
@@ -317,7 +333,7 @@ extern "C" int effdet_train_levels_dw_bwd_dw(void* stream, const float* dY, cons
                                              const int* Hs, const int* Ws, int C, float* workspace, long long workspace_floats) {
     EFFDET_ENTER();
     LvDwWArgs p;
-    if (!dY || !X || !out || !workspace || C <= 0 || fill_levels(p.lv, B, L, Hs, Ws)) return EFFDET_EINVAL;
+    if (!dY || !X || !out || !workspace || C <= 0 || C % 4 || fill_levels(p.lv, B, L, Hs, Ws)) return EFFDET_EINVAL;
     long long per;
     const long long chunks = lv_dw_chunks(p.lv, C, &per);
     if (workspace_floats < chunks * 9 * C || chunks > 65535) return EFFDET_EINVAL;
@@ -334,7 +350,7 @@ extern "C" int effdet_train_levels_col_reduce(void* stream, int mode, const floa
                                               float* workspace, long long workspace_floats) {
     EFFDET_ENTER();
     LvColArgs p;
-    if (!a || !out || !workspace || C <= 0 || (mode != 0 && mode != 2 && mode != 4) || fill_levels(p.lv, B, L, Hs, Ws))
+    if (!a || !out || !workspace || C <= 0 || C % 4 || (mode != 0 && mode != 2 && mode != 4) || fill_levels(p.lv, B, L, Hs, Ws))
         return EFFDET_EINVAL;
     if ((mode == 4 && !b) || (mode >= 2 && !v)) return EFFDET_EINVAL;
     const int S = lv_col_slices(p.lv, C);

@@ -69,6 +69,8 @@ struct GemmNtArgs {
     const float* A; RowMap am; const float* W; const float* bias; float* C; RowMap cm;
     long long M; int K, N, accumulate, vec_out;
     float* C2;                                 // optional second output with the row map of C: silu(C)
+    const float* R;                            // optional residual with the row map of C, added after the bias
+    const float* a_scale; long long a_scale_rpi;   // optional per-image scale of A's columns (SE gate [img][K]), img = row / a_scale_rpi
 };
 
 // VW: widest aligned load the rows allow (4 = 16 bytes, 2 = 8 bytes: e.g. the 810-channel class head, 1 = scalar)
@@ -101,6 +103,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
     const int n0 = blockIdx.y * 64;
     if (m0 >= p.M) return;                                   // wave-uniform, no barriers in this kernel
     const float* arow[RT];
+    const float* grow[RT];
     bool mv[RT];
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
@@ -108,7 +111,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
         mv[i] = m < p.M;
         if (!mv[i]) m = p.M - 1;
         arow[i] = p.A + row_off(p.am, m);
+        grow[i] = p.a_scale ? p.a_scale + (m / p.a_scale_rpi) * p.K : nullptr;
     }
+    auto lda = [&](int i, int k) {                            // A fragment, times the image's gate where there is one
+        Frag<float> f = ld_k4<VEC>(arow[i], k, p.K);
+        if (p.a_scale) f.v *= ld_k4<VEC>(grow[i], k, p.K).v;
+        return f;
+    };
     const float* wrow[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -123,14 +132,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
         for (int t = 0; t < 4; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     Frag<float> bc[RT], ac[4];
 #pragma unroll
-    for (int i = 0; i < RT; ++i) bc[i] = ld_k4<VEC>(arow[i], 4 * g, p.K);
+    for (int i = 0; i < RT; ++i) bc[i] = lda(i, 4 * g);
 #pragma unroll
     for (int t = 0; t < 4; ++t) ac[t] = ld_k4<VEC>(wrow[t], 4 * g, p.K);
     for (int k0 = 0; k0 < p.K; k0 += 16) {
         const int kn = k0 + 16 + 4 * g;                       // past the end of K: ld_k4 returns zeros without touching memory
         Frag<float> bn[RT], an[4];
 #pragma unroll
-        for (int i = 0; i < RT; ++i) bn[i] = ld_k4<VEC>(arow[i], kn, p.K);
+        for (int i = 0; i < RT; ++i) bn[i] = lda(i, kn);
 #pragma unroll
         for (int t = 0; t < 4; ++t) an[t] = ld_k4<VEC>(wrow[t], kn, p.K);
 #pragma unroll
@@ -154,6 +163,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
                 if (n < p.N) {
                     f32x4 v = acc[i][t];
                     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                    if (p.R) v += *reinterpret_cast<const f32x4*>(p.R + coff + n);
                     if (p.accumulate) v += *reinterpret_cast<const f32x4*>(crow + n);
                     *reinterpret_cast<f32x4*>(crow + n) = v;
                     if (p.C2) {
@@ -170,6 +180,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
                 if (n + r < p.N) {
                     float v = acc[i][t][r];
                     if (p.bias) v += p.bias[n + r];
+                    if (p.R) v += p.R[coff + n + r];
                     if (p.accumulate) v += crow[n + r];
                     crow[n + r] = v;
                     if (p.C2) p.C2[coff + n + r] = silu_f(v);
@@ -185,6 +196,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
 struct GemmTnArgs {
     const float* dY; RowMap ym; const float* X; RowMap xm; float* partial;
     long long M, rows_per_slice; int N, K, S;
+    const float* x_scale; long long x_scale_rpi;     // optional per-image scale of X's columns (SE gate [img][K])
 };
 
 // 32 rows of dY [32 n] and X [64 k] per step are staged in LDS with 16-byte global loads (rows padded to 48 / 80 floats:
@@ -235,10 +247,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
             if (m < me) {
                 const float* row = p.X + row_off(p.xm, m);
                 const int kk = k0 + xc;
-                if (VX && kk + 3 < p.K) vx[h] = *reinterpret_cast<const f32x4*>(row + kk);
-                else {
+                const float* gr = p.x_scale ? p.x_scale + (m / p.x_scale_rpi) * p.K : nullptr;
+                if (VX && kk + 3 < p.K) {
+                    vx[h] = *reinterpret_cast<const f32x4*>(row + kk);
+                    if (gr) vx[h] *= *reinterpret_cast<const f32x4*>(gr + kk);
+                } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) vx[h][e] = kk + e < p.K ? row[kk + e] : (kk + e == p.K ? 1.f : 0.f);
+                    for (int e = 0; e < 4; ++e)
+                        vx[h][e] = kk + e < p.K ? (gr ? row[kk + e] * gr[kk + e] : row[kk + e]) : (kk + e == p.K ? 1.f : 0.f);
                 }
             }
         }
@@ -358,11 +374,14 @@ inline int launch_reduce_mid(hipStream_t st, const float* in, int G, int S, long
     return effdet_launch_reduce_mid(st, in, G, S, L, out, accumulate, alpha);
 }
 
+DEV float silu_grad(float z) { const float s = sigmoid_f(z); return s * (1.0f + z * (1.0f - s)); }
+
 // ------------------------------------------------------------------------------------------------------------
 // depthwise backward
 // ------------------------------------------------------------------------------------------------------------
 struct DwBwdArgs {
     const float* dY; const float* X; const float* taps; float* dX; float* partial;
+    const float* Z;                            // dx kernel, optional: dX is multiplied by silu'(Z) (Z = pre-activation of the layer below)
     int B, H, W, C, k, stride, Ho, Wo, pad_t, pad_l; long long segs_per_chunk; int seg;
 };
 
@@ -393,7 +412,13 @@ __global__ __launch_bounds__(256) void dw_bwd_dx_kernel(DwBwdArgs p) {
             acc += d * w;
         }
     }
-    *reinterpret_cast<f32x4*>(p.dX + (((long long)b * p.H + iy) * p.W + ix) * p.C + c) = acc;
+    const long long o = (((long long)b * p.H + iy) * p.W + ix) * p.C + c;
+    if (p.Z) {
+        const f32x4 z = *reinterpret_cast<const f32x4*>(p.Z + o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] *= silu_grad(z[j]);
+    }
+    *reinterpret_cast<f32x4*>(p.dX + o) = acc;
 }
 
 // partial[chunk][k*k+1][C]: taps gradient + sum of dY.  block = 64 channels x 4 lanes; a lane walks row segments of
@@ -481,7 +506,6 @@ struct EwArgs {
     float* out2;                               // optional second output: silu(out)
 };
 
-DEV float silu_grad(float z) { const float s = sigmoid_f(z); return s * (1.0f + z * (1.0f - s)); }
 // second derivative of z * sigmoid(z): sigma (1 - sigma) (2 + z (1 - 2 sigma))   (double backward of the MetaHead, infer.py:658)
 DEV float silu_grad2(float z) { const float s = sigmoid_f(z); return s * (1.0f - s) * (2.0f + z * (1.0f - 2.0f * s)); }
 
@@ -546,6 +570,14 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = a[j] * b[j] * silu_grad2(z[j]);
         break; }
+    case 12: {                                          // SE gate backward, then SiLU backward: (a * gate + ds * s0) * silu'(c)
+        const long long img = i / p.hwC;
+        const f32x4 z = *reinterpret_cast<const f32x4*>(p.c + i);
+        o = a * *reinterpret_cast<const f32x4*>(p.v0 + img * p.C + ch)
+            + *reinterpret_cast<const f32x4*>(p.v1 + img * p.C + ch) * p.s0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] *= silu_grad(z[j]);
+        break; }
     default:                                            // 9: weighted sum without the division ('attn' / 'sum')
     {
         const f32x4 b = *reinterpret_cast<const f32x4*>(p.b + i);
@@ -570,37 +602,59 @@ struct ColArgs {
     long long R, rows_per_slice; int C, S;
 };
 // modes: 0 sum a; 1 sum a*b; 2 sum (a - v[c])^2; 3 sum a*(b - v[c]); 4: both 0 and 3 in one pass (out [G][2][C])
+// V = channels per thread (4: 16-byte loads, a wave reads 4 whole rows of a 64-channel group per instruction; 1: any C).
+// Workgroup = 64 channels x (256 * V / 64) row lanes; the row lanes' sums are added in lane order (fixed association).
+template <int V> struct ColVec;
+template <> struct ColVec<1> { typedef float type; static DEV float get(float v, int) { return v; } };
+template <> struct ColVec<4> { typedef f32x4 type; static DEV float get(const f32x4& v, int j) { return v[j]; } };
+template <int V>
 __global__ __launch_bounds__(256) void col_reduce_kernel(ColArgs p) {
-    __shared__ float sm[4][64];
-    __shared__ float sm2[4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.y * 64 + cl;
+    constexpr int TPG = 64 / V, RL = 256 / TPG;
+    typedef typename ColVec<V>::type vec;
+    __shared__ float sm[RL][64];
+    __shared__ float sm2[RL][64];
+    const int ct = threadIdx.x % TPG, rl = threadIdx.x / TPG;
+    const int c = blockIdx.y * 64 + ct * V;
     const int gi = blockIdx.z, s = blockIdx.x;
-    const bool cv = c < p.C;
+    const bool cv = c < p.C;                                  // V > 1 only with C % V == 0: a vector is inside or outside as a whole
     const long long rb = (long long)s * p.rows_per_slice;
     long long re = rb + p.rows_per_slice;
     if (re > p.R) re = p.R;
-    float acc = 0.f, acc2 = 0.f;
+    float acc[V], acc2[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { acc[j] = 0.f; acc2[j] = 0.f; }
     if (cv) {
-        const float vc = (p.mode >= 2) ? p.v[c] : 0.f;
+        float vc[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) vc[j] = (p.mode >= 2) ? p.v[c + j] : 0.f;
         const long long base = (long long)gi * p.R * p.C + c;
-        for (long long r = rb + rl; r < re; r += 4) {
-            const float a = p.a[base + r * p.C];
-            if (p.mode == 0) acc += a;
-            else if (p.mode == 1) acc += a * p.b[base + r * p.C];
-            else if (p.mode == 2) { const float d = a - vc; acc += d * d; }
-            else if (p.mode == 3) acc += a * (p.b[base + r * p.C] - vc);
-            else { acc += a; acc2 += a * (p.b[base + r * p.C] - vc); }
+        for (long long r = rb + rl; r < re; r += RL) {
+            const vec a = *reinterpret_cast<const vec*>(p.a + base + r * p.C);
+            vec b = a;
+            if (p.mode == 1 || p.mode >= 3) b = *reinterpret_cast<const vec*>(p.b + base + r * p.C);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float aj = ColVec<V>::get(a, j), bj = ColVec<V>::get(b, j);
+                if (p.mode == 0) acc[j] += aj;
+                else if (p.mode == 1) acc[j] += aj * bj;
+                else if (p.mode == 2) { const float d = aj - vc[j]; acc[j] += d * d; }
+                else if (p.mode == 3) acc[j] += aj * (bj - vc[j]);
+                else { acc[j] += aj; acc2[j] += aj * (bj - vc[j]); }
+            }
         }
     }
-    sm[rl][cl] = acc;
-    sm2[rl][cl] = acc2;
+#pragma unroll
+    for (int j = 0; j < V; ++j) { sm[rl][ct * V + j] = acc[j]; sm2[rl][ct * V + j] = acc2[j]; }
     __syncthreads();
-    if (rl == 0 && cv) {
+    const int cl = threadIdx.x;
+    if (cl < 64 && blockIdx.y * 64 + cl < p.C) {
         const int W = p.mode == 4 ? 2 : 1;
-        float* dst = p.partial + ((long long)gi * p.S + s) * W * p.C + c;
-        dst[0] = ((sm[0][cl] + sm[1][cl]) + sm[2][cl]) + sm[3][cl];
-        if (W == 2) dst[p.C] = ((sm2[0][cl] + sm2[1][cl]) + sm2[2][cl]) + sm2[3][cl];
+        float* dst = p.partial + ((long long)gi * p.S + s) * W * p.C + blockIdx.y * 64 + cl;
+        float t = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < RL; ++k) { t += sm[k][cl]; t2 += sm2[k][cl]; }
+        dst[0] = t;
+        if (W == 2) dst[p.C] = t2;
     }
 }
 
@@ -690,7 +744,7 @@ __global__ __launch_bounds__(256) void im2col_stem_kernel(Im2colArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// SqueezeExcite backward (one workgroup per image)
+// SqueezeExcite backward (one 1024-thread workgroup per image: every phase is a short latency-bound loop)
 // ------------------------------------------------------------------------------------------------------------
 struct SeBwdArgs {
     const float* pool_sum; float inv_hw; const float* gate; const float* dgate;
@@ -699,7 +753,7 @@ struct SeBwdArgs {
 };
 // gate = sigmoid(u), u = W2 r + b2, r = silu(rp), rp = W1 s + b1, s = pool_sum / hw.
 // pgrad[img] = { dW1 [R][C], db1 [R], dW2t [R][C], db2 [C] } for this image; ds[img][c] = d loss / d s.
-__global__ __launch_bounds__(256) void se_bwd_kernel(SeBwdArgs p) {
+__global__ __launch_bounds__(1024) void se_bwd_kernel(SeBwdArgs p) {
     extern __shared__ float sh[];
     float* s = sh;                    // [C]
     float* du = sh + p.C;             // [C]
@@ -710,7 +764,7 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(SeBwdArgs p) {
     const long long bc = (long long)img * p.C;
     float* pg = p.pgrad + (long long)img * (2LL * p.R * p.C + p.R + p.C);
     float* dW1 = pg; float* db1 = pg + (long long)p.R * p.C; float* dW2t = db1 + p.R; float* db2 = dW2t + (long long)p.R * p.C;
-    for (int c = tid; c < p.C; c += 256) {
+    for (int c = tid; c < p.C; c += 1024) {
         s[c] = p.pool_sum[bc + c] * p.inv_hw;
         const float g = p.gate[bc + c];
         const float d = p.dgate[bc + c] * g * (1.0f - g);
@@ -718,7 +772,7 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(SeBwdArgs p) {
         db2[c] = d;
     }
     __syncthreads();
-    for (int r = wave; r < p.R; r += 4) {
+    for (int r = wave; r < p.R; r += 16) {
         float a = 0.f, d = 0.f;
         for (int c = lane; c < p.C; c += 64) {
             a += p.W1[(long long)r * p.C + c] * s[c];
@@ -735,7 +789,7 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(SeBwdArgs p) {
         }
     }
     __syncthreads();
-    for (int c = tid; c < p.C; c += 256) {
+    for (int c = tid; c < p.C; c += 1024) {
         float acc = 0.f;
         const float sc = s[c], dc = du[c];
         for (int r = 0; r < p.R; ++r) {
@@ -852,7 +906,8 @@ static int launch_gemm_nt(hipStream_t st, GemmNtArgs& p) {
                      reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(W) % 16 == 0;
     p.vec_out = N % 4 == 0 && p.cm.ld % 4 == 0 && p.cm.img_stride % 4 == 0 && reinterpret_cast<uintptr_t>(C) % 16 == 0 &&
                 (bias == nullptr || reinterpret_cast<uintptr_t>(bias) % 16 == 0) &&
-                (C2 == nullptr || reinterpret_cast<uintptr_t>(C2) % 16 == 0);
+                (C2 == nullptr || reinterpret_cast<uintptr_t>(C2) % 16 == 0) &&
+                (p.R == nullptr || reinterpret_cast<uintptr_t>(p.R) % 16 == 0);
     const dim3 grid((unsigned)gx, (unsigned)((N + 63) / 64));
     const bool vec2 = K % 2 == 0 && p.am.ld % 2 == 0 && p.am.img_stride % 2 == 0 &&
                       reinterpret_cast<uintptr_t>(A) % 8 == 0 && reinterpret_cast<uintptr_t>(W) % 8 == 0;
@@ -869,8 +924,24 @@ extern "C" int effdet_train_gemm_nt(void* stream, const float* A, long long a_rp
     if (!A || !W || !C || M <= 0 || K <= 0 || N <= 0) return EFFDET_EINVAL;
     GemmNtArgs p;
     p.A = A; p.W = W; p.bias = bias; p.C = C; p.M = M; p.K = K; p.N = N; p.accumulate = accumulate; p.C2 = C2;
+    p.R = nullptr; p.a_scale = nullptr; p.a_scale_rpi = 1;
     p.am = make_rowmap(a_rpi, a_img_stride, a_ld, M, K);
     p.cm = make_rowmap(c_rpi, c_img_stride, c_ld, M, N);
+    return launch_gemm_nt(reinterpret_cast<hipStream_t>(stream), p);
+}
+
+// Dense rows with the fused forms of an MBConv block: C = (A * a_scale[row / a_scale_rows]) W^T + bias + R, C2 = silu(C)
+// (a_scale [M / a_scale_rows][K]: the SE gate applied while A is loaded; R [M][N]: the shortcut; each optional)
+extern "C" int effdet_train_gemm_nt_fused(void* stream, const float* A, const float* a_scale, long long a_scale_rows, const float* W,
+                                          const float* bias, const float* R, float* C, float* C2, long long M, int K, int N) {
+    EFFDET_ENTER();
+    if (!A || !W || !C || M <= 0 || K <= 0 || N <= 0 || (a_scale && a_scale_rows <= 0)) return EFFDET_EINVAL;
+    if (a_scale && (K % 4 || reinterpret_cast<uintptr_t>(a_scale) % 16)) return EFFDET_EINVAL;
+    GemmNtArgs p;
+    p.A = A; p.W = W; p.bias = bias; p.C = C; p.M = M; p.K = K; p.N = N; p.accumulate = 0; p.C2 = C2;
+    p.R = R; p.a_scale = a_scale; p.a_scale_rpi = a_scale ? a_scale_rows : 1;
+    p.am = make_rowmap(0, 0, 0, M, K);
+    p.cm = make_rowmap(0, 0, 0, M, N);
     return launch_gemm_nt(reinterpret_cast<hipStream_t>(stream), p);
 }
 
@@ -886,6 +957,7 @@ extern "C" int effdet_train_gemm_nt_levels(void* stream, const float* A, int a_p
     const long long M = make_levels_rowmap(lm, B, L, Hs, Ws, pk_img_stride > 0 ? pk_img_stride : 1, pk_ld > 0 ? pk_ld : 1);
     if (M <= 0) return EFFDET_EINVAL;
     p.A = A; p.W = W; p.bias = bias; p.C = C; p.M = M; p.K = K; p.N = N; p.accumulate = 0; p.C2 = C2;
+    p.R = nullptr; p.a_scale = nullptr; p.a_scale_rpi = 1;
     p.am = a_packed ? lm : make_rowmap(0, 0, 0, M, K);
     p.cm = c_packed ? lm : make_rowmap(0, 0, 0, M, N);
     if ((a_packed && pk_ld < K) || (c_packed && pk_ld < N)) return EFFDET_EINVAL;
@@ -943,9 +1015,22 @@ extern "C" int effdet_train_gemm_tn(void* stream, const float* dY, long long y_r
     EFFDET_ENTER();
     if (!dY || !X || !out || !workspace || M <= 0 || N <= 0 || K <= 0) return EFFDET_EINVAL;
     GemmTnArgs p;
-    p.dY = dY; p.X = X; p.M = M; p.N = N; p.K = K;
+    p.dY = dY; p.X = X; p.M = M; p.N = N; p.K = K; p.x_scale = nullptr; p.x_scale_rpi = 1;
     p.ym = make_rowmap(y_rpi, y_img_stride, y_ld, M, N);
     p.xm = make_rowmap(x_rpi, x_img_stride, x_ld, M, K);
+    return launch_gemm_tn(reinterpret_cast<hipStream_t>(stream), p, out, workspace, workspace_floats);
+}
+
+// dense rows, X scaled per image while it is loaded: out = dY^T [X * x_scale[row / x_scale_rows] | 1]
+extern "C" int effdet_train_gemm_tn_scaled(void* stream, const float* dY, const float* X, const float* x_scale, long long x_scale_rows,
+                                           long long M, int N, int K, float* out, float* workspace, long long workspace_floats) {
+    EFFDET_ENTER();
+    if (!dY || !X || !x_scale || x_scale_rows <= 0 || !out || !workspace || M <= 0 || N <= 0 || K <= 0) return EFFDET_EINVAL;
+    if (K % 4 || reinterpret_cast<uintptr_t>(x_scale) % 16) return EFFDET_EINVAL;
+    GemmTnArgs p;
+    p.dY = dY; p.X = X; p.M = M; p.N = N; p.K = K; p.x_scale = x_scale; p.x_scale_rpi = x_scale_rows;
+    p.ym = make_rowmap(0, 0, 0, M, N);
+    p.xm = make_rowmap(0, 0, 0, M, K);
     return launch_gemm_tn(reinterpret_cast<hipStream_t>(stream), p, out, workspace, workspace_floats);
 }
 
@@ -960,7 +1045,7 @@ extern "C" int effdet_train_gemm_tn_levels(void* stream, const float* dY, int y_
     RowMap lm;
     const long long M = make_levels_rowmap(lm, B, L, Hs, Ws, pk_img_stride > 0 ? pk_img_stride : 1, pk_ld > 0 ? pk_ld : 1);
     if (M <= 0 || (y_packed && pk_ld < N)) return EFFDET_EINVAL;
-    p.dY = dY; p.X = X; p.M = M; p.N = N; p.K = K;
+    p.dY = dY; p.X = X; p.M = M; p.N = N; p.K = K; p.x_scale = nullptr; p.x_scale_rpi = 1;
     p.ym = y_packed ? lm : make_rowmap(0, 0, 0, M, N);
     p.xm = make_rowmap(0, 0, 0, M, K);
     return launch_gemm_tn(reinterpret_cast<hipStream_t>(stream), p, out, workspace, workspace_floats);
@@ -980,12 +1065,25 @@ static int dw_fill(DwBwdArgs& a, int B, int H, int W, int C, int k, int stride) 
     return 0;
 }
 
+static int launch_dw_bwd_dx(void* stream, const float* dY, const float* taps, const float* Z, float* dX,
+                            int B, int H, int W, int C, int k, int stride);
 extern "C" int effdet_train_dwconv_bwd_dx(void* stream, const float* dY, const float* taps, float* dX,
                                           int B, int H, int W, int C, int k, int stride) {
     EFFDET_ENTER();
+    return launch_dw_bwd_dx(stream, dY, taps, nullptr, dX, B, H, W, C, k, stride);
+}
+// the same, followed by the SiLU backward of the layer below in the same pass: dX = (conv^T dY) * silu'(Z), Z [B][H][W][C]
+extern "C" int effdet_train_dwconv_bwd_dx_silu(void* stream, const float* dY, const float* taps, const float* Z, float* dX,
+                                               int B, int H, int W, int C, int k, int stride) {
+    EFFDET_ENTER();
+    if (!Z) return EFFDET_EINVAL;
+    return launch_dw_bwd_dx(stream, dY, taps, Z, dX, B, H, W, C, k, stride);
+}
+static int launch_dw_bwd_dx(void* stream, const float* dY, const float* taps, const float* Z, float* dX,
+                            int B, int H, int W, int C, int k, int stride) {
     DwBwdArgs a;
     if (!dY || !taps || !dX || dw_fill(a, B, H, W, C, k, stride)) return EFFDET_EINVAL;
-    a.dY = dY; a.taps = taps; a.dX = dX; a.X = nullptr; a.partial = nullptr; a.segs_per_chunk = 0; a.seg = 0;
+    a.dY = dY; a.taps = taps; a.dX = dX; a.X = nullptr; a.partial = nullptr; a.segs_per_chunk = 0; a.seg = 0; a.Z = Z;
     const long long total = (long long)B * H * W * (C / 4);
     const long long blocks = (total + 255) / 256;
     if (blocks > 0x7fffffffLL) return EFFDET_EINVAL;
@@ -1022,7 +1120,7 @@ extern "C" int effdet_train_dwconv_bwd_dw(void* stream, const float* dY, const f
     int seg;
     const long long chunks = dw_chunks(a, &per, &seg);
     if (workspace_floats < chunks * (k * k + 1) * C || chunks > 0x7fffffffLL) return EFFDET_EINVAL;
-    a.dY = dY; a.X = X; a.taps = nullptr; a.dX = nullptr; a.partial = workspace; a.segs_per_chunk = per; a.seg = seg;
+    a.dY = dY; a.X = X; a.taps = nullptr; a.dX = nullptr; a.partial = workspace; a.segs_per_chunk = per; a.seg = seg; a.Z = nullptr;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)chunks, (unsigned)((C + 63) / 64));
     if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_bwd_dw_kernel<3, 1>), grid, dim3(256), 0, st, a);
@@ -1038,14 +1136,14 @@ extern "C" int effdet_train_ew(void* stream, int op, float* out, const float* a,
                                const float* v0, const float* v1, const float* v2, const float* v3,
                                float s0, float s1, float s2, float s3, long long n, int C, long long hw, const float* sdev, float* out2) {
     EFFDET_ENTER();
-    if (!out || !a || n <= 0 || n % 4 || C <= 0 || C % 4 || op < 0 || op > 11) return EFFDET_EINVAL;
+    if (!out || !a || n <= 0 || n % 4 || C <= 0 || C % 4 || op < 0 || op > 12) return EFFDET_EINVAL;
     const bool need_b = op == 1 || op == 2 || op == 6 || op == 7 || op == 9 || op == 10 || op == 11;
     if (need_b && !b) return EFFDET_EINVAL;
-    if (op == 11 && !c) return EFFDET_EINVAL;
-    if ((op == 3 || op == 4 || op == 5 || op == 6) && !v0) return EFFDET_EINVAL;
-    if ((op == 5 || op == 6) && !v1) return EFFDET_EINVAL;
+    if ((op == 11 || op == 12) && !c) return EFFDET_EINVAL;
+    if ((op == 3 || op == 4 || op == 5 || op == 6 || op == 12) && !v0) return EFFDET_EINVAL;
+    if ((op == 5 || op == 6 || op == 12) && !v1) return EFFDET_EINVAL;
     if (op == 6 && (!v2 || !v3)) return EFFDET_EINVAL;
-    if ((op == 4 || op == 5) && hw <= 0) return EFFDET_EINVAL;
+    if ((op == 4 || op == 5 || op == 12) && hw <= 0) return EFFDET_EINVAL;
     if (op == 7 && s3 == 0.f && !sdev) return EFFDET_EINVAL;
     EwArgs p{op, out, a, b, c, v0, v1, v2, v3, s0, s1, s2, s3, n, C, (hw > 0 ? hw : 1) * C, sdev, out2};
     const long long blocks = (n / 4 + 255) / 256;
@@ -1084,7 +1182,10 @@ extern "C" int effdet_train_col_reduce(void* stream, int mode, const float* a, c
     if (workspace_floats < (long long)S * G * C * Wd) return EFFDET_EINVAL;
     ColArgs p{mode, a, b, v, workspace, R, rps, C, S};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)S, (unsigned)((C + 63) / 64), (unsigned)G), dim3(256), 0, st, p);
+    const bool vec = C % 4 == 0 && reinterpret_cast<uintptr_t>(a) % 16 == 0 && (!b || reinterpret_cast<uintptr_t>(b) % 16 == 0);
+    const dim3 grid((unsigned)S, (unsigned)((C + 63) / 64), (unsigned)G);
+    if (vec) hipLaunchKernelGGL(col_reduce_kernel<4>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(col_reduce_kernel<1>, grid, dim3(256), 0, st, p);
     int rc = effdet_check_launch();
     if (rc) return rc;
     return launch_reduce_mid(st, workspace, G, S, (long long)C * Wd, out, 0, alpha);
@@ -1121,7 +1222,7 @@ extern "C" int effdet_train_se_bwd(void* stream, const float* pool_sum, int hw, 
     const size_t sh = (size_t)(2 * C + 2 * R) * sizeof(float);
     if (sh > 64 * 1024) return EFFDET_EINVAL;
     SeBwdArgs p{pool_sum, 1.0f / (float)hw, gate, dgate, W1, b1, W2t, ds, pgrad, C, R};
-    hipLaunchKernelGGL(se_bwd_kernel, dim3(B), dim3(256), sh, reinterpret_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(se_bwd_kernel, dim3(B), dim3(1024), sh, reinterpret_cast<hipStream_t>(stream), p);
     return effdet_check_launch();
 }
 

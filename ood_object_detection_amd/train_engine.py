@@ -124,12 +124,47 @@ class _Ops(object):
                                                  shift.data_ptr(), 0, None, B, H, W, C, k, s), 'effdet_dwconv_bn_act')
         return y
 
-    def dw_bwd(self, dy, x, taps, k, s):
-        """-> dx, dtaps [k*k, C], dsum [C]   (taps already carry any folded BN scale)"""
+    def dw_fwd_train(self, x, taps, scale, shift, k, s):
+        """conv_dw + folded BN -> (z, silu(z), SE pool partial rows of silu(z) [B, nblk, C], nblk) in one pass"""
+        B, H, W, C = x.shape
+        Ho, Wo = _same_out(H, s), _same_out(W, s)
+        z, a = self.new(B, Ho, Wo, C), self.new(B, Ho, Wo, C)
+        nblk = self.lib.effdet_dwconv_blocks_per_image(Ho, Wo, C)
+        part = self.new(B, nblk, C)
+        _lib.check(self.lib.effdet_train_dwconv_fwd(self.st(), x.data_ptr(), z.data_ptr(), a.data_ptr(), taps.data_ptr(),
+                                                    scale.data_ptr(), shift.data_ptr(), part.data_ptr(), B, H, W, C, k, s),
+                   'effdet_train_dwconv_fwd')
+        return z, a, part, nblk
+
+    def gemm_nt_fused(self, A, W, bias=None, a_scale=None, a_rows=0, R=None, silu_out=False):
+        """(A * a_scale[row // a_rows]) W^T + bias + R  (and silu of it when asked); dense rows"""
+        N, K = W.shape
+        M = A.numel() // K
+        out = self.new(M, N)
+        out2 = self.new(M, N) if silu_out else None
+        p = lambda t: None if t is None else t.data_ptr()
+        _lib.check(self.lib.effdet_train_gemm_nt_fused(self.st(), A.data_ptr(), p(a_scale), a_rows, W.data_ptr(), p(bias), p(R),
+                                                       out.data_ptr(), p(out2), M, K, N), 'effdet_train_gemm_nt_fused')
+        return (out, out2) if silu_out else out
+
+    def gemm_tn_scaled(self, dY, X, x_scale, x_rows, N, K):
+        M = dY.numel() // N
+        ws = self.ws(self.lib.effdet_train_gemm_tn_workspace_floats(M, N, K))
+        out = self.new(N * K + N)
+        _lib.check(self.lib.effdet_train_gemm_tn_scaled(self.st(), dY.data_ptr(), X.data_ptr(), x_scale.data_ptr(), x_rows, M, N, K,
+                                                        out.data_ptr(), ws.data_ptr(), ws.numel()), 'effdet_train_gemm_tn_scaled')
+        return out[:N * K].view(N, K), out[N * K:]
+
+    def dw_bwd(self, dy, x, taps, k, s, z=None):
+        """-> dx, dtaps [k*k, C], dsum [C]   (taps already carry any folded BN scale); z: dx is multiplied by silu'(z)"""
         B, H, W, C = x.shape
         dx = self.new(B, H, W, C)
-        _lib.check(self.lib.effdet_train_dwconv_bwd_dx(self.st(), dy.data_ptr(), taps.data_ptr(), dx.data_ptr(), B, H, W, C, k, s),
-                   'effdet_train_dwconv_bwd_dx')
+        if z is not None:
+            _lib.check(self.lib.effdet_train_dwconv_bwd_dx_silu(self.st(), dy.data_ptr(), taps.data_ptr(), z.data_ptr(), dx.data_ptr(),
+                                                                B, H, W, C, k, s), 'effdet_train_dwconv_bwd_dx_silu')
+        else:
+            _lib.check(self.lib.effdet_train_dwconv_bwd_dx(self.st(), dy.data_ptr(), taps.data_ptr(), dx.data_ptr(), B, H, W, C, k, s),
+                       'effdet_train_dwconv_bwd_dx')
         n = self.lib.effdet_train_dwconv_bwd_dw_workspace_floats(B, H, W, C, k, s)
         ws = self.ws(n)
         out = self.new(k * k + 1, C)
@@ -384,8 +419,9 @@ class TrainEngine(object):
         grads[gn] = dgb[0]
         grads[bn_] = dgb[1]
 
-    def _pw_bneval_fwd(self, x, conv, bn, names, silu_out=False):
-        """1x1 conv (no bias) + BN with running statistics, folded: z = x (scale*W)^T + shift (and a = silu(z) when asked)."""
+    def _pw_bneval_fwd(self, x, conv, bn, names, silu_out=False, gate=None, resid=None):
+        """1x1 conv (no bias) + BN with running statistics, folded: z = x (scale*W)^T + shift (and a = silu(z) when asked).
+        gate [B, K]: the SE gate, applied to x while the GEMM loads it; resid: the block's shortcut, added in the epilogue."""
         if bn.training:
             raise NotImplementedError('backbone BatchNorm in batch-statistics mode is not built.  For training put the backbone BN in '
                                       'eval mode as pretrain.py:168-176 does (model.backbone.apply(set_bn_eval)); for inference call '
@@ -395,34 +431,41 @@ class TrainEngine(object):
         W = conv.weight.detach().reshape(N, -1)
         Wf, WfT, _, scale, shift, rstd = self._fold(W, bn, True, True, False)
         B, H, Wd, K = x.shape
-        rec = dict(x=x, W=W, Wf=Wf, WfT=WfT, mean=bn.running_mean, rstd=rstd, scale=scale, names=names, wshape=conv.weight.shape)
+        rec = dict(x=x, W=W, Wf=Wf, WfT=WfT, mean=bn.running_mean, rstd=rstd, scale=scale, names=names, wshape=conv.weight.shape,
+                   gate=gate, hw=H * Wd)
+        out = self.ops.gemm_nt_fused(x, Wf, shift, a_scale=gate, a_rows=H * Wd, R=resid, silu_out=silu_out)
         if silu_out:
-            z, a = self.ops.gemm_nt(x, Wf, shift, silu_out=True)
-            return (z.view(B, H, Wd, N), a.view(B, H, Wd, N)), rec
-        return self.ops.gemm_nt(x, Wf, shift).view(B, H, Wd, N), rec
+            return (out[0].view(B, H, Wd, N), out[1].view(B, H, Wd, N)), rec
+        return out.view(B, H, Wd, N), rec
 
-    def _pw_bneval_bwd(self, rec, dz, grads, need_dx=True):
+    def _pw_bneval_bwd(self, rec, dz, grads, need_dx=True, resid=None):
+        """-> d x (+ resid: the gradient that reaches x through the shortcut); for a gated conv d (x * gate)"""
         N, K = rec['Wf'].shape
-        dWraw, _ = self.ops.gemm_tn(dz, rec['x'], N, K)
+        if rec['gate'] is not None:
+            dWraw, _ = self.ops.gemm_tn_scaled(dz, rec['x'], rec['gate'], rec['hw'], N, K)
+        else:
+            dWraw, _ = self.ops.gemm_tn(dz, rec['x'], N, K)
         self._convbn_grads(rec, dWraw._base, False, grads)
         if not need_dx:
             return None
         B, H, Wd, _ = dz.shape
-        return self.ops.gemm_nt(dz, rec['WfT']).view(B, H, Wd, K)
+        return self.ops.gemm_nt_fused(dz, rec['WfT'], R=resid).view(B, H, Wd, K)
 
     def _dw_bneval_fwd(self, x, conv, bn, k, s, names):
+        """-> z (pre-activation), silu(z), SE pool partial rows, rows per image, record"""
         if bn.training:
             raise NotImplementedError('backbone BatchNorm in batch-statistics mode is not built (see pretrain.py:168-176)')
         C = conv.weight.shape[0]
         W = conv.weight.detach().reshape(C, k * k)
         _, taps_s, taps, scale, shift, rstd = self._fold(W, bn, False, True, True)
-        z = self.ops.dw_fwd(x, taps, scale, shift, k, s)
-        return z, dict(x=x, W=W, taps_s=taps_s, mean=bn.running_mean, rstd=rstd, scale=scale, k=k, s=s, names=names,
-                       wshape=conv.weight.shape)
+        z, a, part, nblk = self.ops.dw_fwd_train(x, taps, scale, shift, k, s)
+        return z, a, part, nblk, dict(x=x, W=W, taps_s=taps_s, mean=bn.running_mean, rstd=rstd, scale=scale, k=k, s=s, names=names,
+                                      wshape=conv.weight.shape)
 
-    def _dw_bneval_bwd(self, rec, dz, grads):
+    def _dw_bneval_bwd(self, rec, dz, grads, z_below=None):
+        """z_below: pre-activation of the layer that produced this conv's input: d input is multiplied by silu'(z_below)"""
         k, s = rec['k'], rec['s']
-        dx, dtaps, _ = self.ops.dw_bwd(dz, rec['x'], rec['taps_s'], k, s)
+        dx, dtaps, _ = self.ops.dw_bwd(dz, rec['x'], rec['taps_s'], k, s, z=z_below)
         self._convbn_grads(rec, dtaps._base, True, grads)
         return dx
 
@@ -516,20 +559,21 @@ class TrainEngine(object):
     # =============================================================================================
     # backbone
     # =============================================================================================
-    def _se_fwd(self, a, se, R):
+    def _se_fwd(self, a, part, nblk, se, R):
+        """SqueezeExcite gate [B, C] from the depthwise kernel's pool partial rows (the multiply happens inside the project GEMM)"""
         B, H, W, C = a.shape
-        pool = self.ops.col_reduce(0, a, per_image=True)                   # [B, C] sums
         W1 = se.conv_reduce.weight.detach().reshape(R, C).contiguous()
         b1 = se.conv_reduce.bias.detach().contiguous()
         W2t = se.conv_expand.weight.detach().reshape(C, R).t().contiguous()
         b2 = se.conv_expand.bias.detach().contiguous()
-        gate = self.ops.new(B, C)
-        _lib.check(self.lib.effdet_se_gate(self.ops.st(), pool.data_ptr(), 1, H * W, W1.data_ptr(), b1.data_ptr(), W2t.data_ptr(),
-                                           b2.data_ptr(), gate.data_ptr(), B, C, R), 'effdet_se_gate')
-        ag = self.ops.ew(4, a, v=(gate, None, None, None), hw=H * W)
-        return ag, dict(a=a, pool=pool, gate=gate, W1=W1, b1=b1, W2t=W2t, R=R)
+        gate, pool = self.ops.new(B, C), self.ops.new(B, C)
+        _lib.check(self.lib.effdet_train_se_gate(self.ops.st(), part.data_ptr(), nblk, H * W, W1.data_ptr(), b1.data_ptr(),
+                                                 W2t.data_ptr(), b2.data_ptr(), gate.data_ptr(), pool.data_ptr(), B, C, R),
+                   'effdet_train_se_gate')
+        return gate, dict(a=a, pool=pool, gate=gate, W1=W1, b1=b1, W2t=W2t, R=R)
 
-    def _se_bwd(self, rec, dag, grads, prefix):
+    def _se_bwd(self, rec, dag, z, grads, prefix):
+        """dag = d (a * gate) -> d z, z the pre-activation of a = silu(z)  (gate, pool and SiLU backward in one element-wise pass)"""
         a, gate, R = rec['a'], rec['gate'], rec['R']
         B, H, W, C = a.shape
         dgate = self.ops.col_reduce(1, dag, a, per_image=True)
@@ -541,10 +585,10 @@ class TrainEngine(object):
                                                 pg.data_ptr(), B, C, R), 'effdet_train_se_bwd')
         g = self.ops.reduce_rows(pg)
         grads[prefix + 'conv_reduce.weight'] = g[:R * C].reshape(R, C, 1, 1)
-        grads[prefix + 'conv_reduce.bias'] = g[R * C:R * C + R].clone()
+        grads[prefix + 'conv_reduce.bias'] = g[R * C:R * C + R]
         grads[prefix + 'conv_expand.weight'] = g[R * C + R:2 * R * C + R].reshape(R, C).t().reshape(C, R, 1, 1)
-        grads[prefix + 'conv_expand.bias'] = g[2 * R * C + R:].clone()
-        return self.ops.ew(5, dag, v=(gate, ds, None, None), s=(1.0 / (H * W), 0.0, 0.0, 0.0), hw=H * W)
+        grads[prefix + 'conv_expand.bias'] = g[2 * R * C + R:]
+        return self.ops.ew(12, dag, c=z, v=(gate, ds, None, None), s=(1.0 / (H * W), 0.0, 0.0, 0.0), hw=H * W)
 
     def bb_forward(self, x):
         """x: [B,3,H,W] float32 (normalised) or uint8 (raw; loader normalisation applied).  -> (feats NHWC list, saved)"""
@@ -593,19 +637,20 @@ class TrainEngine(object):
                     (z1, a1), r['pw'] = self._pw_bneval_fwd(cur, m.conv_pw, m.bn1, (p + 'conv_pw.weight', p + 'bn1.weight', p + 'bn1.bias'),
                                                             silu_out=True)
                     r['z1'] = z1
-                    z2, r['dw'] = self._dw_bneval_fwd(a1, m.conv_dw, m.bn2, b['k'], b['s'],
-                                                      (p + 'conv_dw.weight', p + 'bn2.weight', p + 'bn2.bias'))
+                    z2, a2, part, nblk, r['dw'] = self._dw_bneval_fwd(a1, m.conv_dw, m.bn2, b['k'], b['s'],
+                                                                      (p + 'conv_dw.weight', p + 'bn2.weight', p + 'bn2.bias'))
                     proj, bnp, pn = m.conv_pwl, m.bn3, (p + 'conv_pwl.weight', p + 'bn3.weight', p + 'bn3.bias')
                 else:
-                    z2, r['dw'] = self._dw_bneval_fwd(cur, m.conv_dw, m.bn1, b['k'], b['s'],
-                                                      (p + 'conv_dw.weight', p + 'bn1.weight', p + 'bn1.bias'))
+                    z2, a2, part, nblk, r['dw'] = self._dw_bneval_fwd(cur, m.conv_dw, m.bn1, b['k'], b['s'],
+                                                                      (p + 'conv_dw.weight', p + 'bn1.weight', p + 'bn1.bias'))
                     proj, bnp, pn = m.conv_pw, m.bn2, (p + 'conv_pw.weight', p + 'bn2.weight', p + 'bn2.bias')
                 r['z2'] = z2
-                a2 = ops.silu(z2)
-                ag, r['se'] = self._se_fwd(a2, m.se, b['se'])
-                z3, r['proj'] = self._pw_bneval_fwd(ag, proj, bnp, pn)
+                gate, r['se'] = self._se_fwd(a2, part, nblk, m.se, b['se'])
                 r['drop'] = None
-                if b['residual'] and drop_rates is not None and drop_rates[flat_idx] > 0.0:
+                dropped = b['residual'] and drop_rates is not None and drop_rates[flat_idx] > 0.0
+                # project conv: the SE gate multiplies its input while the GEMM loads it, the shortcut is added in its epilogue
+                z3, r['proj'] = self._pw_bneval_fwd(a2, proj, bnp, pn, gate=gate, resid=cur if (b['residual'] and not dropped) else None)
+                if dropped:
                     keep = 1.0 - drop_rates[flat_idx]
                     if fixed_masks is not None and flat_idx in fixed_masks:
                         mask = fixed_masks[flat_idx].to(device=self.dev, dtype=torch.float32).reshape(B)
@@ -613,8 +658,8 @@ class TrainEngine(object):
                         mask = torch.floor(keep + torch.rand(B, device=self.dev, dtype=torch.float32))
                     # per-image scale as a [B, C] table for the element-wise kernel (op 4: a * v0[img, c])
                     r['drop'] = (mask / keep).reshape(B, 1).expand(B, b['cout']).contiguous()
-                    z3 = ops.ew(4, z3, v=(r['drop'], None, None, None), hw=z3.shape[1] * z3.shape[2])
-                cur = ops.add(z3, cur) if b['residual'] else z3
+                    z3 = ops.add(ops.ew(4, z3, v=(r['drop'], None, None, None), hw=z3.shape[1] * z3.shape[2]), cur)
+                cur = z3
                 flat_idx += 1
                 saved['blocks'].append(r)
             if si in (2, 4, 6):
@@ -641,13 +686,14 @@ class TrainEngine(object):
                 raise RuntimeError('no gradient reached the last backbone stage')
             dz3 = dcur if r.get('drop') is None else ops.ew(4, dcur, v=(r['drop'], None, None, None), hw=dcur.shape[1] * dcur.shape[2])
             dag = self._pw_bneval_bwd(r['proj'], dz3, grads)
-            da2 = self._se_bwd(r['se'], dag, grads, r['p'] + 'se.')
-            dz2 = ops.silu_bwd(r['z2'], da2)
-            dx = self._dw_bneval_bwd(r['dw'], dz2, grads)
+            dz2 = self._se_bwd(r['se'], dag, r['z2'], grads, r['p'] + 'se.')
+            shortcut = dcur if b['residual'] else None
             if b['type'] == 'ir':
-                dz1 = ops.silu_bwd(r['z1'], dx)
-                dx = self._pw_bneval_bwd(r['pw'], dz1, grads)
-            dcur = ops.add(dx, dcur) if b['residual'] else dx
+                dz1 = self._dw_bneval_bwd(r['dw'], dz2, grads, z_below=r['z1'])
+                dcur = self._pw_bneval_bwd(r['pw'], dz1, grads, resid=shortcut)
+            else:
+                dx = self._dw_bneval_bwd(r['dw'], dz2, grads)
+                dcur = ops.add(dx, shortcut) if shortcut is not None else dx
         rec, z0 = saved['stem']
         dz0 = ops.silu_bwd(z0, dcur)
         self._pw_bneval_bwd(rec, dz0, grads, need_dx=False)
