@@ -36,6 +36,18 @@ DEV float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 // where the result is rounded to 8 bits anyway; float32 parity mode keeps the correctly rounded forms.
 DEV float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 DEV float fast_silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
+// float32 TRAINING kernels (train_*.hip, the training form of dwconv.hip): SiLU / sigmoid on the hardware exp2 / rcp instructions
+// (~1 ulp each; relative error of the result < 1e-6, against the 1e-5 ... 2e-3 bounds of the gradient parity tests).  The
+// correctly rounded expf + IEEE division of silu_f cost ~10x the instructions, and the step applies ~2 G of them.  The float32
+// INFERENCE parity path keeps silu_f.  -DEFFDET_TRAIN_PRECISE_SILU restores the precise forms here too.
+#ifdef EFFDET_TRAIN_PRECISE_SILU
+DEV float sigmoid_train(float x) { return sigmoid_f(x); }
+DEV float silu_train(float x) { return silu_f(x); }
+#else
+DEV float sigmoid_train(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
+DEV float silu_train(float x) { return x * sigmoid_train(x); }
+#endif
+
 template <typename T> DEV float silu_t(float x) {
     if constexpr (sizeof(T) == 2) return fast_silu(x); else return silu_f(x);
 }

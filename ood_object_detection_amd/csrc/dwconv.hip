@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs p) {
             for (int e = 0; e < 8; ++e) z.v[e] = acc.v[e] * sc.v[e] + sh.v[e];
             store8<T>(Y + (long long)pix * p.C + c0, z);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { o.v[e] = to_f<T>(from_f<T>(silu_t<T>(z.v[e]))); pool.v[e] += o.v[e]; }
+            for (int e = 0; e < 8; ++e) { o.v[e] = to_f<T>(from_f<T>(silu_train(z.v[e]))); pool.v[e] += o.v[e]; }
             store8<T>(Y2 + (long long)pix * p.C + c0, o);
             continue;
         }

@@ -19,7 +19,7 @@ struct FpnArgs {
     int B, H, W, C; long long rows_per_slice; int S;
 };
 
-DEV float fpn_silu_grad(float z) { const float s = sigmoid_f(z); return s * (1.0f + z * (1.0f - s)); }
+DEV float fpn_silu_grad(float z) { const float s = sigmoid_train(z); return s * (1.0f + z * (1.0f - s)); }
 
 // value of resampled input `in` at pixel (b, y, x), 4 channels from c
 DEV f32x4 fpn_sample(const FpnIn& in, long long b, int y, int x, int c, int C) {
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void fpn_combine_kernel(FpnArgs p) {
     *reinterpret_cast<f32x4*>(p.out + i * 4) = o;
     f32x4 q;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) q[j] = silu_f(o[j]);
+    for (int j = 0; j < 4; ++j) q[j] = silu_train(o[j]);
     *reinterpret_cast<f32x4*>(p.out2 + i * 4) = q;
 }
 

@@ -38,7 +38,7 @@ inline int fill_levels(Levels& lv, int B, int L, const int* Hs, const int* Ws) {
     return 0;
 }
 
-DEV float lv_silu_grad(float z) { const float s = sigmoid_f(z); return s * (1.0f + z * (1.0f - s)); }
+DEV float lv_silu_grad(float z) { const float s = sigmoid_train(z); return s * (1.0f + z * (1.0f - s)); }
 
 DEV int level_of(const Levels& lv, long long row) {
     int l = 0;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void lv_ew_kernel(LvEwArgs p) {
     if (p.out2) {
         f32x4 q;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) q[j] = silu_f(r[j]);
+        for (int j = 0; j < 4; ++j) q[j] = silu_train(r[j]);
         *reinterpret_cast<f32x4*>(p.out2 + i) = q;
     }
 }

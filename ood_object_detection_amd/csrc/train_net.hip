@@ -94,14 +94,23 @@ DEV Frag<float> ld_k4(const float* row, int k, int K) {
 // A wave owns 32 rows x 64 columns: every W fragment it fetches feeds two row tiles, and the fragments of the next 16 k are
 // requested before the current ones go to the matrix cores (the loop has a runtime trip count; without the explicit
 // double buffer every step would expose one L2 round trip).  The k order per output element is unchanged: sequential.
-template <int VEC>
+// KS = 4: the four waves of a workgroup share ONE 32-row tile and each takes a quarter of K; the partial accumulators are
+// added in wave order through LDS (fixed association).  For the deep-K convs on small maps (M = a few thousand rows, K up to
+// 1152) this gives 4x the workgroups and a quarter of the serial K chain.
+template <int VEC, int KS>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
     constexpr int RT = 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
-    const long long m0 = ((long long)blockIdx.x * 4 + wave) * (16 * RT);
+    const long long m0 = KS == 1 ? ((long long)blockIdx.x * 4 + wave) * (16 * RT) : (long long)blockIdx.x * (16 * RT);
     const int n0 = blockIdx.y * 64;
-    if (m0 >= p.M) return;                                   // wave-uniform, no barriers in this kernel
+    if (m0 >= p.M) return;                                   // uniform per wave (KS = 1) or per workgroup (KS = 4)
+    int kb = 0, ke = p.K;
+    if constexpr (KS > 1) {
+        const int kchunk = (p.K + 16 * KS - 1) / (16 * KS) * 16;
+        kb = wave * kchunk;
+        ke = kb + kchunk < p.K ? kb + kchunk : p.K;
+    }
     const float* arow[RT];
     const float* grow[RT];
     bool mv[RT];
@@ -132,10 +141,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
         for (int t = 0; t < 4; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     Frag<float> bc[RT], ac[4];
 #pragma unroll
-    for (int i = 0; i < RT; ++i) bc[i] = lda(i, 4 * g);
+    for (int i = 0; i < RT; ++i) bc[i] = lda(i, kb + 4 * g);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) ac[t] = ld_k4<VEC>(wrow[t], 4 * g, p.K);
-    for (int k0 = 0; k0 < p.K; k0 += 16) {
+    for (int t = 0; t < 4; ++t) ac[t] = ld_k4<VEC>(wrow[t], kb + 4 * g, p.K);
+    for (int k0 = kb; k0 < ke; k0 += 16) {
         const int kn = k0 + 16 + 4 * g;                       // past the end of K: ld_k4 returns zeros without touching memory
         Frag<float> bn[RT], an[4];
 #pragma unroll
@@ -150,6 +159,27 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
         for (int i = 0; i < RT; ++i) bc[i] = bn[i];
 #pragma unroll
         for (int t = 0; t < 4; ++t) ac[t] = an[t];
+    }
+    if constexpr (KS > 1) {
+        __shared__ float red[KS - 1][RT * 16][64];
+        if (wave > 0) {
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[wave - 1][(i * 4 + t) * 4 + r][lane] = acc[i][t][r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < KS - 1; ++w)
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][t][r] += red[w][(i * 4 + t) * 4 + r][lane];
     }
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
@@ -169,7 +199,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
                     if (p.C2) {
                         f32x4 q;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) q[r] = silu_f(v[r]);
+                        for (int r = 0; r < 4; ++r) q[r] = silu_train(v[r]);
                         *reinterpret_cast<f32x4*>(p.C2 + coff + n) = q;
                     }
                 }
@@ -183,7 +213,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
                     if (p.R) v += p.R[coff + n + r];
                     if (p.accumulate) v += crow[n + r];
                     crow[n + r] = v;
-                    if (p.C2) p.C2[coff + n + r] = silu_f(v);
+                    if (p.C2) p.C2[coff + n + r] = silu_train(v);
                 }
             }
         }
@@ -374,7 +404,7 @@ inline int launch_reduce_mid(hipStream_t st, const float* in, int G, int S, long
     return effdet_launch_reduce_mid(st, in, G, S, L, out, accumulate, alpha);
 }
 
-DEV float silu_grad(float z) { const float s = sigmoid_f(z); return s * (1.0f + z * (1.0f - s)); }
+DEV float silu_grad(float z) { const float s = sigmoid_train(z); return s * (1.0f + z * (1.0f - s)); }
 
 // ------------------------------------------------------------------------------------------------------------
 // depthwise backward
@@ -507,7 +537,7 @@ struct EwArgs {
 };
 
 // second derivative of z * sigmoid(z): sigma (1 - sigma) (2 + z (1 - 2 sigma))   (double backward of the MetaHead, infer.py:658)
-DEV float silu_grad2(float z) { const float s = sigmoid_f(z); return s * (1.0f - s) * (2.0f + z * (1.0f - 2.0f * s)); }
+DEV float silu_grad2(float z) { const float s = sigmoid_train(z); return s * (1.0f - s) * (2.0f + z * (1.0f - 2.0f * s)); }
 
 __global__ __launch_bounds__(256) void ew_kernel(EwArgs p) {
     const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -519,7 +549,7 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs p) {
     switch (p.op) {
     case 0:                                             // SiLU forward
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = silu_f(a[j]);
+        for (int j = 0; j < 4; ++j) o[j] = silu_train(a[j]);
         break;
     case 1: {                                           // SiLU backward: a = z, b = d(out)
         const f32x4 b = *reinterpret_cast<const f32x4*>(p.b + i);
@@ -589,7 +619,7 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs p) {
     if (p.out2) {
         f32x4 q;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) q[j] = silu_f(o[j]);
+        for (int j = 0; j < 4; ++j) q[j] = silu_train(o[j]);
         *reinterpret_cast<f32x4*>(p.out2 + i) = q;
     }
 }
@@ -796,7 +826,7 @@ __global__ __launch_bounds__(1024) void se_bwd_kernel(SeBwdArgs p) {
             const float dz = drp[r];
             acc += p.W1[(long long)r * p.C + c] * dz;
             dW1[(long long)r * p.C + c] = dz * sc;
-            dW2t[(long long)r * p.C + c] = silu_f(rp[r]) * dc;
+            dW2t[(long long)r * p.C + c] = silu_train(rp[r]) * dc;
         }
         p.ds[bc + c] = acc;
     }
@@ -900,8 +930,11 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(BnBwdArgs p) {
 static int launch_gemm_nt(hipStream_t st, GemmNtArgs& p) {
     const float* A = p.A; const float* W = p.W; const float* bias = p.bias; float* C = p.C; float* C2 = p.C2;
     const long long M = p.M; const int K = p.K, N = p.N;
-    const long long gx = (M + 127) / 128;                    // 4 waves x 32 rows
+    long long gx = (M + 127) / 128;                          // 4 waves x 32 rows
     if (gx > 0x7fffffffLL) return EFFDET_EINVAL;
+    // deep K on few rows: too few workgroups with a long serial chain each -> K split over the workgroup's waves
+    const bool splitk = K >= 192 && gx * ((N + 63) / 64) < 1024;
+    if (splitk) gx = (M + 31) / 32;
     const bool vec = K % 4 == 0 && p.am.ld % 4 == 0 && p.am.img_stride % 4 == 0 &&
                      reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(W) % 16 == 0;
     p.vec_out = N % 4 == 0 && p.cm.ld % 4 == 0 && p.cm.img_stride % 4 == 0 && reinterpret_cast<uintptr_t>(C) % 16 == 0 &&
@@ -911,9 +944,15 @@ static int launch_gemm_nt(hipStream_t st, GemmNtArgs& p) {
     const dim3 grid((unsigned)gx, (unsigned)((N + 63) / 64));
     const bool vec2 = K % 2 == 0 && p.am.ld % 2 == 0 && p.am.img_stride % 2 == 0 &&
                       reinterpret_cast<uintptr_t>(A) % 8 == 0 && reinterpret_cast<uintptr_t>(W) % 8 == 0;
-    if (vec) hipLaunchKernelGGL(gemm_nt_kernel<4>, grid, dim3(256), 0, st, p);
-    else if (vec2) hipLaunchKernelGGL(gemm_nt_kernel<2>, grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, dim3(256), 0, st, p);
+    if (splitk) {
+        if (vec) hipLaunchKernelGGL((gemm_nt_kernel<4, 4>), grid, dim3(256), 0, st, p);
+        else if (vec2) hipLaunchKernelGGL((gemm_nt_kernel<2, 4>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_nt_kernel<1, 4>), grid, dim3(256), 0, st, p);
+    } else {
+        if (vec) hipLaunchKernelGGL((gemm_nt_kernel<4, 1>), grid, dim3(256), 0, st, p);
+        else if (vec2) hipLaunchKernelGGL((gemm_nt_kernel<2, 1>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_nt_kernel<1, 1>), grid, dim3(256), 0, st, p);
+    }
     return effdet_check_launch();
 }
 
