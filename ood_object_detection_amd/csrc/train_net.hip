@@ -327,6 +327,106 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
     }
 }
 
+// The same product for 16-byte aligned operands with N % 4 == 0 and K % 4 == 0 (every conv of the network except the 810-wide
+// class head): rows are fetched TWO steps ahead with unconditional loads on clamped addresses (a load under a branch, or one
+// whose result feeds a select at once, makes the compiler wait for it on the spot: MI355X notes in DESIGN.md), the masks are
+// applied when a step's registers go to LDS.  With one step in flight a workgroup had 12 KB on the wire for about half of the
+// time: 1.8 TB/s on the 315 MB operands of the early layers.  The staging tiles and the epilogue buffer share their LDS.
+// DENSE: both operands are plain row-major (row * ld): no row map in the loop (its 64-bit divisions and level tables cost more
+// than the step itself)
+// SCALED: X is multiplied by the image's gate row; the gate pieces travel with the stage and are applied at the LDS store (no
+// branch and no use of a loaded value inside the fetch: the waits stay counted)
+template <bool DENSE, bool SCALED>
+__global__ __launch_bounds__(256) void gemm_tn_kernel_v(GemmTnArgs p) {
+    constexpr int RT = 32, SY = 48, SX = 80;
+    __shared__ float lds[4 * 32 * 64];
+    float* sY = lds;
+    float* sX = lds + RT * SY;
+    float (*sm)[32 * 64] = reinterpret_cast<float (*)[32 * 64]>(lds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 64;
+    const long long mb = (long long)blockIdx.z * p.rows_per_slice;
+    long long me = mb + p.rows_per_slice;
+    if (me > p.M) me = p.M;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int Kx = p.K + 1;
+    const int yr = tid >> 3, yc = (tid & 7) * 4;
+    const int xr = tid >> 4, xc = (tid & 15) * 4;
+    const int n = n0 + yc, kk = k0 + xc;
+    const bool nok = n < p.N, kok = kk < p.K, kone = kk == p.K;
+    const int nl = nok ? n : 0, kl = kok ? kk : 0;
+    struct Stage { f32x4 vy, vx0, vx1, g0, g1; };
+    auto fetch = [&](long long m0) {
+        Stage s;
+        long long my = m0 + yr, m0x = m0 + xr, m1x = m0 + xr + 16;
+        my = my < me ? my : me - 1; m0x = m0x < me ? m0x : me - 1; m1x = m1x < me ? m1x : me - 1;
+        s.vy = *reinterpret_cast<const f32x4*>(p.dY + (DENSE ? my * p.ym.ld : row_off(p.ym, my)) + nl);
+        s.vx0 = *reinterpret_cast<const f32x4*>(p.X + (DENSE ? m0x * p.xm.ld : row_off(p.xm, m0x)) + kl);
+        s.vx1 = *reinterpret_cast<const f32x4*>(p.X + (DENSE ? m1x * p.xm.ld : row_off(p.xm, m1x)) + kl);
+        if constexpr (SCALED) {                               // rows < 2^31 (checked by the launcher): 32-bit division
+            const unsigned i0 = (unsigned)m0x / (unsigned)p.x_scale_rpi, i1 = (unsigned)m1x / (unsigned)p.x_scale_rpi;
+            s.g0 = *reinterpret_cast<const f32x4*>(p.x_scale + (long long)i0 * p.K + kl);
+            s.g1 = *reinterpret_cast<const f32x4*>(p.x_scale + (long long)i1 * p.K + kl);
+        }
+        return s;
+    };
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f}, one4 = f32x4{1.f, 0.f, 0.f, 0.f};
+    if (mb >= me) return;                                     // (no slice is empty; guards the clamps above)
+    Stage s0 = fetch(mb), s1 = fetch(mb + RT);
+    // one step: the stage's registers go to LDS (masks applied here), are refilled at once with the rows two steps ahead, and the
+    // tile is multiplied.  Two stages ping-pong without register copies (a copy `s0 = s1` would wait for s1's loads).
+    auto step = [&](Stage& sg, long long m0) {
+        __syncthreads();                                      // the previous step's operands have been consumed
+        {
+            const bool ry = m0 + yr < me, r0 = m0 + xr < me, r1 = m0 + xr + 16 < me;
+            if constexpr (SCALED) { sg.vx0 *= sg.g0; sg.vx1 *= sg.g1; }
+            *reinterpret_cast<f32x4*>(sY + yr * SY + yc) = (ry && nok) ? sg.vy : zero4;
+            *reinterpret_cast<f32x4*>(sX + xr * SX + xc) = r0 ? (kok ? sg.vx0 : (kone ? one4 : zero4)) : zero4;
+            *reinterpret_cast<f32x4*>(sX + (xr + 16) * SX + xc) = r1 ? (kok ? sg.vx1 : (kone ? one4 : zero4)) : zero4;
+        }
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        sg = fetch(m0 + 2 * RT);                              // clamped past the end of the slice, masked when stored
+        __builtin_amdgcn_sched_barrier(0);                    // the loads go out HERE, before the tile is multiplied
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int r = 8 * wave + 4 * st + g;
+            float a[2], b[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = sY[r * SY + 16 * i + c16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = sX[r * SX + 16 * j + c16];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    for (long long m0 = mb; m0 < me; m0 += 2 * RT) {
+        step(s0, m0);
+        step(s1, m0 + RT);                                    // past the end of the slice: an all-zero tile
+    }
+    __syncthreads();                                          // the staging tiles are dead: their LDS becomes the epilogue buffer
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sm[wave][(16 * i + 4 * g + r) * 64 + 16 * j + c16] = acc[i][j][r];
+    __syncthreads();
+    float* out = p.partial + (long long)blockIdx.z * p.N * Kx;
+    for (int e = threadIdx.x; e < 32 * 64; e += 256) {
+        const int nn = n0 + e / 64, kq = k0 + e % 64;
+        if (nn < p.N && kq < Kx) out[(long long)nn * Kx + kq] = ((sm[0][e] + sm[1][e]) + sm[2][e]) + sm[3][e];
+    }
+}
+
 // out[g][l] (+)= sum_s in[g][s][l] in index order
 struct ReduceMidArgs { const float* in; float* out; long long L; int G, S, accumulate; float alpha; };
 __global__ __launch_bounds__(256) void reduce_mid_kernel(ReduceMidArgs p) {
@@ -449,6 +549,61 @@ __global__ __launch_bounds__(256) void dw_bwd_dx_kernel(DwBwdArgs p) {
         for (int j = 0; j < 4; ++j) acc[j] *= silu_grad(z[j]);
     }
     *reinterpret_cast<f32x4*>(p.dX + o) = acc;
+}
+
+// Stride 1: a thread owns 4 consecutive pixels of a row (and 4 channels): per tap row it loads the 4 + k - 1 values of dY those
+// pixels share and the k taps once - (4 + k - 1 + k) / 4 loads per pixel and tap row instead of 2 k.  (The one-pixel form above
+// moves k * k * 2 vectors per output through L1 / L2: ~6.6 TB/s of cache traffic for 2.2 TB/s of HBM traffic on the 160 x 160 maps.)
+template <int KS>
+__global__ __launch_bounds__(256) void dw_bwd_dx_s1_kernel(DwBwdArgs p) {
+    constexpr int PX = 4, NW = PX + KS - 1;
+    const int C4 = p.C / 4;
+    const int strips = (p.W + PX - 1) / PX;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)p.B * p.H * strips * C4;
+    if (i >= total) return;
+    const int c = (int)(i % C4) * 4;
+    long long q = i / C4;
+    const int xs = (int)(q % strips); q /= strips;
+    const int iy = (int)(q % p.H);
+    const long long b = q / p.H;
+    const int ix0 = xs * PX;
+    f32x4 acc[PX];
+#pragma unroll
+    for (int u = 0; u < PX; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky) {
+        const int oy = iy + p.pad_t - ky;                     // stride 1: Ho == H
+        if (oy < 0 || oy >= p.Ho) continue;
+        const float* drow = p.dY + ((b * p.Ho + oy) * p.Wo) * p.C + c;
+        f32x4 d[NW], w[KS];
+        // d[j] = dY[oy][ix0 + pad_l - (KS - 1) + j]
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int ox = ix0 + p.pad_l - (KS - 1) + j;
+            d[j] = (ox >= 0 && ox < p.Wo) ? *reinterpret_cast<const f32x4*>(drow + (long long)ox * p.C) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) w[kx] = *reinterpret_cast<const f32x4*>(p.taps + (long long)(ky * KS + kx) * p.C + c);
+        // pixel ix0 + u, tap kx reads dY column ix0 + u + pad_l - kx = d[u + KS - 1 - kx]
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+            for (int u = 0; u < PX; ++u) acc[u] += d[u + KS - 1 - kx] * w[kx];
+    }
+#pragma unroll
+    for (int u = 0; u < PX; ++u) {
+        const int ix = ix0 + u;
+        if (ix >= p.W) break;
+        const long long o = ((b * p.H + iy) * p.W + ix) * p.C + c;
+        f32x4 v = acc[u];
+        if (p.Z) {
+            const f32x4 z = *reinterpret_cast<const f32x4*>(p.Z + o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= silu_grad(z[j]);
+        }
+        *reinterpret_cast<f32x4*>(p.dX + o) = v;
+    }
 }
 
 // partial[chunk][k*k+1][C]: taps gradient + sum of dY.  block = 64 channels x 4 lanes; a lane walks row segments of
@@ -1032,7 +1187,15 @@ static int launch_gemm_tn(hipStream_t st, GemmTnArgs& p, float* out, float* work
     const bool vy = p.ym.ld % 4 == 0 && p.ym.img_stride % 4 == 0 && reinterpret_cast<uintptr_t>(p.dY) % 16 == 0;
     const bool vx = p.xm.ld % 4 == 0 && p.xm.img_stride % 4 == 0 && reinterpret_cast<uintptr_t>(p.X) % 16 == 0;
     const bool vy2 = N % 2 == 0 && p.ym.ld % 2 == 0 && p.ym.img_stride % 2 == 0 && reinterpret_cast<uintptr_t>(p.dY) % 8 == 0;
-    if (vy && vx) hipLaunchKernelGGL((gemm_tn_kernel<4, true>), grid, dim3(256), 0, st, p);
+    if (vy && vx && N % 4 == 0 && K % 4 == 0 &&
+        (!p.x_scale || (reinterpret_cast<uintptr_t>(p.x_scale) % 16 == 0 && M < 0x7fffffffLL && p.x_scale_rpi < 0x7fffffffLL))) {
+        const bool dense = p.ym.nlev == 0 && p.xm.nlev == 0 && p.ym.img_stride == 0 && p.xm.img_stride == 0;
+        if (dense && p.x_scale) hipLaunchKernelGGL((gemm_tn_kernel_v<true, true>), grid, dim3(256), 0, st, p);
+        else if (dense) hipLaunchKernelGGL((gemm_tn_kernel_v<true, false>), grid, dim3(256), 0, st, p);
+        else if (p.x_scale) hipLaunchKernelGGL((gemm_tn_kernel_v<false, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_tn_kernel_v<false, false>), grid, dim3(256), 0, st, p);
+    }
+    else if (vy && vx) hipLaunchKernelGGL((gemm_tn_kernel<4, true>), grid, dim3(256), 0, st, p);
     else if (vx) {
         if (vy2) hipLaunchKernelGGL((gemm_tn_kernel<2, true>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((gemm_tn_kernel<1, true>), grid, dim3(256), 0, st, p);
@@ -1123,10 +1286,19 @@ static int launch_dw_bwd_dx(void* stream, const float* dY, const float* taps, co
     DwBwdArgs a;
     if (!dY || !taps || !dX || dw_fill(a, B, H, W, C, k, stride)) return EFFDET_EINVAL;
     a.dY = dY; a.taps = taps; a.dX = dX; a.X = nullptr; a.partial = nullptr; a.segs_per_chunk = 0; a.seg = 0; a.Z = Z;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (stride == 1) {
+        const long long total = (long long)B * H * ((W + 3) / 4) * (C / 4);
+        const long long blocks = (total + 255) / 256;
+        if (blocks > 0x7fffffffLL) return EFFDET_EINVAL;
+        if (k == 3) hipLaunchKernelGGL(dw_bwd_dx_s1_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(dw_bwd_dx_s1_kernel<5>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+        return effdet_check_launch();
+    }
     const long long total = (long long)B * H * W * (C / 4);
     const long long blocks = (total + 255) / 256;
     if (blocks > 0x7fffffffLL) return EFFDET_EINVAL;
-    hipLaunchKernelGGL(dw_bwd_dx_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(dw_bwd_dx_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
     return effdet_check_launch();
 }
 
