@@ -333,14 +333,15 @@ int effdet_train_bn_bwd_prep(void* stream, const float* s1, const float* s2c, co
                              float* dgamma, float* dbeta, float* v1, float* v3);
 
 /* ---- fused forms of one MBConv block of the backbone (timm InvertedResidual / DepthwiseSeparableConv, BN in eval mode) --------
- * train_dwconv_fwd:     conv_dw + folded BN: Z = pre-activation (kept for the backward), A = silu(Z) and the SE pool partial
- *                       rows of A ([B][effdet_dwconv_blocks_per_image(Ho,Wo,C)][C], optional) in one pass
+ * train_dwconv_fwd:     conv_dw + folded BN: Z = pre-activation (kept for the backward), A = silu(Z) (optional) and the SE pool partial
+ *                       rows of A ([B][effdet_train_dwconv_fwd_parts(H,W,C,k,stride)][C], optional) in one pass
  * train_se_gate:        effdet_se_gate that also writes the pooled sums [B][C] effdet_train_se_bwd reads
  * train_gemm_nt_fused:  C = (A * a_scale[row / a_scale_rows]) W^T + bias + R, C2 = silu(C): the SE gate [B][K] applied while A
  *                       is loaded, the shortcut R [M][N] added in the epilogue (a_scale, bias, R, C2 optional; dense rows)
  * train_gemm_tn_scaled: out = dY^T [X * x_scale[row / x_scale_rows] | 1] (weight gradient of the gated project conv)
  * train_dwconv_bwd_dx_silu: effdet_train_dwconv_bwd_dx followed by * silu'(Z) in the same pass
  * (effdet_train_ew op 12: (a * v0[img][c] + v1[img][c] * s0) * silu'(c) - SE gate backward and SiLU backward in one pass) */
+int effdet_train_dwconv_fwd_parts(int H, int W, int C, int k, int stride);
 int effdet_train_dwconv_fwd(void* stream, const float* X, float* Z, float* A, const float* Wt, const float* scale,
                             const float* shift, float* pool_partial, int B, int H, int W, int C, int k, int stride);
 int effdet_train_se_gate(void* stream, const float* partial, int nblk, int hw, const float* W1, const float* b1,

@@ -142,6 +142,7 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_ll]),
     'effdet_train_fpn_input_bwd': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_int, c_int, c_int, c_int]),
+    'effdet_train_dwconv_fwd_parts': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'effdet_train_dwconv_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int, c_int, c_int, c_int, c_int, c_int]),
     'effdet_train_se_gate': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -78,7 +78,6 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs p) {
 // ---------------------------------------------------------------------------------------- dwconv
 struct DwArgs {
     const void* X; void* Y;
-    void* Y2;                               // training forward: Y keeps the pre-activation, Y2 = silu(Y) (pool sums of Y2); else null
     const float* Wt;                        // [k*k][C] tap-major, fp32
     const float* scale; const float* shift;
     float* pool_partial;                    // [B, blocks_per_image, C] or null
@@ -100,7 +99,6 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs p) {
     const int c0 = cbase + cg * 8;
     const T* X = reinterpret_cast<const T*>(p.X) + (long long)b * p.H * p.W * p.C;
     T* Y = reinterpret_cast<T*>(p.Y) + (long long)b * npix * p.C;
-    T* Y2 = p.Y2 ? reinterpret_cast<T*>(p.Y2) + (long long)b * npix * p.C : nullptr;
 
     F8 sc = load8<float>(p.scale + c0), sh = load8<float>(p.shift + c0);
     F8 pool = f8_zero();
@@ -123,16 +121,6 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs p) {
             }
         }
         F8 o;
-        if (Y2) {
-            F8 z;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) z.v[e] = acc.v[e] * sc.v[e] + sh.v[e];
-            store8<T>(Y + (long long)pix * p.C + c0, z);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { o.v[e] = to_f<T>(from_f<T>(silu_train(z.v[e]))); pool.v[e] += o.v[e]; }
-            store8<T>(Y2 + (long long)pix * p.C + c0, o);
-            continue;
-        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float v = acc.v[e] * sc.v[e] + sh.v[e];
@@ -370,14 +358,14 @@ extern "C" int effdet_dwconv_blocks_per_image(int Ho, int Wo, int C) {
     return (npix + ppb - 1) / ppb;
 }
 
-static int launch_dwconv(void* stream, int dtype, const void* X, void* Y, void* Y2, const float* Wt,
+static int launch_dwconv(void* stream, int dtype, const void* X, void* Y, const float* Wt,
                          const float* scale, const float* shift, int act, float* pool_partial,
                          int B, int H, int W, int C, int k, int stride) {
     if (!X || !Y || !Wt || !scale || !shift || B <= 0 || H <= 0 || W <= 0) return EFFDET_EINVAL;
     if (C <= 0 || C % 8 || (k != 3 && k != 5) || (stride != 1 && stride != 2)) return EFFDET_EINVAL;
     if ((dtype & ~1) || (act & ~1)) return EFFDET_EINVAL;
     DwArgs a;
-    a.X = X; a.Y = Y; a.Y2 = Y2; a.Wt = Wt; a.scale = scale; a.shift = shift; a.pool_partial = pool_partial;
+    a.X = X; a.Y = Y; a.Wt = Wt; a.scale = scale; a.shift = shift; a.pool_partial = pool_partial;
     a.B = B; a.H = H; a.W = W; a.C = C; a.k = k; a.stride = stride; a.act = act;
     a.Ho = same_out(H, stride); a.Wo = same_out(W, stride);
     a.pad_t = same_pad_before(H, k, stride); a.pad_l = same_pad_before(W, k, stride);
@@ -406,17 +394,9 @@ extern "C" int effdet_dwconv_bn_act(void* stream, int dtype, const void* X, void
                                     float* pool_partial,
                                     int B, int H, int W, int C, int k, int stride) {
     EFFDET_ENTER();
-    return launch_dwconv(stream, dtype, X, Y, nullptr, Wt, scale, shift, act, pool_partial, B, H, W, C, k, stride);
+    return launch_dwconv(stream, dtype, X, Y, Wt, scale, shift, act, pool_partial, B, H, W, C, k, stride);
 }
 
-// training forward of conv_dw + folded BN + SiLU: Z = pre-activation (kept for the backward), A = silu(Z), and the SE pool
-// partial rows of A ([B][effdet_dwconv_blocks_per_image][C], optional) from the same pass
-extern "C" int effdet_train_dwconv_fwd(void* stream, const float* X, float* Z, float* A, const float* Wt, const float* scale,
-                                       const float* shift, float* pool_partial, int B, int H, int W, int C, int k, int stride) {
-    EFFDET_ENTER();
-    if (!A) return EFFDET_EINVAL;
-    return launch_dwconv(stream, 0, X, Z, A, Wt, scale, shift, 1, pool_partial, B, H, W, C, k, stride);
-}
 
 static int launch_se_gate(void* stream, const float* partial, int nblk, int hw,
                           const float* W1, const float* b1, const float* W2t, const float* b2,

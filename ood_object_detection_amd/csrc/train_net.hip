@@ -681,6 +681,85 @@ __global__ __launch_bounds__(256) void dw_bwd_dw_kernel(DwBwdArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// depthwise forward of the training path: conv_dw + folded BN -> Z (pre-activation), A = silu(Z), SE pool partial rows of A.
+// A thread owns 4 consecutive output pixels of a row and 4 channels and, per tap row, loads the input values those pixels share
+// once (4 S + k - S of them) together with the k taps.  Workgroup = 64 channels (16 quads) x 16 strip lanes, 8 strips per lane;
+// pool partial row = one workgroup's sum over its 512 output pixels (lanes added in lane order).
+// ------------------------------------------------------------------------------------------------------------
+struct DwFwdArgs {
+    const float* X; float* Z; float* A; const float* taps; const float* scale; const float* shift; float* pool_partial;
+    int B, H, W, C, Ho, Wo, pad_t, pad_l, strips_x, nstrips, blocks_per_image;
+};
+constexpr int DWF_PX = 4, DWF_SPL = 8;                       // pixels per strip, strips per lane
+
+template <int KS, int S>
+__global__ __launch_bounds__(256) void dw_fwd_train_kernel(DwFwdArgs p) {
+    constexpr int PX = DWF_PX, NW = PX * S + KS - S;
+    __shared__ float sm[16][64];
+    const int cq = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.z * 64 + cq * 4;
+    const bool cv = c < p.C;
+    const long long b = blockIdx.y;
+    f32x4 pool = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (cv) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + c), sh = *reinterpret_cast<const f32x4*>(p.shift + c);
+        const float* Xb = p.X + b * p.H * p.W * p.C + c;
+        for (int it = 0; it < DWF_SPL; ++it) {
+            const int strip = (blockIdx.x * DWF_SPL + it) * 16 + sl;
+            if (strip >= p.nstrips) break;
+            const int oy = strip / p.strips_x, ox0 = (strip - oy * p.strips_x) * PX;
+            f32x4 acc[PX];
+#pragma unroll
+            for (int u = 0; u < PX; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+                const int iy = oy * S + ky - p.pad_t;
+                if (iy < 0 || iy >= p.H) continue;
+                const float* xrow = Xb + (long long)iy * p.W * p.C;
+                f32x4 x[NW], w[KS];
+#pragma unroll
+                for (int j = 0; j < NW; ++j) {
+                    const int ix = ox0 * S - p.pad_l + j;
+                    x[j] = (ix >= 0 && ix < p.W) ? *reinterpret_cast<const f32x4*>(xrow + (long long)ix * p.C) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) w[kx] = *reinterpret_cast<const f32x4*>(p.taps + (long long)(ky * KS + kx) * p.C + c);
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+                    for (int u = 0; u < PX; ++u) acc[u] += x[u * S + kx] * w[kx];
+            }
+#pragma unroll
+            for (int u = 0; u < PX; ++u) {
+                const int ox = ox0 + u;
+                if (ox >= p.Wo) break;
+                const long long o = ((b * p.Ho + oy) * p.Wo + ox) * p.C + c;
+                const f32x4 z = acc[u] * sc + sh;
+                *reinterpret_cast<f32x4*>(p.Z + o) = z;
+                if (p.A) {
+                    f32x4 a;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] = silu_train(z[j]);
+                    *reinterpret_cast<f32x4*>(p.A + o) = a;
+                    pool += a;
+                }
+            }
+        }
+    }
+    if (p.pool_partial == nullptr) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sm[sl][cq * 4 + j] = pool[j];
+    __syncthreads();
+    const int cl = threadIdx.x;
+    if (cl < 64 && blockIdx.z * 64 + cl < p.C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sm[k][cl];
+        p.pool_partial[(b * p.blocks_per_image + blockIdx.x) * p.C + blockIdx.z * 64 + cl] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // element-wise family (4 elements per thread; channel = index % C, image = index / (hw*C))
 // ------------------------------------------------------------------------------------------------------------
 struct EwArgs {
@@ -1265,6 +1344,41 @@ static int dw_fill(DwBwdArgs& a, int B, int H, int W, int C, int k, int stride) 
     a.Ho = same_out(H, stride); a.Wo = same_out(W, stride);
     a.pad_t = same_pad_before(H, k, stride); a.pad_l = same_pad_before(W, k, stride);
     return 0;
+}
+
+static int dwf_fill(DwFwdArgs& a, int B, int H, int W, int C, int k, int stride) {
+    if (B <= 0 || B > 65535 || H <= 0 || W <= 0 || C <= 0 || C % 4 || (k != 3 && k != 5) || (stride != 1 && stride != 2)) return EFFDET_EINVAL;
+    a.B = B; a.H = H; a.W = W; a.C = C;
+    a.Ho = same_out(H, stride); a.Wo = same_out(W, stride);
+    a.pad_t = same_pad_before(H, k, stride); a.pad_l = same_pad_before(W, k, stride);
+    a.strips_x = (a.Wo + DWF_PX - 1) / DWF_PX;
+    a.nstrips = a.strips_x * a.Ho;
+    a.blocks_per_image = (a.nstrips + 16 * DWF_SPL - 1) / (16 * DWF_SPL);
+    return 0;
+}
+
+// SE pool partial rows per image that effdet_train_dwconv_fwd writes for this geometry
+extern "C" int effdet_train_dwconv_fwd_parts(int H, int W, int C, int k, int stride) {
+    DwFwdArgs a;
+    if (dwf_fill(a, 1, H, W, C, k, stride)) return EFFDET_EINVAL;
+    return a.blocks_per_image;
+}
+
+// training forward of conv_dw + folded BN + SiLU: Z = pre-activation (kept for the backward), A = silu(Z) (optional), and the
+// SE pool partial rows of A ([B][effdet_train_dwconv_fwd_parts][C], optional) from the same pass
+extern "C" int effdet_train_dwconv_fwd(void* stream, const float* X, float* Z, float* A, const float* Wt, const float* scale,
+                                       const float* shift, float* pool_partial, int B, int H, int W, int C, int k, int stride) {
+    EFFDET_ENTER();
+    DwFwdArgs a;
+    if (!X || !Z || !Wt || !scale || !shift || (!A && pool_partial) || dwf_fill(a, B, H, W, C, k, stride)) return EFFDET_EINVAL;
+    a.X = X; a.Z = Z; a.A = A; a.taps = Wt; a.scale = scale; a.shift = shift; a.pool_partial = pool_partial;
+    const dim3 grid((unsigned)a.blocks_per_image, (unsigned)B, (unsigned)((C + 63) / 64));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_fwd_train_kernel<3, 1>), grid, dim3(256), 0, st, a);
+    else if (k == 3) hipLaunchKernelGGL((dw_fwd_train_kernel<3, 2>), grid, dim3(256), 0, st, a);
+    else if (stride == 1) hipLaunchKernelGGL((dw_fwd_train_kernel<5, 1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((dw_fwd_train_kernel<5, 2>), grid, dim3(256), 0, st, a);
+    return effdet_check_launch();
 }
 
 static int launch_dw_bwd_dx(void* stream, const float* dY, const float* taps, const float* Z, float* dX,

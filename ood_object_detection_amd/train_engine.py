@@ -120,8 +120,8 @@ class _Ops(object):
     def dw_fwd(self, x, taps, scale, shift, k, s):
         B, H, W, C = x.shape
         y = self.new(B, _same_out(H, s), _same_out(W, s), C)
-        _lib.check(self.lib.effdet_dwconv_bn_act(self.st(), 0, x.data_ptr(), y.data_ptr(), taps.data_ptr(), scale.data_ptr(),
-                                                 shift.data_ptr(), 0, None, B, H, W, C, k, s), 'effdet_dwconv_bn_act')
+        _lib.check(self.lib.effdet_train_dwconv_fwd(self.st(), x.data_ptr(), y.data_ptr(), None, taps.data_ptr(), scale.data_ptr(),
+                                                    shift.data_ptr(), None, B, H, W, C, k, s), 'effdet_train_dwconv_fwd')
         return y
 
     def dw_fwd_train(self, x, taps, scale, shift, k, s):
@@ -129,7 +129,7 @@ class _Ops(object):
         B, H, W, C = x.shape
         Ho, Wo = _same_out(H, s), _same_out(W, s)
         z, a = self.new(B, Ho, Wo, C), self.new(B, Ho, Wo, C)
-        nblk = self.lib.effdet_dwconv_blocks_per_image(Ho, Wo, C)
+        nblk = self.lib.effdet_train_dwconv_fwd_parts(H, W, C, k, s)
         part = self.new(B, nblk, C)
         _lib.check(self.lib.effdet_train_dwconv_fwd(self.st(), x.data_ptr(), z.data_ptr(), a.data_ptr(), taps.data_ptr(),
                                                     scale.data_ptr(), shift.data_ptr(), part.data_ptr(), B, H, W, C, k, s),
