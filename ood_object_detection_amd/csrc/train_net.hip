@@ -24,13 +24,19 @@ namespace {
 constexpr int MAXLEV = 8;
 struct RowMap { long long rpi, img_stride, ld; int nlev; long long lrow0[MAXLEV + 1], lq0[MAXLEV], lhw[MAXLEV]; };
 DEV long long row_off(const RowMap& r, long long m) {
-    if (r.nlev > 0) {
-        int l = 0;
+    if (r.nlev > 0) {                                        // rows < 2^31 (make_levels_rowmap checks): 32-bit division
+        const unsigned mu = (unsigned)m;
+        unsigned row0 = 0, hw = (unsigned)r.lhw[0], q0 = 0;
 #pragma unroll
-        for (int i = 1; i < MAXLEV; ++i) l = (i < r.nlev && m >= r.lrow0[i]) ? i : l;
-        const long long local = m - r.lrow0[l];
-        const long long b = local / r.lhw[l];
-        return b * r.img_stride + (r.lq0[l] + (local - b * r.lhw[l])) * r.ld;
+        for (int i = 1; i < MAXLEV; ++i) {
+            const bool in = i < r.nlev && mu >= (unsigned)r.lrow0[i];
+            row0 = in ? (unsigned)r.lrow0[i] : row0;
+            hw = in ? (unsigned)r.lhw[i] : hw;
+            q0 = in ? (unsigned)r.lq0[i] : q0;
+        }
+        const unsigned local = mu - row0;
+        const unsigned b = local / hw;
+        return (long long)b * r.img_stride + (long long)(q0 + (local - b * hw)) * r.ld;
     }
     if (r.img_stride == 0) return m * r.ld;
     const long long q = m / r.rpi;
@@ -58,7 +64,7 @@ inline long long make_levels_rowmap(RowMap& r, int B, int L, const int* Hs, cons
         q += r.lhw[l];
         r.lrow0[l + 1] = r.lrow0[l] + (long long)B * r.lhw[l];
     }
-    if (q * ld > img_stride) return -1;
+    if (q * ld > img_stride || r.lrow0[L] >= 0x7fffffffLL) return -1;
     return r.lrow0[L];
 }
 
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int n = n0 + 16 * t + 4 * g;
-            if (p.vec_out) {                                     // N % 4 == 0 and 16-byte aligned rows: one store per lane and tile
+            if (p.vec_out == 1) {                                // N % 4 == 0 and 16-byte aligned rows: one store per lane and tile
                 if (n < p.N) {
                     f32x4 v = acc[i][t];
                     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
@@ -201,6 +207,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) q[r] = silu_train(v[r]);
                         *reinterpret_cast<f32x4*>(p.C2 + coff + n) = q;
+                    }
+                }
+                continue;
+            }
+            if (p.vec_out == 2) {                                // N even, 8-byte aligned rows (the 810-wide class head): two stores
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (n + 2 * h < p.N) {
+                        f32x2 v = f32x2{acc[i][t][2 * h], acc[i][t][2 * h + 1]};
+                        if (p.bias) v += *reinterpret_cast<const f32x2*>(p.bias + n + 2 * h);
+                        if (p.R) v += *reinterpret_cast<const f32x2*>(p.R + coff + n + 2 * h);
+                        if (p.accumulate) v += *reinterpret_cast<const f32x2*>(crow + n + 2 * h);
+                        *reinterpret_cast<f32x2*>(crow + n + 2 * h) = v;
+                        if (p.C2) *reinterpret_cast<f32x2*>(p.C2 + coff + n + 2 * h) = f32x2{silu_train(v[0]), silu_train(v[1])};
                     }
                 }
                 continue;
@@ -336,7 +356,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
 // than the step itself)
 // SCALED: X is multiplied by the image's gate row; the gate pieces travel with the stage and are applied at the LDS store (no
 // branch and no use of a loaded value inside the fetch: the waits stay counted)
-template <bool DENSE, bool SCALED>
+// VYW = 2: dY rows are only 8-byte aligned (N even: the 810-wide class head) - the dY piece travels as two 8-byte halves
+template <bool DENSE, bool SCALED, int VYW>
 __global__ __launch_bounds__(256) void gemm_tn_kernel_v(GemmTnArgs p) {
     constexpr int RT = 32, SY = 48, SX = 80;
     __shared__ float lds[4 * 32 * 64];
@@ -358,14 +379,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel_v(GemmTnArgs p) {
     const int yr = tid >> 3, yc = (tid & 7) * 4;
     const int xr = tid >> 4, xc = (tid & 15) * 4;
     const int n = n0 + yc, kk = k0 + xc;
-    const bool nok = n < p.N, kok = kk < p.K, kone = kk == p.K;
-    const int nl = nok ? n : 0, kl = kok ? kk : 0;
+    const bool nok = n < p.N, nok2 = n + 2 < p.N, kok = kk < p.K, kone = kk == p.K;     // N even: a half is inside or outside as a whole
+    const int nl = nok ? n : 0, nl2 = nok2 ? n + 2 : 0, kl = kok ? kk : 0;
     struct Stage { f32x4 vy, vx0, vx1, g0, g1; };
     auto fetch = [&](long long m0) {
         Stage s;
         long long my = m0 + yr, m0x = m0 + xr, m1x = m0 + xr + 16;
         my = my < me ? my : me - 1; m0x = m0x < me ? m0x : me - 1; m1x = m1x < me ? m1x : me - 1;
-        s.vy = *reinterpret_cast<const f32x4*>(p.dY + (DENSE ? my * p.ym.ld : row_off(p.ym, my)) + nl);
+        const float* yrow = p.dY + (DENSE ? my * p.ym.ld : row_off(p.ym, my));
+        if constexpr (VYW == 4) s.vy = *reinterpret_cast<const f32x4*>(yrow + nl);
+        else {
+            const f32x2 lo = *reinterpret_cast<const f32x2*>(yrow + nl), hi = *reinterpret_cast<const f32x2*>(yrow + nl2);
+            s.vy = f32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
         s.vx0 = *reinterpret_cast<const f32x4*>(p.X + (DENSE ? m0x * p.xm.ld : row_off(p.xm, m0x)) + kl);
         s.vx1 = *reinterpret_cast<const f32x4*>(p.X + (DENSE ? m1x * p.xm.ld : row_off(p.xm, m1x)) + kl);
         if constexpr (SCALED) {                               // rows < 2^31 (checked by the launcher): 32-bit division
@@ -385,7 +411,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel_v(GemmTnArgs p) {
         {
             const bool ry = m0 + yr < me, r0 = m0 + xr < me, r1 = m0 + xr + 16 < me;
             if constexpr (SCALED) { sg.vx0 *= sg.g0; sg.vx1 *= sg.g1; }
-            *reinterpret_cast<f32x4*>(sY + yr * SY + yc) = (ry && nok) ? sg.vy : zero4;
+            if constexpr (VYW == 4) *reinterpret_cast<f32x4*>(sY + yr * SY + yc) = (ry && nok) ? sg.vy : zero4;
+            else {
+                const bool lo = ry && nok, hi = ry && nok2;
+                *reinterpret_cast<f32x4*>(sY + yr * SY + yc) = f32x4{lo ? sg.vy[0] : 0.f, lo ? sg.vy[1] : 0.f, hi ? sg.vy[2] : 0.f, hi ? sg.vy[3] : 0.f};
+            }
             *reinterpret_cast<f32x4*>(sX + xr * SX + xc) = r0 ? (kok ? sg.vx0 : (kone ? one4 : zero4)) : zero4;
             *reinterpret_cast<f32x4*>(sX + (xr + 16) * SX + xc) = r1 ? (kok ? sg.vx1 : (kone ? one4 : zero4)) : zero4;
         }
@@ -1167,7 +1197,7 @@ static int launch_gemm_nt(hipStream_t st, GemmNtArgs& p) {
     long long gx = (M + 127) / 128;                          // 4 waves x 32 rows
     if (gx > 0x7fffffffLL) return EFFDET_EINVAL;
     // deep K on few rows: too few workgroups with a long serial chain each -> K split over the workgroup's waves
-    const bool splitk = K >= 192 && gx * ((N + 63) / 64) < 1024;
+    const bool splitk = K >= 384 && gx * ((N + 63) / 64) < 1024;
     if (splitk) gx = (M + 31) / 32;
     const bool vec = K % 4 == 0 && p.am.ld % 4 == 0 && p.am.img_stride % 4 == 0 &&
                      reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(W) % 16 == 0;
@@ -1175,6 +1205,9 @@ static int launch_gemm_nt(hipStream_t st, GemmNtArgs& p) {
                 (bias == nullptr || reinterpret_cast<uintptr_t>(bias) % 16 == 0) &&
                 (C2 == nullptr || reinterpret_cast<uintptr_t>(C2) % 16 == 0) &&
                 (p.R == nullptr || reinterpret_cast<uintptr_t>(p.R) % 16 == 0);
+    if (!p.vec_out && N % 2 == 0 && p.cm.ld % 2 == 0 && p.cm.img_stride % 2 == 0 && reinterpret_cast<uintptr_t>(C) % 8 == 0 &&
+        (bias == nullptr || reinterpret_cast<uintptr_t>(bias) % 8 == 0) && (C2 == nullptr || reinterpret_cast<uintptr_t>(C2) % 8 == 0) &&
+        (p.R == nullptr || reinterpret_cast<uintptr_t>(p.R) % 8 == 0)) p.vec_out = 2;
     const dim3 grid((unsigned)gx, (unsigned)((N + 63) / 64));
     const bool vec2 = K % 2 == 0 && p.am.ld % 2 == 0 && p.am.img_stride % 2 == 0 &&
                       reinterpret_cast<uintptr_t>(A) % 8 == 0 && reinterpret_cast<uintptr_t>(W) % 8 == 0;
@@ -1266,13 +1299,17 @@ static int launch_gemm_tn(hipStream_t st, GemmTnArgs& p, float* out, float* work
     const bool vy = p.ym.ld % 4 == 0 && p.ym.img_stride % 4 == 0 && reinterpret_cast<uintptr_t>(p.dY) % 16 == 0;
     const bool vx = p.xm.ld % 4 == 0 && p.xm.img_stride % 4 == 0 && reinterpret_cast<uintptr_t>(p.X) % 16 == 0;
     const bool vy2 = N % 2 == 0 && p.ym.ld % 2 == 0 && p.ym.img_stride % 2 == 0 && reinterpret_cast<uintptr_t>(p.dY) % 8 == 0;
-    if (vy && vx && N % 4 == 0 && K % 4 == 0 &&
-        (!p.x_scale || (reinterpret_cast<uintptr_t>(p.x_scale) % 16 == 0 && M < 0x7fffffffLL && p.x_scale_rpi < 0x7fffffffLL))) {
-        const bool dense = p.ym.nlev == 0 && p.xm.nlev == 0 && p.ym.img_stride == 0 && p.xm.img_stride == 0;
-        if (dense && p.x_scale) hipLaunchKernelGGL((gemm_tn_kernel_v<true, true>), grid, dim3(256), 0, st, p);
-        else if (dense) hipLaunchKernelGGL((gemm_tn_kernel_v<true, false>), grid, dim3(256), 0, st, p);
-        else if (p.x_scale) hipLaunchKernelGGL((gemm_tn_kernel_v<false, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_tn_kernel_v<false, false>), grid, dim3(256), 0, st, p);
+    const bool xs_ok = !p.x_scale || (reinterpret_cast<uintptr_t>(p.x_scale) % 16 == 0 && M < 0x7fffffffLL && p.x_scale_rpi < 0x7fffffffLL);
+    const bool dense = p.ym.nlev == 0 && p.xm.nlev == 0 && p.ym.img_stride == 0 && p.xm.img_stride == 0;
+    if (vy && vx && N % 4 == 0 && K % 4 == 0 && xs_ok) {
+        if (dense && p.x_scale) hipLaunchKernelGGL((gemm_tn_kernel_v<true, true, 4>), grid, dim3(256), 0, st, p);
+        else if (dense) hipLaunchKernelGGL((gemm_tn_kernel_v<true, false, 4>), grid, dim3(256), 0, st, p);
+        else if (p.x_scale) hipLaunchKernelGGL((gemm_tn_kernel_v<false, true, 4>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_tn_kernel_v<false, false, 4>), grid, dim3(256), 0, st, p);
+    }
+    else if (vy2 && vx && K % 4 == 0 && !p.x_scale) {
+        if (dense) hipLaunchKernelGGL((gemm_tn_kernel_v<true, false, 2>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_tn_kernel_v<false, false, 2>), grid, dim3(256), 0, st, p);
     }
     else if (vy && vx) hipLaunchKernelGGL((gemm_tn_kernel<4, true>), grid, dim3(256), 0, st, p);
     else if (vx) {

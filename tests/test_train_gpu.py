@@ -163,6 +163,191 @@ def test_maxpool_backward_and_upsample(H, W):
     _close(ops.spatial(1, du.permute(0, 2, 3, 1).contiguous().to(DEV)).permute(0, 3, 1, 2), gu, 1e-6, 'upsample bwd')
 
 
+def _nhwc(t):
+    return t.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+@pytest.mark.parametrize('hw', [[(8, 8), (4, 4), (2, 2), (1, 1)], [(10, 6), (5, 3), (3, 2)]])
+def test_levels_ops_match_per_level_torch(hw):
+    """Whole-pyramid operators of csrc/train_levels.hip (one launch over the level-major packed pyramid) against per-level torch:
+    depthwise 3x3 forward / d input / d taps, per-level BN sums, per-level affine + SiLU, BN backward with the SiLU backward
+    folded in, and the GEMMs that read / write the image-major head tensor."""
+    from ood_object_detection_amd.train_engine import _Levels
+    import ctypes
+    ops = _ops()
+    B, C, L = 3, 64, len(hw)
+    lv = _Levels(B, hw)
+    xs = [_rnd(21, 'x%d' % l, (B, C, h, w)) for l, (h, w) in enumerate(hw)]
+    taps = _rnd(21, 'taps', (C, 1, 3, 3), scale=0.3)
+    packed = torch.cat([_nhwc(x).reshape(-1, C) for x in xs], 0)
+    tk = taps.permute(2, 3, 0, 1).reshape(9, C).contiguous().to(DEV)
+    # depthwise forward, d input, d taps
+    xr = [x.clone().requires_grad_() for x in xs]
+    tr = taps.clone().requires_grad_()
+    ys = [F.conv2d(x, tr, None, 1, 1, groups=C) for x in xr]
+    dys = [_rnd(21, 'dy%d' % l, tuple(y.shape)) for l, y in enumerate(ys)]
+    grads = torch.autograd.grad(ys, xr + [tr], dys)
+    y = ops.lv_dw(lv, packed, tk)
+    dyp = torch.cat([_nhwc(d).reshape(-1, C) for d in dys], 0)
+    for l, (got, ref) in enumerate(zip(lv.split(y), ys)):
+        _close(got.permute(0, 3, 1, 2), ref, 1e-5, 'levels dw fwd %d' % l)
+    for l, (got, ref) in enumerate(zip(lv.split(ops.lv_dw(lv, dyp, tk, flip=True)), grads[:L])):
+        _close(got.permute(0, 3, 1, 2), ref, 1e-5, 'levels dw dx %d' % l)
+    _close(ops.lv_dw_bwd_dw(lv, dyp, packed).reshape(3, 3, C, 1).permute(2, 3, 0, 1), grads[L], 2e-5, 'levels dw dtaps')
+    # per-level sums
+    sums = ops.lv_col_reduce(lv, 0, packed)
+    sq = ops.lv_col_reduce(lv, 2, packed, v=sums, vscale=lv.inv_m)
+    pre = torch.cat([_nhwc(_rnd(21, 'z%d' % l, (B, C, h, w))).reshape(-1, C) for l, (h, w) in enumerate(hw)], 0)
+    both = ops.lv_col_reduce(lv, 4, dyp, b=packed, v=(sums * torch.tensor(list(lv.inv_m), device=DEV)[:, None]).contiguous(), pre=pre)
+    o = 0
+    for l, r in enumerate(lv.rows):
+        seg, dseg, zseg = packed[o:o + r].double(), dyp[o:o + r].double(), pre[o:o + r].double()
+        mean = seg.mean(0)
+        _close(sums[l], seg.sum(0), 1e-5, 'levels sum %d' % l)
+        _close(sq[l], ((seg - mean) ** 2).sum(0), 2e-5, 'levels centred sumsq %d' % l)
+        sg = torch.sigmoid(zseg)
+        dd = dseg * (sg * (1 + zseg * (1 - sg)))
+        _close(both[l, 0], dd.sum(0), 2e-5, 'levels sum of dy silu\'(z) %d' % l)
+        _close(both[l, 1], (dd * (seg - mean)).sum(0), 2e-5, 'levels centred dot %d' % l)
+        o += r
+    # per-level affine + SiLU, BN backward
+    v = [ops.new(L, C).copy_(_rnd(21, 'v%d' % i, (L, C))) for i in range(4)]
+    out, act = ops.lv_ew(lv, 3, packed, v=(v[0], v[1], None, None), silu_out=True)
+    train = (ctypes.c_int * L)(*[1 if l % 2 == 0 else 0 for l in range(L)])
+    dc = ops.lv_ew(lv, 6, dyp, b=packed, pre=pre, v=tuple(v), train=train)
+    o = 0
+    for l, r in enumerate(lv.rows):
+        seg = packed[o:o + r]
+        ref = seg * v[0][l] + v[1][l]
+        _close(out[o:o + r], ref, 1e-6, 'levels affine %d' % l)
+        _close(act[o:o + r], ref * torch.sigmoid(ref), 2e-6, 'levels affine + silu %d' % l)
+        z = pre[o:o + r]
+        sg = torch.sigmoid(z)
+        dd = dyp[o:o + r] * (sg * (1 + z * (1 - sg)))
+        ref = v[0][l] * (dd - v[1][l] - (seg - v[2][l]) * v[3][l]) if l % 2 == 0 else dd * v[0][l]
+        _close(dc[o:o + r], ref, 2e-6, 'levels bn bwd %d' % l)
+        o += r
+    # GEMM writing / reading the image-major head tensor [B, P, N]
+    N = 36
+    W = ops.new(N, C).copy_(_rnd(21, 'W', (N, C), scale=0.2))
+    bias = ops.new(N).copy_(_rnd(21, 'b', (N,)))
+    head = ops.new(B, lv.P, N)
+    ops.gemm_nt_levels(lv, packed, W, bias, out_packed=head, pk=(lv.P * N, N))
+    ref = torch.cat([(t.reshape(B, -1, C) @ W.t() + bias) for t in lv.split(packed)], 1)
+    _close(head, ref, 1e-5, 'packed head write')
+    g = ops.new(B, lv.P, N).copy_(_rnd(21, 'g', (B, lv.P, N)))
+    dW, dsum = ops.gemm_tn_levels(lv, g, packed, N, C, y_packed=True, pk=(lv.P * N, N))
+    gl, po = [], 0
+    for (h, w) in hw:
+        gl.append(g[:, po:po + h * w].reshape(-1, N))
+        po += h * w
+    gl = torch.cat(gl, 0).double()
+    _close(dW, gl.t() @ packed.double(), 2e-5, 'dW from the head tensor')
+    _close(dsum, gl.sum(0), 2e-5, 'dsum from the head tensor')
+    _close(ops.gemm_nt_levels(lv, g, W.t().contiguous(), a_packed=True, pk=(lv.P * N, N)), gl @ W.double(), 1e-5, 'dX from the head tensor')
+
+
+@pytest.mark.parametrize('H,W,method', [(8, 8, 0), (5, 5, 1), (6, 10, 0), (1, 1, 0), (4, 4, 2)])
+def test_fpn_combine_ops_match_autograd(H, W, method):
+    """csrc/train_fpn.hip: FpnCombine (identity + nearest x2 upsample + 3x3 / s2 TF-SAME max-pool inputs, 'fastattn' / 'attn' /
+    'sum' weights) + SiLU, forward and backward (edge-weight gradient, per-input gradients with accumulation) against autograd."""
+    from oracle.model import maxpool_pad
+    ops = _ops()
+    B, C = 2, 16
+    fine = (2 * H - (1 if H % 2 else 0), 2 * W - (1 if W % 2 else 0)) if H > 1 else (2, 2)   # a finer map that pools to H x W
+    srcs = [_rnd(31, 'same', (B, C, H, W)).requires_grad_(), _rnd(31, 'fine', (B, C) + fine).requires_grad_()]
+    if H % 2 == 0 and W % 2 == 0:
+        srcs.append(_rnd(31, 'coarse', (B, C, H // 2, W // 2)).requires_grad_())
+    n = len(srcs)
+    ew = _rnd(31, 'ew', (n,)).abs() + 0.1
+    ew[0] = -0.3 if method == 0 else ew[0]                       # a clipped edge weight: its gradient is exactly zero
+    ew = ew.requires_grad_()
+    res = [srcs[0], maxpool_pad(srcs[1], 3, 2, 'same')] + ([F.interpolate(srcs[2], scale_factor=2.0, mode='nearest')] if n > 2 else [])
+    if method == 0:
+        wv = torch.relu(ew)
+        fused = sum(r * wv[i] / (wv.sum() + 0.0001) for i, r in enumerate(res))
+    elif method == 1:
+        wv = torch.softmax(ew, 0)
+        fused = sum(r * wv[i] for i, r in enumerate(res))
+    else:
+        fused = sum(res)
+    act = fused * torch.sigmoid(fused)
+    dact = _rnd(31, 'dact', tuple(act.shape))
+    grads = torch.autograd.grad(act, srcs + ([ew] if method < 2 else []), dact)
+    ins = [_nhwc(t) for t in srcs]
+    ewd = ew.detach().to(DEV)
+    wdev = ops.fpn_weights(ewd if method < 2 else None, n, method)
+    f_hip, a_hip = ops.fpn_combine(ins, wdev, method, H, W)
+    _close(f_hip.permute(0, 3, 1, 2), fused, 2e-6, 'fpn fused')
+    _close(a_hip.permute(0, 3, 1, 2), act, 2e-6, 'fpn act')
+    dd = _nhwc(dact)
+    if method < 2:
+        # the closed form subtracts terms of size |sum(dfused * input_i)| / den: the bound is relative to those, not to the
+        # (possibly cancelled) result
+        sg = torch.sigmoid(fused.detach())
+        dfused = dact * (sg * (1 + fused.detach() * (1 - sg)))
+        scale = max(float((dfused * r.detach()).sum().abs()) for r in res) / (float(torch.relu(ew.detach()).sum()) + 1e-4 if method == 0 else 1.0)
+        got = ops.fpn_wgrad(ins, wdev, method, ewd, dd, f_hip).cpu()
+        assert float((got - grads[n]).abs().max()) <= 2e-5 * max(scale, float(grads[n].abs().max())), (got, grads[n], scale)
+        if method == 0:
+            assert float(ops.fpn_wgrad(ins, wdev, method, ewd, dd, f_hip)[0]) == 0.0
+    for i in range(n):
+        _close(ops.fpn_input_bwd(i, ins[i], wdev, dd, f_hip).permute(0, 3, 1, 2), grads[i], 1e-5, 'd input %d' % i)
+    prev = ops.new(*ins[1].shape).copy_(_rnd(31, 'prev', tuple(ins[1].shape)))
+    _close(ops.fpn_input_bwd(1, ins[1], wdev, dd, f_hip, acc=prev).permute(0, 3, 1, 2), grads[1] + prev.permute(0, 3, 1, 2).cpu(), 1e-5,
+           'd input accumulated')
+
+
+@pytest.mark.parametrize('H,W,C,k,s', [(12, 10, 40, 3, 1), (9, 13, 24, 5, 1), (12, 12, 96, 3, 2), (7, 9, 72, 5, 2), (4, 4, 8, 5, 1)])
+def test_fused_mbconv_kernels(H, W, C, k, s):
+    """The fused forms of one MBConv block: depthwise forward (Z, silu(Z), SE pool partial rows), SE gate with pooled sums, project
+    GEMM with the gate on load and the shortcut in the epilogue, gated weight gradient, depthwise d input with SiLU backward."""
+    from ood_object_detection_amd import _lib
+    ops = _ops()
+    B, R, N = 3, 4, 16
+    x = _rnd(41, 'x', (B, C, H, W))
+    taps, scale, shift = _rnd(41, 't', (C, 1, k, k), scale=0.3), _rnd(41, 'sc', (C,)).abs() + 0.5, _rnd(41, 'sh', (C,))
+    z_ref = F.conv2d(_same_pad(x, k, s), taps, None, s, groups=C) * scale[None, :, None, None] + shift[None, :, None, None]
+    a_ref = z_ref * torch.sigmoid(z_ref)
+    tk = taps.permute(2, 3, 0, 1).reshape(k * k, C).contiguous().to(DEV)
+    z, a, part, nblk = ops.dw_fwd_train(_nhwc(x), tk, scale.to(DEV), shift.to(DEV), k, s)
+    _close(z.permute(0, 3, 1, 2), z_ref, 1e-5, 'dw z')
+    _close(a.permute(0, 3, 1, 2), a_ref, 1e-5, 'dw silu(z)')
+    _close(part.sum(1), a_ref.sum((2, 3)), 1e-5, 'SE pool partial rows')
+    _close(ops.dw_fwd(_nhwc(x), tk, scale.to(DEV), shift.to(DEV), k, s).permute(0, 3, 1, 2), z_ref, 1e-5, 'dw z only')
+    Ho, Wo = z_ref.shape[2:]
+    W1, b1, W2, b2 = _rnd(41, 'W1', (R, C), scale=0.2), _rnd(41, 'b1', (R,)), _rnd(41, 'W2', (C, R), scale=0.2), _rnd(41, 'b2', (C,))
+    s_ref = a_ref.mean((2, 3))
+    r_ref = s_ref @ W1.t() + b1
+    gate_ref = torch.sigmoid((r_ref * torch.sigmoid(r_ref)) @ W2.t() + b2)
+    gate, pool = ops.new(B, C), ops.new(B, C)
+    w1d, b1d, w2td, b2d = W1.to(DEV), b1.to(DEV), W2.t().contiguous().to(DEV), b2.to(DEV)      # kept alive across the launch
+    _lib.check(ops.lib.effdet_train_se_gate(ops.st(), part.data_ptr(), nblk, Ho * Wo, w1d.data_ptr(), b1d.data_ptr(),
+                                            w2td.data_ptr(), b2d.data_ptr(), gate.data_ptr(), pool.data_ptr(), B, C, R),
+               'effdet_train_se_gate')
+    _close(gate, gate_ref, 1e-5, 'SE gate')
+    _close(pool, a_ref.sum((2, 3)), 1e-5, 'SE pooled sums')
+    Wp, bp, res = _rnd(41, 'Wp', (N, C), scale=0.2), _rnd(41, 'bp', (N,)), _rnd(41, 'res', (B, Ho, Wo, N))
+    ag = (a_ref * gate_ref[:, :, None, None]).permute(0, 2, 3, 1)
+    out, out2 = ops.gemm_nt_fused(a, Wp.to(DEV), bp.to(DEV), a_scale=gate, a_rows=Ho * Wo, R=res.to(DEV), silu_out=True)
+    ref = ag @ Wp.t() + bp + res
+    _close(out.view(B, Ho, Wo, N), ref, 1e-5, 'gated project conv + shortcut')
+    _close(out2.view(B, Ho, Wo, N), ref * torch.sigmoid(ref), 1e-5, 'silu of it')
+    dz = _rnd(41, 'dz', (B, Ho, Wo, N))
+    dW, dsum = ops.gemm_tn_scaled(dz.to(DEV), a, gate, Ho * Wo, N, C)
+    _close(dW, dz.reshape(-1, N).double().t() @ ag.reshape(-1, C).double(), 2e-5, 'gated dW')
+    _close(dsum, dz.reshape(-1, N).double().sum(0), 2e-5, 'dsum')
+    # depthwise d input, times silu'(z_below)
+    xr = x.clone().requires_grad_()
+    zb = _rnd(41, 'zb', (B, C, H, W)).requires_grad_()
+    y = F.conv2d(_same_pad(xr * 1.0, k, s), taps, None, s, groups=C)
+    dy = _rnd(41, 'dy', tuple(y.shape))
+    (gx,) = torch.autograd.grad(y, xr, dy)
+    sg = torch.sigmoid(zb.detach())
+    dx, _, _ = ops.dw_bwd(_nhwc(dy), _nhwc(x), tk, k, s, z=_nhwc(zb))
+    _close(dx.permute(0, 3, 1, 2), gx * (sg * (1 + zb.detach() * (1 - sg))), 1e-5, 'dw dx * silu\'(z)')
+
+
 def test_im2col_stem_matches_conv():
     from ood_object_detection_amd import _lib
     ops = _ops()
