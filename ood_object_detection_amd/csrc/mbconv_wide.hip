@@ -382,7 +382,7 @@ WideGeometry pick_wide(int H, int W, int Cin, int mid, int k, int stride) {
     g.use = false;
     const int cbytes = Cin * 2;
     g.nkc = (cbytes + 63) / 64;
-    if ((g.nkc != 3 && g.nkc != 4 && g.nkc != 6) || mid % 16 || Cin % 8) return g;        // narrower inputs: mbconv_roll.hip; wider: the band x slice form
+    if ((g.nkc < 3 || g.nkc > 6) || mid % 16 || Cin % 8) return g;        // narrower inputs: mbconv_roll.hip; wider: the band x slice form
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
     // one strip per row where the row fits 64 input pixels, else equal strips
     int best_ns = 0;
@@ -500,6 +500,7 @@ int launch_wide_ks(hipStream_t st, const WideArgs& r, const WideGeometry& g) {
     switch (g.nkc) {
         case 3: kern = wide_kernel_for<KS, S, 3>(mt, no, g.npl); break;
         case 4: kern = wide_kernel_for<KS, S, 4>(mt, no, g.npl); break;
+        case 5: kern = wide_kernel_for<KS, S, 5>(mt, no, g.npl); break;
         case 6: kern = wide_kernel_for<KS, S, 6>(mt, no, g.npl); break;
         default: break;
     }
