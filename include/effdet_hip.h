@@ -332,6 +332,15 @@ int effdet_train_bn_finalize(void* stream, const float* mean, const float* var, 
 int effdet_train_bn_bwd_prep(void* stream, const float* s1, const float* s2c, const float* rstd, int C, float inv_m,
                              float* dgamma, float* dbeta, float* v1, float* v3);
 
+/* Table-driven forms of effdet_train_fold_bn / plain transposes and of effdet_train_convbn_grads: one launch for all convs of
+ * a stage.  `table` = n records in DEVICE memory:
+ *   prep  { int kind, rows, cols; float eps; const float *src, *gamma, *beta, *mean, *var; float *dst0, *dst1, *dst2, *scale,
+ *           *shift, *rstd; }   kind 0: dst0 [cols][rows] = src [rows][cols] transposed; kind 1: fold_bn with W = src [N = rows][K = cols],
+ *           dst0 = Wf, dst1 = WfT, dst2 = WT (each optional)
+ *   grads { const float *dWext, *W, *scale, *rstd, *mean; float *dW, *dgamma, *dbeta; int N, K, transposed, pad; } */
+int effdet_train_prep_table(void* stream, const void* table, int n, long long max_elems);
+int effdet_train_grads_table(void* stream, const void* table, int n, int max_n);
+
 /* ---- fused forms of one MBConv block of the backbone (timm InvertedResidual / DepthwiseSeparableConv, BN in eval mode) --------
  * train_dwconv_fwd:     conv_dw + folded BN: Z = pre-activation (kept for the backward), A = silu(Z) (optional) and the SE pool partial
  *                       rows of A ([B][effdet_train_dwconv_fwd_parts(H,W,C,k,stride)][C], optional) in one pass

@@ -151,6 +151,8 @@ SIGNATURES = {
                                            c_ll, c_int, c_int]),
     'effdet_train_gemm_tn_scaled': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_ll, c_int, c_int, c_void_p, c_void_p, c_ll]),
     'effdet_train_dwconv_bwd_dx_silu': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
+    'effdet_train_prep_table': (c_int, [c_void_p, c_void_p, c_int, c_ll]),
+    'effdet_train_grads_table': (c_int, [c_void_p, c_void_p, c_int, c_int]),
     'effdet_gather_ood': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_int, c_int, c_int,
                                   c_void_p, c_void_p, c_void_p]),
 }

@@ -402,7 +402,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel_v(GemmTnArgs p) {
         return s;
     };
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f}, one4 = f32x4{1.f, 0.f, 0.f, 0.f};
-    if (mb >= me) return;                                     // (no slice is empty; guards the clamps above)
+    // a slice past the end of M (rows_per_slice is rounded up to whole steps) is empty: no step runs and its partial row is
+    // written as zeros below - the second stage adds every row.  The clamps above stay valid (me - 1 = M - 1 then).
     Stage s0 = fetch(mb), s1 = fetch(mb + RT);
     // one step: the stage's registers go to LDS (masks applied here), are refilled at once with the rows two steps ahead, and the
     // tile is multiplied.  Two stages ping-pong without register copies (a copy `s0 = s1` would wait for s1's loads).
@@ -1186,7 +1187,78 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(BnBwdArgs p) {
     p.v3[c] = rs * rs * s2 * p.invM;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Table-driven forms of the parameter-sized helpers: ONE launch for every conv of a stage instead of one per conv.
+// ------------------------------------------------------------------------------------------------------------
+struct PrepOp {                                 // mirrored by train_engine._PrepOp (ctypes)
+    int kind, rows, cols; float eps;            // kind 0: transpose src [rows][cols] -> dst0 [cols][rows]; 1: fold_bn (rows = N, cols = K)
+    const float* src; const float* gamma; const float* beta; const float* mean; const float* var;
+    float* dst0; float* dst1; float* dst2; float* scale; float* shift; float* rstd;      // fold: Wf, WfT, WT (each optional)
+};
+__global__ __launch_bounds__(256) void prep_table_kernel(const PrepOp* ops, int n) {
+    const PrepOp p = ops[blockIdx.y];
+    const long long total = (long long)p.rows * p.cols;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int r = (int)(e / p.cols), c = (int)(e - (long long)r * p.cols);
+        const float w = p.src[e];
+        if (p.kind == 0) { p.dst0[(long long)c * p.rows + r] = w; continue; }
+        const float rs = 1.0f / sqrtf(p.var[r] + p.eps);
+        const float sc = p.gamma[r] * rs;
+        if (c == 0) { p.scale[r] = sc; p.shift[r] = p.beta[r] - p.mean[r] * sc; p.rstd[r] = rs; }
+        if (p.dst0) p.dst0[e] = w * sc;
+        if (p.dst1) p.dst1[(long long)c * p.rows + r] = w * sc;
+        if (p.dst2) p.dst2[(long long)c * p.rows + r] = w;
+    }
+}
+
+struct GradOp {                                 // mirrored by train_engine._GradOp: effdet_train_convbn_grads per table row
+    const float* dWext; const float* W; const float* scale; const float* rstd; const float* mean;
+    float* dW; float* dgamma; float* dbeta; int N, K, transposed, pad;
+};
+__global__ __launch_bounds__(256) void grads_table_kernel(const GradOp* ops, int n) {
+    __shared__ float sm[4];
+    const GradOp p = ops[blockIdx.y];
+    const int nn = blockIdx.x;
+    if (nn >= p.N) return;                       // uniform per workgroup
+    const float sc = p.scale[nn];
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < p.K; k += 256) {
+        const float v = p.transposed ? p.dWext[(long long)k * p.N + nn] : p.dWext[(long long)nn * p.K + k];
+        p.dW[(long long)nn * p.K + k] = sc * v;
+        acc += p.W[(long long)nn * p.K + k] * v;
+    }
+    acc = wave_reduce_sum(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tot = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+        const float dsum = p.dWext[(long long)p.K * p.N + nn];
+        p.dgamma[nn] = p.rstd[nn] * (tot - p.mean[nn] * dsum);
+        p.dbeta[nn] = dsum;
+    }
+}
+
 }  // namespace
+
+// table: n PrepOp records in device memory (layout above); max_elems = the largest rows * cols in the table
+extern "C" int effdet_train_prep_table(void* stream, const void* table, int n, long long max_elems) {
+    EFFDET_ENTER();
+    if (!table || n <= 0 || n > 65535 || max_elems <= 0) return EFFDET_EINVAL;
+    long long gx = (max_elems + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(prep_table_kernel, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       static_cast<const PrepOp*>(table), n);
+    return effdet_check_launch();
+}
+
+// table: n GradOp records in device memory; max_n = the largest N in the table
+extern "C" int effdet_train_grads_table(void* stream, const void* table, int n, int max_n) {
+    EFFDET_ENTER();
+    if (!table || n <= 0 || n > 65535 || max_n <= 0) return EFFDET_EINVAL;
+    hipLaunchKernelGGL(grads_table_kernel, dim3((unsigned)max_n, (unsigned)n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       static_cast<const GradOp*>(table), n);
+    return effdet_check_launch();
+}
 
 // ================================================================================================================
 // C ABI

@@ -39,6 +39,9 @@ class _HeadKernels(TrainEngine):
         self.ops = _Ops(dev)
         self.lib = self.ops.lib
         self._ones = {}
+        self._stage = None                       # never inside a TrainEngine stage: derived weights are computed on the spot
+        self._tables = {}
+        self.use_tables = False
 
 
 _kernels = {}

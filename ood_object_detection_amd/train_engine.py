@@ -16,6 +16,7 @@ d weight / d gamma / d beta / d edge_weights) and owns memory, streams and the a
 functions (`BackboneFn`, `FpnHeadFn`) plug into, so `loss.backward()` fills `.grad` exactly like the reference.
 There is no CPU fallback.
 """
+import ctypes
 import math
 
 import torch
@@ -28,6 +29,103 @@ def _same_out(n, s):
 
 
 _FPN_METHODS = {'fastattn': 0, 'attn': 1, 'sum': 2}
+
+
+class _PrepOp(ctypes.Structure):               # csrc/train_net.hip PrepOp
+    _fields_ = [('kind', ctypes.c_int), ('rows', ctypes.c_int), ('cols', ctypes.c_int), ('eps', ctypes.c_float)] + \
+               [(n, ctypes.c_void_p) for n in ('src', 'gamma', 'beta', 'mean', 'var', 'dst0', 'dst1', 'dst2', 'scale', 'shift', 'rstd')]
+
+
+class _GradOp(ctypes.Structure):               # csrc/train_net.hip GradOp
+    _fields_ = [(n, ctypes.c_void_p) for n in ('dWext', 'W', 'scale', 'rstd', 'mean', 'dW', 'dgamma', 'dbeta')] + \
+               [('N', ctypes.c_int), ('K', ctypes.c_int), ('transposed', ctypes.c_int), ('pad', ctypes.c_int)]
+
+
+class _StageTables(object):
+    """The parameter-sized work of one stage (backbone, or BiFPN + heads) as ONE launch per kind instead of one per conv:
+    the derived weights of a step (BN folded into conv weights, transposed copies for the dX GEMMs, tap-major depthwise taps,
+    the transposed SE expand weight) and the closed-form conv + BN parameter gradients.  The first forward / backward records
+    what the stage needs (and computes it conv by conv); from then on `run_prep()` at the start of the forward refreshes every
+    derived tensor - they live in persistent buffers - from the current parameters, and `run_grads()` at the end of the backward
+    turns the raw GEMM sums into parameter gradients.  Keys are parameter names, so the stage must keep its module structure."""
+
+    def __init__(self, ops):
+        self.ops, self.lib = ops, ops.lib
+        self.prep, self.grad = {}, {}              # key -> (op record, tensors kept alive)
+        self.ptab = self.gtab = None
+        self.frozen = False                        # True once the tables are on the device
+
+    def _check_src(self, entry, src):
+        if entry[0].src != src.data_ptr():
+            raise RuntimeError('a parameter was re-allocated after the training engine recorded it; build a new TrainEngine')
+
+    def transpose(self, key, src2d):
+        """-> persistent [cols, rows] transpose of the contiguous 2-D parameter view src2d (None while recording: caller computes)"""
+        if key in self.prep:
+            self._check_src(self.prep[key], src2d)
+            return self.prep[key][1][0]
+        if self.frozen:
+            raise RuntimeError('unrecorded derived weight %r' % (key,))
+        rows, cols = src2d.shape
+        dst = self.ops.new(cols, rows)
+        dst.copy_(src2d.t())
+        op = _PrepOp(0, rows, cols, 0.0, src2d.data_ptr(), None, None, None, None, dst.data_ptr(), None, None, None, None, None)
+        self.prep[key] = (op, (dst, src2d))
+        return dst
+
+    def fold(self, key, W, bn, want_wf, want_wft, want_wt, compute):
+        if key in self.prep:
+            self._check_src(self.prep[key], W)
+            return self.prep[key][1][0]
+        if self.frozen:
+            raise RuntimeError('unrecorded derived weight %r' % (key,))
+        out = compute()                             # (Wf, WfT, WT, scale, shift, rstd) from effdet_train_fold_bn: these buffers persist
+        p = lambda t: None if t is None else t.data_ptr()
+        N, K = W.shape
+        op = _PrepOp(1, N, K, float(bn.eps), W.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                     bn.running_var.data_ptr(), p(out[0]), p(out[1]), p(out[2]), out[3].data_ptr(), out[4].data_ptr(), out[5].data_ptr())
+        self.prep[key] = (op, (out, W, bn))
+        return out
+
+    def grad_entry(self, key, rec, transposed):
+        """-> (dWext buffer the backward GEMM writes, dW, dgb, deferred) for conv `key`; deferred: run_grads() will fill dW / dgb"""
+        if key in self.grad:
+            return self.grad[key][1][:3] + (self.gtab is not None,)
+        if self.gtab is not None:
+            raise RuntimeError('unrecorded gradient %r' % (key,))
+        N, K = rec['W'].shape
+        dwext, dW, dgb = self.ops.new(N * K + N), self.ops.new(N, K), self.ops.new(2, N)
+        op = _GradOp(dwext.data_ptr(), rec['W'].data_ptr(), rec['scale'].data_ptr(), rec['rstd'].data_ptr(), rec['mean'].data_ptr(),
+                     dW.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), N, K, int(transposed), 0)
+        self.grad[key] = (op, (dwext, dW, dgb, rec['W'], rec['scale'], rec['rstd'], rec['mean']))
+        return dwext, dW, dgb, False
+
+    @staticmethod
+    def _upload(ops_list, cls, dev):
+        arr = (cls * len(ops_list))(*ops_list)
+        return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+
+    def run_prep(self):
+        if not self.prep:
+            return
+        if self.ptab is None:
+            recs = [v[0] for v in self.prep.values()]
+            self.ptab = self._upload(recs, _PrepOp, self.ops.dev)
+            self.pmax = max(r.rows * r.cols for r in recs)
+            self.frozen = True
+        _lib.check(self.lib.effdet_train_prep_table(self.ops.st(), self.ptab.data_ptr(), len(self.prep), self.pmax),
+                   'effdet_train_prep_table')
+
+    def run_grads(self):
+        if not self.grad:
+            return
+        if self.gtab is None:                        # end of the recording backward (it computed conv by conv): table for the next ones
+            recs = [v[0] for v in self.grad.values()]
+            self.gtab = self._upload(recs, _GradOp, self.ops.dev)
+            self.gmax = max(r.N for r in recs)
+            return
+        _lib.check(self.lib.effdet_train_grads_table(self.ops.st(), self.gtab.data_ptr(), len(self.grad), self.gmax),
+                   'effdet_train_grads_table')
 
 
 class _Levels(object):
@@ -98,7 +196,7 @@ class _Ops(object):
                                                  None if out2 is None else out2.data_ptr()), 'effdet_train_gemm_nt')
         return (out, out2) if silu_out else out
 
-    def gemm_tn(self, dY, X, N, K, M=None, y_map=None, x_map=None):
+    def gemm_tn(self, dY, X, N, K, M=None, y_map=None, x_map=None, out=None):
         """-> (dW [N,K], dsum [N]) = dY^T [X | 1]"""
         if y_map is None:
             M = dY.numel() // N
@@ -111,7 +209,7 @@ class _Ops(object):
             xp, xm = x_map[0], x_map[1:]
         n = self.lib.effdet_train_gemm_tn_workspace_floats(M, N, K)
         ws = self.ws(n)
-        out = self.new(N * K + N)
+        out = self.new(N * K + N) if out is None else out
         _lib.check(self.lib.effdet_train_gemm_tn(self.st(), yp, ym[0], ym[1], ym[2], xp, xm[0], xm[1], xm[2], M, N, K,
                                                  out.data_ptr(), ws.data_ptr(), ws.numel()), 'effdet_train_gemm_tn')
         return out[:N * K].view(N, K), out[N * K:]
@@ -147,15 +245,15 @@ class _Ops(object):
                                                        out.data_ptr(), p(out2), M, K, N), 'effdet_train_gemm_nt_fused')
         return (out, out2) if silu_out else out
 
-    def gemm_tn_scaled(self, dY, X, x_scale, x_rows, N, K):
+    def gemm_tn_scaled(self, dY, X, x_scale, x_rows, N, K, out=None):
         M = dY.numel() // N
         ws = self.ws(self.lib.effdet_train_gemm_tn_workspace_floats(M, N, K))
-        out = self.new(N * K + N)
+        out = self.new(N * K + N) if out is None else out
         _lib.check(self.lib.effdet_train_gemm_tn_scaled(self.st(), dY.data_ptr(), X.data_ptr(), x_scale.data_ptr(), x_rows, M, N, K,
                                                         out.data_ptr(), ws.data_ptr(), ws.numel()), 'effdet_train_gemm_tn_scaled')
         return out[:N * K].view(N, K), out[N * K:]
 
-    def dw_bwd(self, dy, x, taps, k, s, z=None):
+    def dw_bwd(self, dy, x, taps, k, s, z=None, out=None):
         """-> dx, dtaps [k*k, C], dsum [C]   (taps already carry any folded BN scale); z: dx is multiplied by silu'(z)"""
         B, H, W, C = x.shape
         dx = self.new(B, H, W, C)
@@ -167,7 +265,7 @@ class _Ops(object):
                        'effdet_train_dwconv_bwd_dx')
         n = self.lib.effdet_train_dwconv_bwd_dw_workspace_floats(B, H, W, C, k, s)
         ws = self.ws(n)
-        out = self.new(k * k + 1, C)
+        out = self.new(k * k + 1, C) if out is None else out.view(k * k + 1, C)
         _lib.check(self.lib.effdet_train_dwconv_bwd_dw(self.st(), dy.data_ptr(), x.data_ptr(), out.data_ptr(), B, H, W, C, k, s,
                                                        ws.data_ptr(), ws.numel()), 'effdet_train_dwconv_bwd_dw')
         return dx, out[:k * k], out[k * k]
@@ -379,6 +477,10 @@ class TrainEngine(object):
         self.L = cfg.num_levels
         self.A = model.num_anchors
         self._ones = {}
+        self._tables = {'bb': _StageTables(self.ops), 'fh': _StageTables(self.ops)}
+        self._stage = None                          # the stage whose forward / backward is running (None: called from outside, e.g. meta_grad)
+        import os
+        self.use_tables = os.environ.get('EFFDET_TRAIN_TABLES', '1') != '0'     # 0: every derived weight / gradient conv by conv (debugging)
         self.direct_grad = False        # True: parameter gradients are added into existing `.grad`s by one multi-tensor launch
 
     def _const(self, C, v):
@@ -390,36 +492,55 @@ class TrainEngine(object):
     # =============================================================================================
     # conv (+BN) building blocks.  Every *_fwd returns (output, record); *_bwd(record, dy, grads) returns dx.
     # =============================================================================================
-    def _fold(self, W, bn, want_wf, want_wft, want_wt):
+    def _fold(self, W, bn, want_wf, want_wft, want_wt, key=None):
         """effdet_train_fold_bn: (Wf, WfT, WT, scale, shift, rstd) of a conv weight [N, K] and its BatchNorm (running stats)"""
         N, K = W.shape
         ops = self.ops
-        Wf = ops.new(N, K) if want_wf else None
-        WfT = ops.new(K, N) if want_wft else None
-        WT = ops.new(K, N) if want_wt else None
-        vec = ops.new(3, N)
-        p = lambda t: None if t is None else t.data_ptr()
-        _lib.check(self.lib.effdet_train_fold_bn(ops.st(), W.data_ptr(), N, K, bn.weight.data_ptr(), bn.bias.data_ptr(),
-                                                 bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.eps),
-                                                 p(Wf), p(WfT), p(WT), vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr()),
-                   'effdet_train_fold_bn')
-        return Wf, WfT, WT, vec[0], vec[1], vec[2]
 
-    def _convbn_grads(self, rec, dwext, transposed, grads):
-        """effdet_train_convbn_grads: d weight (parameter layout), d gamma, d beta from the raw sums of the backward GEMM"""
+        def compute():
+            Wf = ops.new(N, K) if want_wf else None
+            WfT = ops.new(K, N) if want_wft else None
+            WT = ops.new(K, N) if want_wt else None
+            vec = ops.new(3, N)
+            p = lambda t: None if t is None else t.data_ptr()
+            _lib.check(self.lib.effdet_train_fold_bn(ops.st(), W.data_ptr(), N, K, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                                     bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.eps),
+                                                     p(Wf), p(WfT), p(WT), vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr()),
+                       'effdet_train_fold_bn')
+            return Wf, WfT, WT, vec[0], vec[1], vec[2]
+
+        if self._stage is None or key is None:
+            return compute()
+        return self._tables[self._stage].fold(key, W, bn, want_wf, want_wft, want_wt, compute)
+
+    def _transposed(self, key, src2d):
+        """contiguous transpose of a 2-D parameter view: from the stage's table inside a stage, computed on the spot otherwise"""
+        if self._stage is None or key is None:
+            return src2d.t().contiguous()
+        return self._tables[self._stage].transpose(key, src2d)
+
+    def _grad_bufs(self, rec, transposed):
+        """-> (buffer for the backward GEMM's raw sums [N*K + N], dW, dgb, deferred)"""
+        if self._stage is None or not rec.get('table', True):
+            N, K = rec['W'].shape
+            return self.ops.new(N * K + N), self.ops.new(N, K), self.ops.new(2, N), False
+        return self._tables[self._stage].grad_entry(rec['names'][0], rec, transposed)
+
+    def _convbn_grads(self, rec, bufs, transposed, grads):
+        """effdet_train_convbn_grads: d weight (parameter layout), d gamma, d beta from the raw sums of the backward GEMM (bufs[0]);
+        deferred: the stage's table launch at the end of the backward fills dW / dgb instead"""
         N, K = rec['W'].shape
-        ops = self.ops
-        dW = ops.new(N, K)
-        dgb = ops.new(2, N)
-        _lib.check(self.lib.effdet_train_convbn_grads(ops.st(), dwext.data_ptr(), N, K, int(transposed), rec['W'].data_ptr(),
-                                                      rec['scale'].data_ptr(), rec['rstd'].data_ptr(), rec['mean'].data_ptr(),
-                                                      dW.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr()), 'effdet_train_convbn_grads')
+        dwext, dW, dgb, deferred = bufs
+        if not deferred:
+            _lib.check(self.lib.effdet_train_convbn_grads(self.ops.st(), dwext.data_ptr(), N, K, int(transposed), rec['W'].data_ptr(),
+                                                          rec['scale'].data_ptr(), rec['rstd'].data_ptr(), rec['mean'].data_ptr(),
+                                                          dW.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr()), 'effdet_train_convbn_grads')
         wn, gn, bn_ = rec['names']
         grads[wn] = dW.view(rec['wshape'])
         grads[gn] = dgb[0]
         grads[bn_] = dgb[1]
 
-    def _pw_bneval_fwd(self, x, conv, bn, names, silu_out=False, gate=None, resid=None):
+    def _pw_bneval_fwd(self, x, conv, bn, names, silu_out=False, gate=None, resid=None, table=True):
         """1x1 conv (no bias) + BN with running statistics, folded: z = x (scale*W)^T + shift (and a = silu(z) when asked).
         gate [B, K]: the SE gate, applied to x while the GEMM loads it; resid: the block's shortcut, added in the epilogue."""
         if bn.training:
@@ -429,10 +550,10 @@ class TrainEngine(object):
                                       'the differentiable path)')
         N = conv.weight.shape[0]
         W = conv.weight.detach().reshape(N, -1)
-        Wf, WfT, _, scale, shift, rstd = self._fold(W, bn, True, True, False)
+        Wf, WfT, _, scale, shift, rstd = self._fold(W, bn, True, True, False, key=names[0] if table else None)
         B, H, Wd, K = x.shape
         rec = dict(x=x, W=W, Wf=Wf, WfT=WfT, mean=bn.running_mean, rstd=rstd, scale=scale, names=names, wshape=conv.weight.shape,
-                   gate=gate, hw=H * Wd)
+                   gate=gate, hw=H * Wd, table=table)
         out = self.ops.gemm_nt_fused(x, Wf, shift, a_scale=gate, a_rows=H * Wd, R=resid, silu_out=silu_out)
         if silu_out:
             return (out[0].view(B, H, Wd, N), out[1].view(B, H, Wd, N)), rec
@@ -441,11 +562,12 @@ class TrainEngine(object):
     def _pw_bneval_bwd(self, rec, dz, grads, need_dx=True, resid=None):
         """-> d x (+ resid: the gradient that reaches x through the shortcut); for a gated conv d (x * gate)"""
         N, K = rec['Wf'].shape
+        bufs = self._grad_bufs(rec, False)
         if rec['gate'] is not None:
-            dWraw, _ = self.ops.gemm_tn_scaled(dz, rec['x'], rec['gate'], rec['hw'], N, K)
+            self.ops.gemm_tn_scaled(dz, rec['x'], rec['gate'], rec['hw'], N, K, out=bufs[0])
         else:
-            dWraw, _ = self.ops.gemm_tn(dz, rec['x'], N, K)
-        self._convbn_grads(rec, dWraw._base, False, grads)
+            self.ops.gemm_tn(dz, rec['x'], N, K, out=bufs[0])
+        self._convbn_grads(rec, bufs, False, grads)
         if not need_dx:
             return None
         B, H, Wd, _ = dz.shape
@@ -457,7 +579,7 @@ class TrainEngine(object):
             raise NotImplementedError('backbone BatchNorm in batch-statistics mode is not built (see pretrain.py:168-176)')
         C = conv.weight.shape[0]
         W = conv.weight.detach().reshape(C, k * k)
-        _, taps_s, taps, scale, shift, rstd = self._fold(W, bn, False, True, True)
+        _, taps_s, taps, scale, shift, rstd = self._fold(W, bn, False, True, True, key=names[0])
         z, a, part, nblk = self.ops.dw_fwd_train(x, taps, scale, shift, k, s)
         return z, a, part, nblk, dict(x=x, W=W, taps_s=taps_s, mean=bn.running_mean, rstd=rstd, scale=scale, k=k, s=s, names=names,
                                       wshape=conv.weight.shape)
@@ -465,8 +587,9 @@ class TrainEngine(object):
     def _dw_bneval_bwd(self, rec, dz, grads, z_below=None):
         """z_below: pre-activation of the layer that produced this conv's input: d input is multiplied by silu'(z_below)"""
         k, s = rec['k'], rec['s']
-        dx, dtaps, _ = self.ops.dw_bwd(dz, rec['x'], rec['taps_s'], k, s, z=z_below)
-        self._convbn_grads(rec, dtaps._base, True, grads)
+        bufs = self._grad_bufs(rec, True)
+        dx, _, _ = self.ops.dw_bwd(dz, rec['x'], rec['taps_s'], k, s, z=z_below, out=bufs[0])
+        self._convbn_grads(rec, bufs, True, grads)
         return dx
 
     def _bn_fwd(self, c, bn, prefix, silu_out=False):
@@ -524,7 +647,8 @@ class TrainEngine(object):
         else:
             self.ops.gemm_nt(x, W, bias, M=B * H * Wd, a_map=(x.data_ptr(), 0, 0, 0), c_map=c_map)
             c = None
-        return c, dict(x=x, W=W, prefix=prefix, wshape=conv.weight.shape, has_bias=bias is not None)
+        Wt = self._transposed(prefix + 'weight^T', W) if self._stage is not None else None
+        return c, dict(x=x, W=W, Wt=Wt, prefix=prefix, wshape=conv.weight.shape, has_bias=bias is not None)
 
     def _pw_bwd(self, rec, dc, grads, y_map=None, need_dx=True):
         N, K = rec['W'].shape
@@ -536,7 +660,7 @@ class TrainEngine(object):
             self._acc(grads, rec['prefix'] + 'bias', dsum)
         if not need_dx:
             return None
-        Wt = rec['W'].t().contiguous()
+        Wt = rec['Wt'] if rec.get('Wt') is not None else rec['W'].t().contiguous()
         if y_map is None:
             return self.ops.gemm_nt(dc, Wt).view(B, H, Wd, K)
         return self.ops.gemm_nt(None, Wt, M=M, a_map=y_map).view(B, H, Wd, K)
@@ -545,7 +669,7 @@ class TrainEngine(object):
         """depthwise 3x3/s1 without BN (SeparableConv2d.conv_dw, efficientdet.py:66-69)"""
         C = conv.weight.shape[0]
         k = conv.weight.shape[-1]
-        taps = conv.weight.detach().permute(2, 3, 0, 1).reshape(k * k, C).contiguous()
+        taps = self._transposed(prefix + 'weight^T' if self._stage is not None else None, conv.weight.detach().reshape(C, k * k))
         d = self.ops.dw_fwd(x, taps, self._const(C, 1.0), self._const(C, 0.0), k, 1)
         return d, dict(x=x, taps=taps, k=k, prefix=prefix, wshape=conv.weight.shape)
 
@@ -559,12 +683,12 @@ class TrainEngine(object):
     # =============================================================================================
     # backbone
     # =============================================================================================
-    def _se_fwd(self, a, part, nblk, se, R):
+    def _se_fwd(self, a, part, nblk, se, R, prefix):
         """SqueezeExcite gate [B, C] from the depthwise kernel's pool partial rows (the multiply happens inside the project GEMM)"""
         B, H, W, C = a.shape
         W1 = se.conv_reduce.weight.detach().reshape(R, C).contiguous()
         b1 = se.conv_reduce.bias.detach().contiguous()
-        W2t = se.conv_expand.weight.detach().reshape(C, R).t().contiguous()
+        W2t = self._transposed(prefix + 'conv_expand.weight^T', se.conv_expand.weight.detach().reshape(C, R))
         b2 = se.conv_expand.bias.detach().contiguous()
         gate, pool = self.ops.new(B, C), self.ops.new(B, C)
         _lib.check(self.lib.effdet_train_se_gate(self.ops.st(), part.data_ptr(), nblk, H * W, W1.data_ptr(), b1.data_ptr(),
@@ -590,7 +714,48 @@ class TrainEngine(object):
         grads[prefix + 'conv_expand.bias'] = g[2 * R * C + R:]
         return self.ops.ew(12, dag, c=z, v=(gate, ds, None, None), s=(1.0 / (H * W), 0.0, 0.0, 0.0), hw=H * W)
 
+    # The stage functions proper.  Inside them `self._stage` names the stage, and the parameter-sized work (derived weights,
+    # conv + BN parameter gradients) goes through that stage's tables: one launch per kind (see _StageTables).
+    def _in_stage(self, stage, fn, *args, **kw):
+        self._stage = stage if self.use_tables else None
+        try:
+            return fn(*args, **kw)
+        finally:
+            self._stage = None
+
     def bb_forward(self, x):
+        """x: [B,3,H,W] float32 (normalised) or uint8 (raw; loader normalisation applied).  -> (feats NHWC list, saved)"""
+        def run():
+            if self.use_tables:
+                self._tables['bb'].run_prep()
+            return self._bb_forward(x)
+        return self._in_stage('bb', run)
+
+    def bb_backward(self, dfeats, saved):
+        """dfeats: d loss / d feature maps (NHWC, None allowed) -> {param name (relative to backbone): grad}"""
+        def run():
+            grads = self._bb_backward(dfeats, saved)
+            if self.use_tables:
+                self._tables['bb'].run_grads()
+            stem_c = self.model.backbone.arch[0]
+            g = grads['conv_stem.weight']                          # [C0, 32] patch layout -> [C0, 3, 3, 3]
+            grads['conv_stem.weight'] = g.reshape(stem_c, 32)[:, :27].reshape(stem_c, 3, 3, 3).permute(0, 3, 1, 2).contiguous()
+            return grads
+        return self._in_stage('bb', run)
+
+    def fh_forward(self, feats, want_cls=True, want_box=True):
+        """feats: backbone feature maps (NHWC).  -> (cls_all [B,N,C], box_all [B,N,4], saved)"""
+        def run():
+            if self.use_tables:
+                self._tables['fh'].run_prep()
+            return self._fh_forward(feats, want_cls, want_box)
+        return self._in_stage('fh', run)
+
+    def fh_backward(self, g_cls, g_box, saved, need_dfeats=True):
+        """-> (d feats list (NHWC), {param name: grad})"""
+        return self._in_stage('fh', self._fh_backward, g_cls, g_box, saved, need_dfeats)
+
+    def _bb_forward(self, x):
         """x: [B,3,H,W] float32 (normalised) or uint8 (raw; loader normalisation applied).  -> (feats NHWC list, saved)"""
         bb = self.model.backbone
         ops = self.ops
@@ -624,7 +789,8 @@ class TrainEngine(object):
         sc = _StemConv()
         w = bb.conv_stem.weight.detach().permute(0, 2, 3, 1).reshape(stem_c, 27)
         sc.weight = torch.cat([w, w.new_zeros(stem_c, 5)], 1)
-        (z0, cur), rec = self._pw_bneval_fwd(col, sc, bb.bn1, ('conv_stem.weight', 'bn1.weight', 'bn1.bias'), silu_out=True)
+        (z0, cur), rec = self._pw_bneval_fwd(col, sc, bb.bn1, ('conv_stem.weight', 'bn1.weight', 'bn1.bias'), silu_out=True,
+                                             table=False)       # its padded weight is a fresh tensor every step
         rec['wshape'] = (stem_c, 32)
         saved['stem'] = (rec, z0)
         feats = []
@@ -645,7 +811,7 @@ class TrainEngine(object):
                                                                       (p + 'conv_dw.weight', p + 'bn1.weight', p + 'bn1.bias'))
                     proj, bnp, pn = m.conv_pw, m.bn2, (p + 'conv_pw.weight', p + 'bn2.weight', p + 'bn2.bias')
                 r['z2'] = z2
-                gate, r['se'] = self._se_fwd(a2, part, nblk, m.se, b['se'])
+                gate, r['se'] = self._se_fwd(a2, part, nblk, m.se, b['se'], p + 'se.')
                 r['drop'] = None
                 dropped = b['residual'] and drop_rates is not None and drop_rates[flat_idx] > 0.0
                 # project conv: the SE gate multiplies its input while the GEMM loads it, the shortcut is added in its epilogue
@@ -666,7 +832,7 @@ class TrainEngine(object):
                 feats.append(cur)
         return feats, saved
 
-    def bb_backward(self, dfeats, saved):
+    def _bb_backward(self, dfeats, saved):
         """dfeats: d loss / d feature maps (NHWC, None allowed) -> {param name (relative to backbone): grad}"""
         ops = self.ops
         grads = {}
@@ -697,8 +863,6 @@ class TrainEngine(object):
         rec, z0 = saved['stem']
         dz0 = ops.silu_bwd(z0, dcur)
         self._pw_bneval_bwd(rec, dz0, grads, need_dx=False)
-        g = grads['conv_stem.weight']                              # [C0, 32] patch layout -> [C0, 3, 3, 3]
-        grads['conv_stem.weight'] = g[:, :27].reshape(stem_c, 3, 3, 3).permute(0, 3, 1, 2).contiguous()
         return grads
 
     # =============================================================================================
@@ -740,7 +904,7 @@ class TrainEngine(object):
             dy = self._convbn_bwd(rec['conv'], dy, grads)
         return dy
 
-    def fh_forward(self, feats, want_cls=True, want_box=True):
+    def _fh_forward(self, feats, want_cls=True, want_box=True):
         """feats: backbone feature maps (NHWC).  -> (cls_all [B,N,C], box_all [B,N,4], saved)"""
         model, ops, F, L = self.model, self.ops, self.F, self.L
         fpn = model.fpn
@@ -834,12 +998,11 @@ class TrainEngine(object):
         saved['P'] = P
         return outs[0], outs[1], saved
 
-    @staticmethod
-    def _dw_taps(conv):
+    def _dw_taps(self, conv, key):
         C, k = conv.weight.shape[0], conv.weight.shape[-1]
         if k != 3 or tuple(conv.stride) != (1, 1):
             raise NotImplementedError('head depthwise convs other than 3x3 / stride 1')
-        return conv.weight.detach().permute(2, 3, 0, 1).reshape(k * k, C).contiguous()
+        return self._transposed(key, conv.weight.detach().reshape(C, k * k))
 
     def _head_fwd(self, lv, t, head, hrec):
         """HeadNet.forward (efficientdet.py:438-452) over all levels at once: per repeat dw3x3 -> 1x1 conv (+bias) -> per-level
@@ -849,7 +1012,7 @@ class TrainEngine(object):
         hrec['reps'] = []
         for r in range(len(head.conv_rep)):
             conv = head.conv_rep[r]
-            taps = self._dw_taps(conv.conv_dw)
+            taps = self._dw_taps(conv.conv_dw, '%sconv_rep.%d.conv_dw.weight^T' % (name, r))
             d = ops.lv_dw(lv, t, taps)
             N = conv.conv_pw.weight.shape[0]
             W = conv.conv_pw.weight.detach().reshape(N, -1).contiguous()
@@ -863,17 +1026,19 @@ class TrainEngine(object):
             st = ops.lv_bn_finalize(lv, sums, sq, bns, N)                  # mean, scale, shift, rstd  [4, L, N]
             y, tn = ops.lv_ew(lv, 3, c, v=(st[1], st[2], None, None), silu_out=True)
             import ctypes
-            hrec['reps'].append(dict(x=t, taps=taps, d=d, W=W, c=c, y=y, st=st, has_bias=bias is not None, r=r,
+            hrec['reps'].append(dict(x=t, taps=taps, d=d, W=W, Wt=self._transposed('%sconv_rep.%d.conv_pw.weight^T' % (name, r), W),
+                                     c=c, y=y, st=st, has_bias=bias is not None, r=r,
                                      train=(ctypes.c_int * L)(*[int(bn.training) for bn in bns]),
                                      wshape=conv.conv_pw.weight.shape, dwshape=conv.conv_dw.weight.shape))
             t = tn
-        taps = self._dw_taps(head.predict.conv_dw)
+        taps = self._dw_taps(head.predict.conv_dw, name + 'predict.conv_dw.weight^T')
         d = ops.lv_dw(lv, t, taps)
         Wp = head.predict.conv_pw.weight.detach().reshape(NO, -1).contiguous()
         bias = None if head.predict.conv_pw.bias is None else head.predict.conv_pw.bias.detach().contiguous()
         pk = (lv.P * NO, NO)
         ops.gemm_nt_levels(lv, d, Wp, bias, out_packed=out_t, pk=pk)
-        hrec['predict'] = dict(x=t, taps=taps, d=d, W=Wp, has_bias=bias is not None, pk=pk,
+        hrec['predict'] = dict(x=t, taps=taps, d=d, W=Wp, Wt=self._transposed(name + 'predict.conv_pw.weight^T', Wp),
+                               has_bias=bias is not None, pk=pk,
                                wshape=head.predict.conv_pw.weight.shape, dwshape=head.predict.conv_dw.weight.shape)
 
     def _head_bwd(self, lv, hrec, g, grads):
@@ -893,7 +1058,7 @@ class TrainEngine(object):
         grads[name + 'predict.conv_pw.weight'] = dW.reshape(rec['wshape'])
         if rec['has_bias']:
             grads[name + 'predict.conv_pw.bias'] = dsum
-        dd = ops.gemm_nt_levels(lv, g, rec['W'].t().contiguous(), a_packed=True, pk=rec['pk'])
+        dd = ops.gemm_nt_levels(lv, g, rec['Wt'], a_packed=True, pk=rec['pk'])
         da = dw_grads(rec, dd, name + 'predict.')
         for rec in reversed(hrec['reps']):
             r, st = rec['r'], rec['st']
@@ -909,11 +1074,11 @@ class TrainEngine(object):
             grads['%sconv_rep.%d.conv_pw.weight' % (name, r)] = dW.reshape(rec['wshape'])
             if rec['has_bias']:
                 grads['%sconv_rep.%d.conv_pw.bias' % (name, r)] = dsum
-            dd = ops.gemm_nt(dc, rec['W'].t().contiguous())
+            dd = ops.gemm_nt(dc, rec['Wt'])
             da = dw_grads(rec, dd, '%sconv_rep.%d.' % (name, r))
         return da
 
-    def fh_backward(self, g_cls, g_box, saved, need_dfeats=True):
+    def _fh_backward(self, g_cls, g_box, saved, need_dfeats=True):
         """-> (d feats list (NHWC), {param name: grad})"""
         ops, L = self.ops, self.L
         grads = {}

@@ -62,10 +62,13 @@ def test_gemm_row_maps_packed_levels():
     _close(dx, gl @ W.double(), 1e-5, 'dX from packed dY')
 
 
-@pytest.mark.parametrize('M,N,K', [(5000, 64, 64), (70000, 96, 16), (333, 810, 64), (2048, 24, 144), (100, 8, 32)])
+@pytest.mark.parametrize('M,N,K', [(5000, 64, 64), (70000, 96, 16), (333, 810, 64), (2048, 24, 144), (100, 8, 32),
+                                   (68200, 64, 64)])           # 256 slices of 288 rows: the last 19 slices are empty
 def test_gemm_tn(M, N, K):
     ops = _ops()
     dY, X = _rnd(3, 'dY', (M, N)), _rnd(3, 'X', (M, K))
+    # the partial rows of EVERY slice must be written, the empty ones past the end of M too: poison the workspace first
+    ops.ws(ops.lib.effdet_train_gemm_tn_workspace_floats(M, N, K)).fill_(float('nan'))
     dW, dsum = ops.gemm_tn(dY.to(DEV), X.to(DEV), N, K)
     _close(dW, dY.double().t() @ X.double(), 3e-6 * math.sqrt(M), 'dW')
     _close(dsum, dY.double().sum(0), 3e-6 * math.sqrt(M), 'dsum')
