@@ -275,12 +275,13 @@ int effdet_train_gemm_tn(void* stream, const float* dY, long long y_rpi, long lo
 /* out[g][l] (+)= sum_s in[g][s][l], s ascending. */
 int effdet_train_reduce_mid(void* stream, const float* in, int G, int S, long long L, float* out, int accumulate);
 /* depthwise k x k (k = 3|5, stride 1|2, TF-SAME) backward: dX [B,H,W,C] from dY [B,Ho,Wo,C] and taps [k*k][C];
- * out [(k*k+1)][C] = tap gradients (rows 0..k*k-1) and sum of dY (last row). */
+ * out [(k*k+1)][C] = tap gradients (rows 0..k*k-1) and sum of dY (last row); cmajor != 0: the tap gradients in the
+ * parameter's layout [C][k*k], followed by the C sums. */
 int effdet_train_dwconv_bwd_dx(void* stream, const float* dY, const float* taps, float* dX,
                                int B, int H, int W, int C, int k, int stride);
 long long effdet_train_dwconv_bwd_dw_workspace_floats(int B, int H, int W, int C, int k, int stride);
 int effdet_train_dwconv_bwd_dw(void* stream, const float* dY, const float* X, float* out,
-                               int B, int H, int W, int C, int k, int stride, float* workspace, long long workspace_floats);
+                               int B, int H, int W, int C, int k, int stride, float* workspace, long long workspace_floats, int cmajor);
 /* Element-wise family over n floats (n, C multiples of 4; channel = i % C, image = i / (hw*C)):
  *  0 silu(a)   1 b*silu'(a)   2 a+b   3 a*v0[c]+v1[c] (v1 optional)   4 a*v0[img,c]   5 a*v0[img,c]+v1[img,c]*s0
  *  6 v0[c]*(a - v1[c] - (b - v2[c])*v3[c])  (batch-statistics BN backward)
@@ -331,12 +332,23 @@ int effdet_train_bn_finalize(void* stream, const float* mean, const float* var, 
                              float momentum, float unbias, float eps, float* scale, float* shift, float* rstd);
 int effdet_train_bn_bwd_prep(void* stream, const float* s1, const float* s2c, const float* rstd, int C, float inv_m,
                              float* dgamma, float* dbeta, float* v1, float* v3);
+/* The two halves above fused with the column reductions in front of them (one launch less per BatchNorm and direction):
+ * bn_var_finalize = effdet_train_col_reduce mode 2 over a [R][C] with the batch mean, then finalize in training mode;
+ * bn_bwd_sums     = effdet_train_col_reduce mode 4 (sum dy, sum dy (c - mean)), then bwd_prep -> out [4][C] = d gamma, d beta, v1, v3.
+ * workspace: effdet_train_col_reduce_workspace_floats(1, R, C) floats. */
+int effdet_train_bn_var_finalize(void* stream, const float* a, const float* mean, long long R, int C, const float* gamma,
+                                 const float* beta, float* running_mean, float* running_var, long long* num_batches_tracked,
+                                 float momentum, float unbias, float eps, float* scale, float* shift, float* rstd,
+                                 float* workspace, long long workspace_floats);
+int effdet_train_bn_bwd_sums(void* stream, const float* dy, const float* c, const float* mean, const float* rstd,
+                             long long R, int C, float* out, float* workspace, long long workspace_floats);
 
 /* Table-driven forms of effdet_train_fold_bn / plain transposes and of effdet_train_convbn_grads: one launch for all convs of
  * a stage.  `table` = n records in DEVICE memory:
  *   prep  { int kind, rows, cols; float eps; const float *src, *gamma, *beta, *mean, *var; float *dst0, *dst1, *dst2, *scale,
  *           *shift, *rstd; }   kind 0: dst0 [cols][rows] = src [rows][cols] transposed; kind 1: fold_bn with W = src [N = rows][K = cols],
- *           dst0 = Wf, dst1 = WfT, dst2 = WT (each optional)
+ *           dst0 = Wf, dst1 = WfT, dst2 = WT (each optional); kind 2: effdet_train_fpn_weights with src = edge_weights [rows],
+ *           method = (int) eps ('fastattn' 0 | 'attn' 1), dst0 = {w0, w1, w2, den}
  *   grads { const float *dWext, *W, *scale, *rstd, *mean; float *dW, *dgamma, *dbeta; int N, K, transposed, pad; } */
 int effdet_train_prep_table(void* stream, const void* table, int n, long long max_elems);
 int effdet_train_grads_table(void* stream, const void* table, int n, int max_n);
@@ -370,7 +382,7 @@ int effdet_train_dwconv_bwd_dx_silu(void* stream, const float* dY, const float* 
  * other; C2 needs a dense C).  Reductions are two-stage in a fixed order (bitwise reproducible); `workspace`:
  * effdet_train_levels_workspace_floats floats.
  *   levels_dw          depthwise 3x3 / s1 / TF-SAME, taps [9][C]; flip != 0: taps mirrored = gradient w.r.t. the input
- *   levels_dw_bwd_dw   out [9][C] = gradient of the (shared) taps, summed over all levels
+ *   levels_dw_bwd_dw   out [9][C] (cmajor != 0: [C][9], the parameter's layout) = gradient of the (shared) taps, summed over all levels
  *   levels_col_reduce  out [L][C] (mode 0: sum a; mode 2: sum (a - v[l][c] * vscale[l])^2) or [L][2][C] (mode 4: sum a',
  *                      sum a' (b - v[l][c]), a' = a * silu'(pre) when pre is given - the SiLU backward of the layer above)
  *   levels_bn_finalize nn.BatchNorm2d bookkeeping of the L layers (pointer tables of their parameters / buffers; train[l] != 0:
@@ -389,7 +401,8 @@ long long effdet_train_levels_workspace_floats(int B, int L, const int* Hs, cons
 int effdet_train_levels_dw(void* stream, const float* X, const float* taps, float* Y, int B, int L, const int* Hs,
                            const int* Ws, int C, int flip);
 int effdet_train_levels_dw_bwd_dw(void* stream, const float* dY, const float* X, float* out, int B, int L,
-                                  const int* Hs, const int* Ws, int C, float* workspace, long long workspace_floats);
+                                  const int* Hs, const int* Ws, int C, float* workspace, long long workspace_floats,
+                                  int cmajor);
 int effdet_train_levels_col_reduce(void* stream, int mode, const float* a, const float* b, const float* v,
                                    const float* pre, const float* vscale, int B, int L, const int* Hs, const int* Ws, int C,
                                    float* out, float* workspace, long long workspace_floats);

@@ -97,7 +97,7 @@ SIGNATURES = {
     'effdet_train_dwconv_bwd_dx': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
     'effdet_train_dwconv_bwd_dw_workspace_floats': (c_ll, [c_int, c_int, c_int, c_int, c_int, c_int]),
     'effdet_train_dwconv_bwd_dw': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                                           c_void_p, c_ll]),
+                                           c_void_p, c_ll, c_int]),
     'effdet_train_ew': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_float, c_float, c_float, c_float, c_ll, c_int, c_ll, c_void_p, c_void_p]),
     'effdet_train_col_reduce_workspace_floats': (c_ll, [c_int, c_ll, c_int]),
@@ -124,7 +124,7 @@ SIGNATURES = {
     'effdet_train_levels_workspace_floats': (c_ll, [c_int, c_int, P(c_int), P(c_int), c_int]),
     'effdet_train_levels_dw': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, P(c_int), P(c_int), c_int, c_int]),
     'effdet_train_levels_dw_bwd_dw': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, P(c_int), P(c_int), c_int,
-                                              c_void_p, c_ll]),
+                                              c_void_p, c_ll, c_int]),
     'effdet_train_levels_col_reduce': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, P(c_float), c_int, c_int,
                                                P(c_int), P(c_int), c_int, c_void_p, c_void_p, c_ll]),
     'effdet_train_levels_bn_finalize': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, P(c_void_p), P(c_void_p), P(c_void_p),
@@ -153,6 +153,9 @@ SIGNATURES = {
     'effdet_train_dwconv_bwd_dx_silu': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
     'effdet_train_prep_table': (c_int, [c_void_p, c_void_p, c_int, c_ll]),
     'effdet_train_grads_table': (c_int, [c_void_p, c_void_p, c_int, c_int]),
+    'effdet_train_bn_var_finalize': (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_ll]),
+    'effdet_train_bn_bwd_sums': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_ll]),
     'effdet_gather_ood': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_int, c_int, c_int,
                                   c_void_p, c_void_p, c_void_p]),
 }

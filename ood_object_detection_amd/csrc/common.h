@@ -198,6 +198,9 @@ __attribute__((visibility("hidden"))) int effdet_stem_roll_launch(hipStream_t st
 // train_net.hip (internal): out[g][l] (+)= alpha * sum_s in[g][s][l], summed in a fixed order
 __attribute__((visibility("hidden"))) int effdet_launch_reduce_mid(hipStream_t st, const float* in, int G, int S, long long L, float* out,
                                                                    int accumulate, float alpha);
+// the same; the leading [trT][trC] matrix of every row is written transposed ([trC][trT]), what follows it keeps its place
+__attribute__((visibility("hidden"))) int effdet_launch_reduce_mid_tr(hipStream_t st, const float* in, int G, int S, long long L, float* out,
+                                                                      int accumulate, float alpha, int trC, int trT);
 
 // TF "SAME" padding: amount in front (reference semantics live in timm)
 static inline int same_pad_before(int size, int k, int s) {

@@ -330,7 +330,8 @@ extern "C" long long effdet_train_levels_workspace_floats(int B, int L, const in
 }
 
 extern "C" int effdet_train_levels_dw_bwd_dw(void* stream, const float* dY, const float* X, float* out, int B, int L,
-                                             const int* Hs, const int* Ws, int C, float* workspace, long long workspace_floats) {
+                                             const int* Hs, const int* Ws, int C, float* workspace, long long workspace_floats,
+                                             int cmajor) {
     EFFDET_ENTER();
     LvDwWArgs p;
     if (!dY || !X || !out || !workspace || C <= 0 || C % 4 || fill_levels(p.lv, B, L, Hs, Ws)) return EFFDET_EINVAL;
@@ -342,7 +343,7 @@ extern "C" int effdet_train_levels_dw_bwd_dw(void* stream, const float* dY, cons
     hipLaunchKernelGGL(lv_dw_bwd_dw_kernel, dim3((unsigned)chunks, (unsigned)((C + 63) / 64)), dim3(256), 0, st, p);
     const int rc = effdet_check_launch();
     if (rc) return rc;
-    return effdet_launch_reduce_mid(st, workspace, 1, (int)chunks, 9LL * C, out, 0, 1.0f);
+    return effdet_launch_reduce_mid_tr(st, workspace, 1, (int)chunks, 9LL * C, out, 0, 1.0f, cmajor ? C : 0, 9);
 }
 
 extern "C" int effdet_train_levels_col_reduce(void* stream, int mode, const float* a, const float* b, const float* v,

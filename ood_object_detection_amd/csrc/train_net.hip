@@ -459,7 +459,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel_v(GemmTnArgs p) {
 }
 
 // out[g][l] (+)= sum_s in[g][s][l] in index order
-struct ReduceMidArgs { const float* in; float* out; long long L; int G, S, accumulate; float alpha; };
+// trC > 0: the first trC * trT entries of a row are a [trT][trC] matrix that is written transposed, [trC][trT] (depthwise tap
+// gradients [k*k][C] -> the parameter's [C][k*k]); entries behind it keep their place
+struct ReduceMidArgs { const float* in; float* out; long long L; int G, S, accumulate; float alpha; int trC, trT; };
 __global__ __launch_bounds__(256) void reduce_mid_kernel(ReduceMidArgs p) {
     // 16 consecutive l per workgroup x 16 lanes over s: lane j sums s = j, j+16, ... in order, then the 16 lane sums are
     // added in lane order - a fixed association, so the result is bitwise reproducible
@@ -484,9 +486,60 @@ __global__ __launch_bounds__(256) void reduce_mid_kernel(ReduceMidArgs p) {
         float t = 0.f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) t += sm[j][li];
-        float* dst = p.out + (long long)gi * p.L + l;
+        long long o = l;
+        if (p.trC > 0 && l < (long long)p.trC * p.trT) { const long long tt = l / p.trC; o = (l - tt * p.trC) * p.trT + tt; }
+        float* dst = p.out + (long long)gi * p.L + o;
         t *= p.alpha;
         *dst = p.accumulate ? *dst + t : t;
+    }
+}
+
+// Second stage of a BatchNorm column reduction with the layer's bookkeeping in the same launch (one launch less per BN):
+//   kind 0 (forward, after the centred second pass): var[c] = alpha * sum_s partial[s][c], then effdet_train_bn_finalize's
+//           arithmetic (running statistics, rstd, scale, shift) with the batch mean given;
+//   kind 1 (backward, partial rows [2][C] = {sum dy, sum dy (c - mean)}): effdet_train_bn_bwd_prep's d gamma, d beta, v1, v3.
+// Same fixed summation order as reduce_mid_kernel (16 lanes over s, lane sums added in lane order).
+struct ReduceBnArgs {
+    const float* in; int S, C, kind; float alpha;
+    const float* mean; const float* gamma; const float* beta; float* running_mean; float* running_var; long long* nbt;
+    float momentum, unbias, eps; float* scale; float* shift; float* rstd_out;
+    const float* rstd_in; float invM; float* dgamma; float* dbeta; float* v1; float* v3;
+};
+__global__ __launch_bounds__(256) void reduce_bn_kernel(ReduceBnArgs p) {
+    __shared__ float sm[2][16][17];
+    const int li = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + li;
+    const int W = p.kind == 1 ? 2 : 1;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < p.C) {
+        for (int i = sl; i < p.S; i += 16) {
+            s0 += p.in[((long long)i * W) * p.C + c];
+            if (W == 2) s1 += p.in[((long long)i * W + 1) * p.C + c];
+        }
+    }
+    sm[0][sl][li] = s0;
+    sm[1][sl][li] = s1;
+    __syncthreads();
+    if (sl != 0 || c >= p.C) return;
+    float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { t0 += sm[0][j][li]; t1 += sm[1][j][li]; }
+    if (p.kind == 0) {
+        if (c == 0 && p.nbt) *p.nbt += 1;
+        const float m = p.mean[c], v = t0 * p.alpha;
+        p.running_mean[c] = p.running_mean[c] * (1.0f - p.momentum) + p.momentum * m;
+        p.running_var[c] = p.running_var[c] * (1.0f - p.momentum) + p.momentum * (v * p.unbias);
+        const float rs = 1.0f / sqrtf(v + p.eps);
+        const float sc = p.gamma[c] * rs;
+        p.rstd_out[c] = rs;
+        p.scale[c] = sc;
+        p.shift[c] = p.beta[c] - m * sc;
+    } else {
+        const float rs = p.rstd_in[c];
+        p.dgamma[c] = t1 * rs;
+        p.dbeta[c] = t0;
+        p.v1[c] = t0 * p.invM;
+        p.v3[c] = rs * rs * t1 * p.invM;
     }
 }
 
@@ -523,12 +576,16 @@ __global__ __launch_bounds__(256) void reduce_split_kernel(ReduceSplitArgs p) {
 
 }  // namespace
 // out[g][l] (+)= alpha * sum_s in[g][s][l] in fixed order (declared in common.h: the second stage of every two-stage reduction)
-int effdet_launch_reduce_mid(hipStream_t st, const float* in, int G, int S, long long L, float* out, int accumulate, float alpha) {
-    ReduceMidArgs a{in, out, L, G, S, accumulate, alpha};
+int effdet_launch_reduce_mid_tr(hipStream_t st, const float* in, int G, int S, long long L, float* out, int accumulate, float alpha,
+                                int trC, int trT) {
+    ReduceMidArgs a{in, out, L, G, S, accumulate, alpha, trC, trT};
     const long long blocks = (L + 15) / 16;
     if (blocks > 0x7fffffffLL || G > 65535) return EFFDET_EINVAL;
     hipLaunchKernelGGL(reduce_mid_kernel, dim3((unsigned)blocks, (unsigned)G), dim3(256), 0, st, a);
     return effdet_check_launch();
+}
+int effdet_launch_reduce_mid(hipStream_t st, const float* in, int G, int S, long long L, float* out, int accumulate, float alpha) {
+    return effdet_launch_reduce_mid_tr(st, in, G, S, L, out, accumulate, alpha, 0, 0);
 }
 namespace {
 inline int launch_reduce_mid(hipStream_t st, const float* in, int G, int S, long long L, float* out, int accumulate, float alpha = 1.0f) {
@@ -873,6 +930,10 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] *= silu_grad(z[j]);
         break; }
+    case 13: {                                          // stochastic depth + shortcut: a * v0[img, c] + b
+        const long long img = i / p.hwC;
+        o = a * *reinterpret_cast<const f32x4*>(p.v0 + img * p.C + ch) + *reinterpret_cast<const f32x4*>(p.b + i);
+        break; }
     default:                                            // 9: weighted sum without the division ('attn' / 'sum')
     {
         const f32x4 b = *reinterpret_cast<const f32x4*>(p.b + i);
@@ -1191,7 +1252,7 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(BnBwdArgs p) {
 // Table-driven forms of the parameter-sized helpers: ONE launch for every conv of a stage instead of one per conv.
 // ------------------------------------------------------------------------------------------------------------
 struct PrepOp {                                 // mirrored by train_engine._PrepOp (ctypes)
-    int kind, rows, cols; float eps;            // kind 0: transpose src [rows][cols] -> dst0 [cols][rows]; 1: fold_bn (rows = N, cols = K)
+    int kind, rows, cols; float eps;            // kind 0: transpose src [rows][cols] -> dst0 [cols][rows]; 1: fold_bn (rows = N, cols = K); 2: BiFPN edge weights
     const float* src; const float* gamma; const float* beta; const float* mean; const float* var;
     float* dst0; float* dst1; float* dst2; float* scale; float* shift; float* rstd;      // fold: Wf, WfT, WT (each optional)
 };
@@ -1200,6 +1261,25 @@ __global__ __launch_bounds__(256) void prep_table_kernel(const PrepOp* ops, int 
     const long long total = (long long)p.rows * p.cols;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         const int r = (int)(e / p.cols), c = (int)(e - (long long)r * p.cols);
+        if (p.kind == 2) {                                   // BiFPN edge weights (rows = n inputs, cols = 1, eps = method): dst0 = {w0, w1, w2, den}
+            if (e != 0) break;
+            const int method = (int)p.eps;
+            float w[3] = {0.f, 0.f, 0.f};
+            float den = 1.0f;
+            if (method == 0) {
+                float sum = 0.f;
+                for (int i = 0; i < p.rows; ++i) { w[i] = fmaxf(p.src[i], 0.f); sum += w[i]; }
+                den = sum + 0.0001f;
+            } else if (method == 1) {
+                float m = p.src[0];
+                for (int i = 1; i < p.rows; ++i) m = fmaxf(m, p.src[i]);
+                float sum = 0.f;
+                for (int i = 0; i < p.rows; ++i) { w[i] = expf(p.src[i] - m); sum += w[i]; }
+                for (int i = 0; i < p.rows; ++i) w[i] = w[i] / sum;
+            }
+            p.dst0[0] = w[0]; p.dst0[1] = w[1]; p.dst0[2] = w[2]; p.dst0[3] = den;
+            break;
+        }
         const float w = p.src[e];
         if (p.kind == 0) { p.dst0[(long long)c * p.rows + r] = w; continue; }
         const float rs = 1.0f / sqrtf(p.var[r] + p.eps);
@@ -1546,7 +1626,8 @@ extern "C" long long effdet_train_dwconv_bwd_dw_workspace_floats(int B, int H, i
 }
 
 extern "C" int effdet_train_dwconv_bwd_dw(void* stream, const float* dY, const float* X, float* out,
-                                          int B, int H, int W, int C, int k, int stride, float* workspace, long long workspace_floats) {
+                                          int B, int H, int W, int C, int k, int stride, float* workspace, long long workspace_floats,
+                                          int cmajor) {
     EFFDET_ENTER();
     DwBwdArgs a;
     if (!dY || !X || !out || !workspace || dw_fill(a, B, H, W, C, k, stride)) return EFFDET_EINVAL;
@@ -1563,21 +1644,21 @@ extern "C" int effdet_train_dwconv_bwd_dw(void* stream, const float* dY, const f
     else hipLaunchKernelGGL((dw_bwd_dw_kernel<5, 2>), grid, dim3(256), 0, st, a);
     int rc = effdet_check_launch();
     if (rc) return rc;
-    return launch_reduce_mid(st, workspace, 1, (int)chunks, (long long)(k * k + 1) * C, out, 0);
+    return effdet_launch_reduce_mid_tr(st, workspace, 1, (int)chunks, (long long)(k * k + 1) * C, out, 0, 1.0f, cmajor ? C : 0, k * k);
 }
 
 extern "C" int effdet_train_ew(void* stream, int op, float* out, const float* a, const float* b, const float* c,
                                const float* v0, const float* v1, const float* v2, const float* v3,
                                float s0, float s1, float s2, float s3, long long n, int C, long long hw, const float* sdev, float* out2) {
     EFFDET_ENTER();
-    if (!out || !a || n <= 0 || n % 4 || C <= 0 || C % 4 || op < 0 || op > 12) return EFFDET_EINVAL;
-    const bool need_b = op == 1 || op == 2 || op == 6 || op == 7 || op == 9 || op == 10 || op == 11;
+    if (!out || !a || n <= 0 || n % 4 || C <= 0 || C % 4 || op < 0 || op > 13) return EFFDET_EINVAL;
+    const bool need_b = op == 1 || op == 2 || op == 6 || op == 7 || op == 9 || op == 10 || op == 11 || op == 13;
     if (need_b && !b) return EFFDET_EINVAL;
     if ((op == 11 || op == 12) && !c) return EFFDET_EINVAL;
-    if ((op == 3 || op == 4 || op == 5 || op == 6 || op == 12) && !v0) return EFFDET_EINVAL;
+    if ((op == 3 || op == 4 || op == 5 || op == 6 || op == 12 || op == 13) && !v0) return EFFDET_EINVAL;
     if ((op == 5 || op == 6 || op == 12) && !v1) return EFFDET_EINVAL;
     if (op == 6 && (!v2 || !v3)) return EFFDET_EINVAL;
-    if ((op == 4 || op == 5 || op == 12) && hw <= 0) return EFFDET_EINVAL;
+    if ((op == 4 || op == 5 || op == 12 || op == 13) && hw <= 0) return EFFDET_EINVAL;
     if (op == 7 && s3 == 0.f && !sdev) return EFFDET_EINVAL;
     EwArgs p{op, out, a, b, c, v0, v1, v2, v3, s0, s1, s2, s3, n, C, (hw > 0 ? hw : 1) * C, sdev, out2};
     const long long blocks = (n / 4 + 255) / 256;
@@ -1623,6 +1704,58 @@ extern "C" int effdet_train_col_reduce(void* stream, int mode, const float* a, c
     int rc = effdet_check_launch();
     if (rc) return rc;
     return launch_reduce_mid(st, workspace, G, S, (long long)C * Wd, out, 0, alpha);
+}
+
+// BatchNorm (batch statistics) forward, second half: var = mean((a - mean)^2) over the R rows and the layer's bookkeeping
+// (effdet_train_col_reduce mode 2 + effdet_train_bn_finalize in two launches instead of three); mean [C] = the batch mean
+extern "C" int effdet_train_bn_var_finalize(void* stream, const float* a, const float* mean, long long R, int C, const float* gamma,
+                                            const float* beta, float* running_mean, float* running_var, long long* num_batches_tracked,
+                                            float momentum, float unbias, float eps, float* scale, float* shift, float* rstd,
+                                            float* workspace, long long workspace_floats) {
+    EFFDET_ENTER();
+    if (!a || !mean || !gamma || !beta || !running_mean || !running_var || !scale || !shift || !rstd || !workspace || R <= 0 || C <= 0)
+        return EFFDET_EINVAL;
+    long long rps;
+    const int S = col_slices(1, R, C, &rps);
+    if (workspace_floats < (long long)S * C) return EFFDET_EINVAL;
+    ColArgs p{2, a, nullptr, mean, workspace, R, rps, C, S};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool vec = C % 4 == 0 && reinterpret_cast<uintptr_t>(a) % 16 == 0;
+    const dim3 grid((unsigned)S, (unsigned)((C + 63) / 64), 1);
+    if (vec) hipLaunchKernelGGL(col_reduce_kernel<4>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(col_reduce_kernel<1>, grid, dim3(256), 0, st, p);
+    int rc = effdet_check_launch();
+    if (rc) return rc;
+    ReduceBnArgs q{};
+    q.in = workspace; q.S = S; q.C = C; q.kind = 0; q.alpha = 1.0f / (float)R;
+    q.mean = mean; q.gamma = gamma; q.beta = beta; q.running_mean = running_mean; q.running_var = running_var; q.nbt = num_batches_tracked;
+    q.momentum = momentum; q.unbias = unbias; q.eps = eps; q.scale = scale; q.shift = shift; q.rstd_out = rstd;
+    hipLaunchKernelGGL(reduce_bn_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, st, q);
+    return effdet_check_launch();
+}
+
+// BatchNorm backward, first half: sums of dy and dy (c - mean) over the R rows, then d gamma, d beta, v1, v3 (out [4][C]):
+// effdet_train_col_reduce mode 4 + effdet_train_bn_bwd_prep in two launches instead of three
+extern "C" int effdet_train_bn_bwd_sums(void* stream, const float* dy, const float* c, const float* mean, const float* rstd,
+                                        long long R, int C, float* out, float* workspace, long long workspace_floats) {
+    EFFDET_ENTER();
+    if (!dy || !c || !mean || !rstd || !out || !workspace || R <= 0 || C <= 0) return EFFDET_EINVAL;
+    long long rps;
+    const int S = col_slices(1, R, C, &rps);
+    if (workspace_floats < (long long)S * C * 2) return EFFDET_EINVAL;
+    ColArgs p{4, dy, c, mean, workspace, R, rps, C, S};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool vec = C % 4 == 0 && reinterpret_cast<uintptr_t>(dy) % 16 == 0 && reinterpret_cast<uintptr_t>(c) % 16 == 0;
+    const dim3 grid((unsigned)S, (unsigned)((C + 63) / 64), 1);
+    if (vec) hipLaunchKernelGGL(col_reduce_kernel<4>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(col_reduce_kernel<1>, grid, dim3(256), 0, st, p);
+    int rc = effdet_check_launch();
+    if (rc) return rc;
+    ReduceBnArgs q{};
+    q.in = workspace; q.S = S; q.C = C; q.kind = 1; q.rstd_in = rstd; q.invM = 1.0f / (float)R;
+    q.dgamma = out; q.dbeta = out + C; q.v1 = out + 2LL * C; q.v3 = out + 3LL * C;
+    hipLaunchKernelGGL(reduce_bn_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, st, q);
+    return effdet_check_launch();
 }
 
 extern "C" int effdet_train_spatial(void* stream, int op, const float* in, const float* aux, float* out,

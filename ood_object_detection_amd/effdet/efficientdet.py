@@ -27,6 +27,19 @@ def _no_forward(self, *a, **k):
                        'EfficientDet.forward(..., mode=...)' % type(self).__name__)
 
 
+_REGISTRATIONS = [0]              # parameter / buffer / sub-module registrations anywhere in the process (weights_token)
+
+
+def _count_registration(*_args):
+    _REGISTRATIONS[0] += 1
+    return None
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_count_registration)
+torch.nn.modules.module.register_module_buffer_registration_hook(_count_registration)
+torch.nn.modules.module.register_module_module_registration_hook(_count_registration)
+
+
 class _Holder(nn.Module):
     forward = _no_forward
 
@@ -325,12 +338,15 @@ class EfficientDet(nn.Module):
         pred = getattr(self.class_net, 'predict', None)
         mods = (id(self.backbone), id(self.fpn), id(self.class_net), id(self.box_net), id(getattr(pred, 'conv_pw', None)))
         c = self._wver[1]
-        if c is None or c[0] != mods or c[2] != self._wver[0]:
-            c = self._wver[1] = (mods, list(self.parameters()) + list(self.buffers()), self._wver[0])
+        # the cached tensor list is rebuilt when ANY module of the process registered a parameter, buffer or sub-module since it
+        # was made (`m.weight = nn.Parameter(...)`, `m.conv = nn.Conv2d(...)`: _REGISTRATIONS counts those through torch's global
+        # registration hooks) - a replaced Parameter object would otherwise leave its predecessor in the list
+        if c is None or c[0] != mods or c[2] != self._wver[0] or c[3] != _REGISTRATIONS[0]:
+            c = self._wver[1] = (mods, list(self.parameters()) + list(self.buffers()), self._wver[0], _REGISTRATIONS[0])
         v = 0
         for t in c[1]:
             v += t._version
-        return (self._wver[0], mods, v)
+        return (self._wver[0], mods, v, c[3])
 
     def prepare(self, batch_size, image_size=None, ood_out=None):
         """Fold BN, repack weights to the kernel layouts and build the launch plan."""

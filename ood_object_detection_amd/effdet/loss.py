@@ -20,8 +20,10 @@ class _DetectionLossFn(torch.autograd.Function):
         lib = _lib.load()
         if cls_all.device.type != 'cuda':
             raise RuntimeError('DetectionLoss runs on the GPU only (no CPU fallback)')
+        ctx.in_dtypes = (cls_all.dtype, box_all.dtype)
         if cls_all.dtype == torch.bfloat16 and box_all.dtype == torch.float32:
-            box_all = box_all.to(torch.bfloat16)             # a bf16 inference model writes float32 box regressions (engine.py)
+            cls_all = cls_all.float()                        # a bf16 inference model writes float32 box regressions (engine.py):
+                                                             # the loss runs on the float32 kernel, the boxes keep their precision
         if cls_all.dtype != box_all.dtype or cls_all.dtype not in (torch.float32, torch.bfloat16):
             raise RuntimeError('head outputs must both be float32 or bfloat16')
         B, N, C = cls_all.shape
@@ -46,7 +48,8 @@ class _DetectionLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, _g_parts):
         g_cls, g_box = ctx.saved_tensors
-        return (g_cls * g_total.to(g_cls.dtype), g_box * g_total.to(g_box.dtype), None, None, None, None, None, None, None)
+        return ((g_cls * g_total.to(g_cls.dtype)).to(ctx.in_dtypes[0]), (g_box * g_total.to(g_box.dtype)).to(ctx.in_dtypes[1]),
+                None, None, None, None, None, None, None)
 
 
 def _pack(outs, width):

@@ -251,7 +251,7 @@ class DwBwdDw(torch.autograd.Function):
         ws = o.ws(n)
         out = o.new(10, C)
         _lib.check(o.lib.effdet_train_dwconv_bwd_dw(o.st(), G.data_ptr(), X.data_ptr(), out.data_ptr(), B, H, W, C, 3, 1,
-                                                    ws.data_ptr(), ws.numel()), 'effdet_train_dwconv_bwd_dw')
+                                                    ws.data_ptr(), ws.numel(), 0), 'effdet_train_dwconv_bwd_dw')
         return out[:9].clone()
 
     @staticmethod

@@ -73,6 +73,18 @@ class _StageTables(object):
         self.prep[key] = (op, (dst, src2d))
         return dst
 
+    def edge_weights(self, key, ewp, n, method, compute):
+        """-> persistent {w0, w1, w2, den} of a BiFPN node's edge_weights parameter ('fastattn' / 'attn')"""
+        if key in self.prep:
+            self._check_src(self.prep[key], ewp)
+            return self.prep[key][1][0]
+        if self.frozen:
+            raise RuntimeError('unrecorded derived weight %r' % (key,))
+        wdev = compute()
+        op = _PrepOp(2, n, 1, float(method), ewp.data_ptr(), None, None, None, None, wdev.data_ptr(), None, None, None, None, None)
+        self.prep[key] = (op, (wdev, ewp))
+        return wdev
+
     def fold(self, key, W, bn, want_wf, want_wft, want_wt, compute):
         if key in self.prep:
             self._check_src(self.prep[key], W)
@@ -253,7 +265,7 @@ class _Ops(object):
                                                         out.data_ptr(), ws.data_ptr(), ws.numel()), 'effdet_train_gemm_tn_scaled')
         return out[:N * K].view(N, K), out[N * K:]
 
-    def dw_bwd(self, dy, x, taps, k, s, z=None, out=None):
+    def dw_bwd(self, dy, x, taps, k, s, z=None, out=None, cmajor=False):
         """-> dx, dtaps [k*k, C], dsum [C]   (taps already carry any folded BN scale); z: dx is multiplied by silu'(z)"""
         B, H, W, C = x.shape
         dx = self.new(B, H, W, C)
@@ -267,7 +279,9 @@ class _Ops(object):
         ws = self.ws(n)
         out = self.new(k * k + 1, C) if out is None else out.view(k * k + 1, C)
         _lib.check(self.lib.effdet_train_dwconv_bwd_dw(self.st(), dy.data_ptr(), x.data_ptr(), out.data_ptr(), B, H, W, C, k, s,
-                                                       ws.data_ptr(), ws.numel()), 'effdet_train_dwconv_bwd_dw')
+                                                       ws.data_ptr(), ws.numel(), int(cmajor)), 'effdet_train_dwconv_bwd_dw')
+        if cmajor:                                   # tap gradients in the parameter's [C, k*k] layout
+            return dx, out.view(-1)[:k * k * C].view(C, k * k), out[k * k]
         return dx, out[:k * k], out[k * k]
 
     # ---- element-wise ---------------------------------------------------------------------------
@@ -336,12 +350,13 @@ class _Ops(object):
                                                    C, int(flip)), 'effdet_train_levels_dw')
         return y
 
-    def lv_dw_bwd_dw(self, lv, dy, x):
+    def lv_dw_bwd_dw(self, lv, dy, x, cmajor=False):
+        """-> tap gradients [9, C] (cmajor: [C, 9], the parameter's layout)"""
         C = x.shape[-1]
         ws = self.lv_ws(lv, C)
-        out = self.new(9, C)
+        out = self.new(C, 9) if cmajor else self.new(9, C)
         _lib.check(self.lib.effdet_train_levels_dw_bwd_dw(self.st(), dy.data_ptr(), x.data_ptr(), out.data_ptr(), lv.B, lv.L, lv.Hs,
-                                                          lv.Ws, C, ws.data_ptr(), ws.numel()), 'effdet_train_levels_dw_bwd_dw')
+                                                          lv.Ws, C, ws.data_ptr(), ws.numel(), int(cmajor)), 'effdet_train_levels_dw_bwd_dw')
         return out
 
     def lv_col_reduce(self, lv, mode, a, b=None, v=None, pre=None, vscale=None):
@@ -598,18 +613,24 @@ class TrainEngine(object):
         C = c.shape[-1]
         M = c.numel() // C
         ops = self.ops
-        if bn.training:
-            mean = ops.col_reduce(0, c, alpha=1.0 / M)
-            var = ops.col_reduce(2, c, v=mean, alpha=1.0 / M)
-        else:
-            mean, var = bn.running_mean, bn.running_var
         vec = ops.new(3, C)
         mom = bn.momentum if bn.momentum is not None else 0.1
-        _lib.check(self.lib.effdet_train_bn_finalize(ops.st(), mean.data_ptr(), var.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
-                                                     bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
-                                                     bn.num_batches_tracked.data_ptr(), C, int(bn.training), float(mom),
-                                                     float(M / max(M - 1, 1)), float(bn.eps), vec[0].data_ptr(), vec[1].data_ptr(),
-                                                     vec[2].data_ptr()), 'effdet_train_bn_finalize')
+        if bn.training:
+            # batch mean, then the centred second pass whose second stage also does the layer's bookkeeping
+            mean = ops.col_reduce(0, c, alpha=1.0 / M)
+            ws = ops.ws(self.lib.effdet_train_col_reduce_workspace_floats(1, M, C))
+            _lib.check(self.lib.effdet_train_bn_var_finalize(ops.st(), c.data_ptr(), mean.data_ptr(), M, C, bn.weight.data_ptr(),
+                                                             bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                                             bn.num_batches_tracked.data_ptr(), float(mom), float(M / max(M - 1, 1)),
+                                                             float(bn.eps), vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(),
+                                                             ws.data_ptr(), ws.numel()), 'effdet_train_bn_var_finalize')
+        else:
+            mean, var = bn.running_mean, bn.running_var
+            _lib.check(self.lib.effdet_train_bn_finalize(ops.st(), mean.data_ptr(), var.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                                         bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                                         bn.num_batches_tracked.data_ptr(), C, 0, float(mom),
+                                                         float(M / max(M - 1, 1)), float(bn.eps), vec[0].data_ptr(), vec[1].data_ptr(),
+                                                         vec[2].data_ptr()), 'effdet_train_bn_finalize')
         scale, shift, rstd = vec[0], vec[1], vec[2]
         y = ops.ew(3, c, v=(scale, shift, None, None), silu_out=silu_out)
         if not bn.training:
@@ -620,12 +641,12 @@ class TrainEngine(object):
         c, mean, rstd = rec['c'], rec['mean'], rec['rstd']
         ops = self.ops
         C = c.shape[-1]
-        both = ops.col_reduce(4, dy, c, v=mean)                # [2, C]: sum(dy), sum(dy * (c - mean)) in one pass over dy
-        s1, s2c = both[0], both[1]
+        # sum(dy), sum(dy * (c - mean)) in one pass over dy; its second stage turns them into d gamma, d beta, v1, v3
         out = ops.new(4, C)
-        _lib.check(self.lib.effdet_train_bn_bwd_prep(ops.st(), s1.data_ptr(), s2c.data_ptr(), rstd.data_ptr(), C, 1.0 / rec['M'],
-                                                     out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr()),
-                   'effdet_train_bn_bwd_prep')
+        R = c.numel() // C
+        ws = ops.ws(self.lib.effdet_train_col_reduce_workspace_floats(1, R, C))
+        _lib.check(self.lib.effdet_train_bn_bwd_sums(ops.st(), dy.data_ptr(), c.data_ptr(), mean.data_ptr(), rstd.data_ptr(), R, C,
+                                                     out.data_ptr(), ws.data_ptr(), ws.numel()), 'effdet_train_bn_bwd_sums')
         self._acc(grads, rec['prefix'] + 'weight', out[0])
         self._acc(grads, rec['prefix'] + 'bias', out[1])
         if rec['train']:
@@ -675,9 +696,8 @@ class TrainEngine(object):
 
     def _dw_bwd(self, rec, dd, grads):
         k = rec['k']
-        dx, dtaps, _ = self.ops.dw_bwd(dd, rec['x'], rec['taps'], k, 1)
-        C = dtaps.shape[1]
-        self._acc(grads, rec['prefix'] + 'weight', dtaps.reshape(k, k, C, 1).permute(2, 3, 0, 1).reshape(rec['wshape']))
+        dx, dtaps, _ = self.ops.dw_bwd(dd, rec['x'], rec['taps'], k, 1, cmajor=True)
+        self._acc(grads, rec['prefix'] + 'weight', dtaps.reshape(rec['wshape']))
         return dx
 
     # =============================================================================================
@@ -783,6 +803,14 @@ class TrainEngine(object):
         drop_rates = bb.block_drop_rates() if (bb.training and bb.drop_path_rate > 0.0) else None
         fixed_masks = getattr(bb, 'drop_path_masks', None)
         flat_idx = 0
+        drop_scale = None
+        if drop_rates is not None and fixed_masks is None:
+            # every residual block's per-image scale floor(keep + U) / keep from ONE draw (a handful of launches, not five per block)
+            key = tuple(float(v) for v in drop_rates)
+            if getattr(self, '_keeps', (None,))[0] != key:
+                self._keeps = (key, torch.tensor([1.0 - v for v in key], dtype=torch.float32, device=self.dev).reshape(-1, 1))
+            keeps = self._keeps[1]
+            drop_scale = torch.floor(keeps + torch.rand(len(key), B, device=self.dev, dtype=torch.float32)) / keeps
 
         class _StemConv(object):                      # conv_stem as a 1x1 conv over the 32-wide patches
             pass
@@ -818,13 +846,15 @@ class TrainEngine(object):
                 z3, r['proj'] = self._pw_bneval_fwd(a2, proj, bnp, pn, gate=gate, resid=cur if (b['residual'] and not dropped) else None)
                 if dropped:
                     keep = 1.0 - drop_rates[flat_idx]
-                    if fixed_masks is not None and flat_idx in fixed_masks:
-                        mask = fixed_masks[flat_idx].to(device=self.dev, dtype=torch.float32).reshape(B)
+                    if drop_scale is not None:
+                        scale = drop_scale[flat_idx]
+                    elif flat_idx in fixed_masks:
+                        scale = fixed_masks[flat_idx].to(device=self.dev, dtype=torch.float32).reshape(B) / keep
                     else:
-                        mask = torch.floor(keep + torch.rand(B, device=self.dev, dtype=torch.float32))
-                    # per-image scale as a [B, C] table for the element-wise kernel (op 4: a * v0[img, c])
-                    r['drop'] = (mask / keep).reshape(B, 1).expand(B, b['cout']).contiguous()
-                    z3 = ops.add(ops.ew(4, z3, v=(r['drop'], None, None, None), hw=z3.shape[1] * z3.shape[2]), cur)
+                        scale = torch.floor(keep + torch.rand(B, device=self.dev, dtype=torch.float32)) / keep
+                    # per-image scale as a [B, C] table for the element-wise kernels (a * v0[img, c])
+                    r['drop'] = scale.reshape(B, 1).expand(B, b['cout']).contiguous()
+                    z3 = ops.ew(13, z3, cur, v=(r['drop'], None, None, None), hw=z3.shape[1] * z3.shape[2])
                 cur = z3
                 flat_idx += 1
                 saved['blocks'].append(r)
@@ -948,7 +978,11 @@ class TrainEngine(object):
                 mid = _FPN_METHODS[method]
                 ewp = fn.combine.edge_weights.detach() if mid < 2 else None
                 # fusion weights stay on the device (a float[4] = w0, w1, w2, den read by the kernels): no host read-back
-                wdev = ops.fpn_weights(ewp, len(ins), mid)
+                if mid < 2 and self._stage is not None:
+                    wdev = self._tables[self._stage].edge_weights(p + 'combine.edge_weights', ewp, len(ins), mid,
+                                                                  lambda: ops.fpn_weights(ewp, len(ins), mid))
+                else:
+                    wdev = ops.fpn_weights(ewp, len(ins), mid)
                 H_, W_ = lvl_hw[lvl]
                 fused, act = ops.fpn_combine(ins, wdev, mid, H_, W_)
                 sc = fn.after_combine.conv
@@ -1047,9 +1081,7 @@ class TrainEngine(object):
         L = lv.L
 
         def dw_grads(rec, dd, prefix):
-            dtaps = ops.lv_dw_bwd_dw(lv, dd, rec['x'])
-            C = dtaps.shape[1]
-            grads[prefix + 'conv_dw.weight'] = dtaps.reshape(3, 3, C, 1).permute(2, 3, 0, 1).reshape(rec['dwshape'])
+            grads[prefix + 'conv_dw.weight'] = ops.lv_dw_bwd_dw(lv, dd, rec['x'], cmajor=True).reshape(rec['dwshape'])
             return ops.lv_dw(lv, dd, rec['taps'], flip=True)
 
         rec = hrec['predict']

@@ -564,6 +564,34 @@ def test_detection_loss_golden(golden, tag, alpha, w, ls):
         assert np.allclose(grads[5 + i].cpu().numpy(), g['%s_gb%d' % (tag, i)], rtol=1e-4, atol=1e-7)
 
 
+def test_detection_loss_mixed_dtypes():
+    """bfloat16 class outputs next to float32 box outputs (what a bf16 inference model returns): the loss upcasts the class
+    outputs (the boxes keep their precision) and hands each input a gradient of its own dtype"""
+    from _seeded import seeded_array
+    from ood_object_detection_amd.effdet.loss import loss_fn
+    B, C, A, sizes = 2, 6, 9, [8, 4, 2, 1, 1]
+    cls32 = [torch.from_numpy(seeded_array(14, 'c%d' % i, (B, A * C, s, s), scale=1.5)).to(DEV).to(torch.bfloat16).float() for i, s in enumerate(sizes)]
+    box32 = [torch.from_numpy(seeded_array(14, 'b%d' % i, (B, A * 4, s, s), scale=0.3)).to(DEV) for i, s in enumerate(sizes)]
+    g = torch.Generator().manual_seed(3)
+    cls_t = [torch.randint(-2, C, (B, s, s, A), generator=g).to(DEV) for s in sizes]
+    box_t = [torch.randn(B, s, s, A * 4, generator=g).to(DEV) for s in sizes]
+    npos = torch.tensor([3.0, 5.0], device=DEV)
+    kw = dict(num_classes=C, alpha=0.25, gamma=1.5, delta=0.1, box_loss_weight=50.0)
+    a = [t.clone().requires_grad_() for t in cls32]
+    b = [t.clone().requires_grad_() for t in box32]
+    ref, _, _ = loss_fn(a, b, cls_t, box_t, npos, **kw)
+    gr = torch.autograd.grad(ref, a + b)
+    a16 = [t.to(torch.bfloat16).requires_grad_() for t in cls32]
+    b2 = [t.clone().requires_grad_() for t in box32]
+    tot, _, _ = loss_fn(a16, b2, cls_t, box_t, npos, **kw)
+    assert float(tot) == float(ref)
+    gm = torch.autograd.grad(tot, a16 + b2)
+    for i in range(5):
+        assert gm[i].dtype == torch.bfloat16 and gm[5 + i].dtype == torch.float32
+        assert torch.equal(gm[5 + i], gr[5 + i])
+        assert torch.equal(gm[i], gr[i].to(torch.bfloat16))
+
+
 def test_anchor_labeler_golden(golden):
     """class / box targets, matches and num_positives vs the reference's TargetAssigner.assign"""
     from ood_object_detection_amd import _lib

@@ -95,6 +95,9 @@ def test_dwconv_backward(k, s, H, W, C):
     _close(dx.permute(0, 3, 1, 2), gx, 1e-5, 'dw dx')
     _close(dtaps.reshape(k, k, C, 1).permute(2, 3, 0, 1), gw, 2e-5, 'dw dtaps')
     _close(dsum, dy.sum((0, 2, 3)), 2e-5, 'dw dsum')
+    _, dtc, dsc = ops.dw_bwd(dy.permute(0, 2, 3, 1).contiguous().to(DEV), x.detach().permute(0, 2, 3, 1).contiguous().to(DEV), taps, k, s, cmajor=True)
+    _close(dtc.reshape(C, 1, k, k), gw, 2e-5, 'dw dtaps, parameter layout')
+    _close(dsc, dy.sum((0, 2, 3)), 2e-5, 'dw dsum, parameter layout')
 
 
 def test_elementwise_family():
@@ -197,6 +200,7 @@ def test_levels_ops_match_per_level_torch(hw):
     for l, (got, ref) in enumerate(zip(lv.split(ops.lv_dw(lv, dyp, tk, flip=True)), grads[:L])):
         _close(got.permute(0, 3, 1, 2), ref, 1e-5, 'levels dw dx %d' % l)
     _close(ops.lv_dw_bwd_dw(lv, dyp, packed).reshape(3, 3, C, 1).permute(2, 3, 0, 1), grads[L], 2e-5, 'levels dw dtaps')
+    _close(ops.lv_dw_bwd_dw(lv, dyp, packed, cmajor=True).reshape(C, 1, 3, 3), grads[L], 2e-5, 'levels dw dtaps, parameter layout')
     # per-level sums
     sums = ops.lv_col_reduce(lv, 0, packed)
     sq = ops.lv_col_reduce(lv, 2, packed, v=sums, vscale=lv.inv_m)
