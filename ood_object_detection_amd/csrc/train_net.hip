@@ -103,7 +103,11 @@ DEV Frag<float> ld_k4(const float* row, int k, int K) {
 // KS = 4: the four waves of a workgroup share ONE 32-row tile and each takes a quarter of K; the partial accumulators are
 // added in wave order through LDS (fixed association).  For the deep-K convs on small maps (M = a few thousand rows, K up to
 // 1152) this gives 4x the workgroups and a quarter of the serial K chain.
-template <int VEC, int KS>
+// FAST (VEC = 4, K % 4 == 0, dense A rows): the k loop has no branch around a load and no use of a loaded value before the next
+// step - operands are fetched TWO steps ahead into two register stages that ping-pong (addresses clamped to the last quad of K,
+// the out-of-range lanes zeroed where the A fragment is built; the SE gate travels with the stage), so the waits are counted
+// and a wave keeps 12 - 16 KB on the wire.  The general loop below issues every load under `k + 3 < K` and waits for it at once.
+template <int VEC, int KS, bool FAST = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
     constexpr int RT = 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -125,8 +129,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
         long long m = m0 + 16 * i + r16;
         mv[i] = m < p.M;
         if (!mv[i]) m = p.M - 1;
-        arow[i] = p.A + row_off(p.am, m);
-        grow[i] = p.a_scale ? p.a_scale + (m / p.a_scale_rpi) * p.K : nullptr;
+        arow[i] = p.A + (FAST ? m * p.am.ld : row_off(p.am, m));
+        grow[i] = p.a_scale ? p.a_scale + (long long)((unsigned)m / (unsigned)p.a_scale_rpi) * p.K : nullptr;    // rows < 2^31 (launcher)
     }
     auto lda = [&](int i, int k) {                            // A fragment, times the image's gate where there is one
         Frag<float> f = ld_k4<VEC>(arow[i], k, p.K);
@@ -145,6 +149,44 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
     for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (FAST) {
+        struct Stage { f32x4 a[RT], w[4], gt[RT]; };
+        const bool scaled = p.a_scale != nullptr;             // uniform
+        auto fetch = [&](int k0) {
+            int k = k0 + 4 * g;
+            k = k < p.K - 3 ? k : p.K - 4;
+            Stage sg;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) sg.w[t] = *reinterpret_cast<const f32x4*>(wrow[t] + k);
+#pragma unroll
+            for (int i = 0; i < RT; ++i) sg.a[i] = *reinterpret_cast<const f32x4*>(arow[i] + k);
+#pragma unroll
+            for (int i = 0; i < RT; ++i) sg.gt[i] = *reinterpret_cast<const f32x4*>((scaled ? grow[i] : arow[i]) + k);
+            return sg;
+        };
+        auto step = [&](Stage& sg, int k0) {
+            const bool kv = k0 + 4 * g < ke;
+            Frag<float> fa[RT], fw[4];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                f32x4 v = scaled ? sg.a[i] * sg.gt[i] : sg.a[i];
+                fa[i].v = kv ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fw[t].v = sg.w[t];
+            __builtin_amdgcn_sched_barrier(0);
+            sg = fetch(k0 + 32);                              // this stage again two steps on (clamped past the end of K)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < RT; ++i) mma_chunk(fw[t], fa[i], acc[i][t]);
+        };
+        Stage s0 = fetch(kb), s1 = fetch(kb + 16);
+        int k0 = kb;
+        for (; k0 + 16 < ke; k0 += 32) { step(s0, k0); step(s1, k0 + 16); }
+        if (k0 < ke) step(s0, k0);
+    } else {
     Frag<float> bc[RT], ac[4];
 #pragma unroll
     for (int i = 0; i < RT; ++i) bc[i] = lda(i, kb + 4 * g);
@@ -165,6 +207,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
         for (int i = 0; i < RT; ++i) bc[i] = bn[i];
 #pragma unroll
         for (int t = 0; t < 4; ++t) ac[t] = an[t];
+    }
     }
     if constexpr (KS > 1) {
         __shared__ float red[KS - 1][RT * 16][64];
@@ -1363,6 +1406,13 @@ static int launch_gemm_nt(hipStream_t st, GemmNtArgs& p) {
     const dim3 grid((unsigned)gx, (unsigned)((N + 63) / 64));
     const bool vec2 = K % 2 == 0 && p.am.ld % 2 == 0 && p.am.img_stride % 2 == 0 &&
                       reinterpret_cast<uintptr_t>(A) % 8 == 0 && reinterpret_cast<uintptr_t>(W) % 8 == 0;
+    const bool fast = vec && K >= 4 && p.am.nlev == 0 && p.am.img_stride == 0 && M < 0x7fffffffLL &&
+                      (!p.a_scale || (reinterpret_cast<uintptr_t>(p.a_scale) % 16 == 0 && p.a_scale_rpi < 0x7fffffffLL));
+    if (fast) {
+        if (splitk) hipLaunchKernelGGL((gemm_nt_kernel<4, 4, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_nt_kernel<4, 1, true>), grid, dim3(256), 0, st, p);
+        return effdet_check_launch();
+    }
     if (splitk) {
         if (vec) hipLaunchKernelGGL((gemm_nt_kernel<4, 4>), grid, dim3(256), 0, st, p);
         else if (vec2) hipLaunchKernelGGL((gemm_nt_kernel<2, 4>), grid, dim3(256), 0, st, p);
