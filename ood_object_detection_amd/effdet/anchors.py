@@ -198,15 +198,17 @@ class AnchorLabeler(object):
         dev = boxes.device
         B = len(gt_boxes)
         assert B == len(gt_classes)
-        Mmax = max([int(b.shape[0]) for b in gt_boxes] + [1])
+        lens = [int(b.shape[0]) for b in gt_boxes]
+        Mmax = max(lens + [1])
         gb = torch.zeros(B, Mmax, 4, dtype=torch.float32, device=dev)
         gc = torch.full((B, Mmax), -1, dtype=torch.int64, device=dev)
-        for i in range(B):
-            m = int(gt_boxes[i].shape[0])
-            if m:
-                gb[i, :m] = gt_boxes[i].to(device=dev, dtype=torch.float32)
-                c = gt_classes[i].to(device=dev, dtype=torch.int64).reshape(-1)
-                gc[i, :m] = c if filter_valid else c.clamp(min=0)
+        if sum(lens):
+            # one scatter for the whole batch (the lengths are host values): rows i * Mmax + j <- the j-th box of image i
+            rows = torch.tensor([i * Mmax + j for i, m in enumerate(lens) for j in range(m)], dtype=torch.int64).to(dev)
+            allb = torch.cat([b.to(device=dev, dtype=torch.float32).reshape(-1, 4) for b, m in zip(gt_boxes, lens) if m], 0)
+            allc = torch.cat([c.to(device=dev, dtype=torch.int64).reshape(-1) for c, m in zip(gt_classes, lens) if m], 0)
+            gb.view(-1, 4)[rows] = allb
+            gc.view(-1)[rows] = allc if filter_valid else allc.clamp(min=0)
         N = boxes.shape[0]
         cls_t = torch.empty(B, N, dtype=torch.int64, device=dev)
         box_t = torch.empty(B, N, 4, dtype=torch.float32, device=dev)

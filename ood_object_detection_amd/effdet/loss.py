@@ -64,6 +64,25 @@ def _pack(outs, width):
     return torch.cat([o.permute(0, 2, 3, 1).reshape(B, -1, width) for o in outs], 1)
 
 
+def _pack_targets(ts, last):
+    """per-level targets [B, H, W, A(*4)] -> [B, N] (last = 0) or [B, N, 4]: the labeler's own packed tensor when the levels are
+    its views in order (AnchorLabeler._unpack), else a concatenation"""
+    B = ts[0].shape[0]
+    base = ts[0]._base
+    if base is not None and base.is_contiguous() and base.shape[0] == B and all(t._base is base for t in ts) and \
+            base.dim() == (3 if last else 2) and (not last or base.shape[2] == last):
+        n, off, ok = base.shape[1], 0, True
+        for t in ts:
+            cnt = t[0].numel() // (last or 1)
+            ok = ok and t.storage_offset() == off * (last or 1) and t.stride(0) == base.stride(0)
+            off += cnt
+        if ok and off == n:
+            return base
+    if last:
+        return torch.cat([t.reshape(B, -1, last) for t in ts], 1)
+    return torch.cat([t.reshape(B, -1) for t in ts], 1)
+
+
 def loss_fn(cls_outputs: List[torch.Tensor], box_outputs: List[torch.Tensor], cls_targets: List[torch.Tensor],
             box_targets: List[torch.Tensor], num_positives: torch.Tensor, num_classes: int, alpha: float, gamma: float,
             delta: float, box_loss_weight: float, label_smoothing: float = 0.,
@@ -73,8 +92,8 @@ def loss_fn(cls_outputs: List[torch.Tensor], box_outputs: List[torch.Tensor], cl
     B = cls_outputs[0].shape[0]
     cls_all = _pack(list(cls_outputs), num_classes)
     box_all = _pack(list(box_outputs), 4)
-    cls_t = torch.cat([t.reshape(B, -1) for t in cls_targets], 1)
-    box_t = torch.cat([t.reshape(B, -1, 4) for t in box_targets], 1)
+    cls_t = _pack_targets(list(cls_targets), 0)
+    box_t = _pack_targets(list(box_targets), 4)
     total, parts = _DetectionLossFn.apply(cls_all, box_all, cls_t, box_t, num_positives, float(alpha), float(delta),
                                           float(box_loss_weight), float(label_smoothing))
     return total, parts[1], parts[2]

@@ -102,9 +102,17 @@ class PretrainStep(object):
     # ---- captured iteration ---------------------------------------------------------------------------------
     def _capture(self, x, cls_t, box_t, npos):
         model, opt = self.model, self.opt
+        from .effdet.loss import _pack_targets
         sx = x.clone()
-        s_cls = [t.clone() for t in cls_t]
-        s_box = [t.clone() for t in box_t]
+        # static targets: ONE packed tensor each when they are the labeler's views (one copy per replay instead of one per level)
+        cb, bb = _pack_targets(list(cls_t), 0), _pack_targets(list(box_t), 4)
+        if self.labeler is not None and cb is cls_t[0]._base and bb is box_t[0]._base:
+            self._static_base = (cb.clone(), bb.clone())
+            s_cls, s_box = self.labeler._unpack(*self._static_base)
+        else:
+            self._static_base = None
+            s_cls = [t.clone() for t in cls_t]
+            s_box = [t.clone() for t in box_t]
         s_np = npos.clone()
         torch.cuda.synchronize()
         g1 = torch.cuda.CUDAGraph()
@@ -129,10 +137,17 @@ class PretrainStep(object):
         if tuple(x.shape) != tuple(sx.shape) or x.dtype != sx.dtype:
             raise ValueError('graph mode: input shape / dtype changed (%s %s, captured %s %s)' % (tuple(x.shape), x.dtype, tuple(sx.shape), sx.dtype))
         sx.copy_(x)
-        for d, t in zip(s_cls, cls_t):
-            d.copy_(t)
-        for d, t in zip(s_box, box_t):
-            d.copy_(t)
+        base = self._static_base
+        if base is not None and cls_t[0]._base is not None and cls_t[0]._base.shape == base[0].shape and \
+                box_t[0]._base is not None and box_t[0]._base.shape == base[1].shape and \
+                all(t._base is cls_t[0]._base for t in cls_t) and all(t._base is box_t[0]._base for t in box_t):
+            base[0].copy_(cls_t[0]._base)
+            base[1].copy_(box_t[0]._base)
+        else:
+            for d, t in zip(s_cls, cls_t):
+                d.copy_(t)
+            for d, t in zip(s_box, box_t):
+                d.copy_(t)
         s_np.copy_(npos)
         self.opt.advance()
         g1.replay()
