@@ -348,6 +348,13 @@ class EfficientDet(nn.Module):
             v += t._version
         return (self._wver[0], mods, v, c[3])
 
+    def train_signature(self):
+        """What the training engine's recorded tables depend on besides parameter VALUES: the identity of the sub-modules the
+        scripts swap and the process-wide count of parameter / buffer / module registrations (a replaced Parameter object, a new
+        head).  A change means: build a new TrainEngine (its first step records again)."""
+        pred = getattr(self.class_net, 'predict', None)
+        return (id(self.backbone), id(self.fpn), id(self.class_net), id(self.box_net), id(getattr(pred, 'conv_pw', None)), _REGISTRATIONS[0])
+
     def prepare(self, batch_size, image_size=None, ood_out=None):
         """Fold BN, repack weights to the kernel layouts and build the launch plan."""
         from ..engine import Engine
@@ -428,7 +435,7 @@ def _run_train(model, x, mode):
     """Differentiable forward on the training engine (train_engine.py); outputs carry autograd history."""
     from ..train_engine import TrainEngine, run_backbone, run_fpn_heads
     eng = model._train_engine
-    if eng is None or eng.dev != model.backbone.conv_stem.weight.device:
+    if eng is None or eng.dev != model.backbone.conv_stem.weight.device or eng.signature != model.train_signature():
         eng = model._train_engine = TrainEngine(model)
     model.ood_energy = model.ood_max_logit = None          # the OOD epilogue belongs to the inference kernels
     if mode == 'bb':

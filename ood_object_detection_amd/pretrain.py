@@ -179,7 +179,7 @@ class PretrainStep(object):
     def __call__(self, x, target, time_allreduce=False, evaluator=None):
         model, opt = self.model, self.opt
         self._calls += 1
-        if model._train_engine is None:
+        if model._train_engine is None or model._train_engine.signature != model.train_signature():
             from .train_engine import TrainEngine
             model._train_engine = TrainEngine(model)
         self._engine_flags()

@@ -483,6 +483,7 @@ class TrainEngine(object):
         if p0.dtype != torch.float32:
             raise RuntimeError('the training path is float32 (the reference trains in fp32; pretrain.py:226)')
         self.model = model
+        self.signature = model.train_signature() if hasattr(model, 'train_signature') else None
         self.dev = p0.device
         self.ops = _Ops(self.dev)
         self.lib = self.ops.lib

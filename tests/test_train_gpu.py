@@ -585,6 +585,58 @@ def test_full_net_autograd_and_reproducible():
     assert not c2[0].requires_grad
 
 
+def test_training_engine_follows_structure_changes_and_table_mode_equals_recording_mode():
+    """(a) The first step records the stage tables (derived weights / parameter gradients conv by conv), later steps run them as
+    one launch per kind: both give bit-identical gradients.  (b) `reset_head` (a new predict conv) and a replaced Parameter object
+    make the model build a new TrainEngine instead of reading stale pointers."""
+    from ood_object_detection_amd.effdet.loss import DetectionLoss
+    size, B, C = 128, 2, 20
+    model, cfg, nodes, sd, x = _train_setup(size, B, C, seed=27)
+    cls_t, box_t, npos = _targets(cfg, size, B, C, 8)
+    model = model.to(DEV).float().train()
+    model.backbone.apply(lambda m: m.eval() if isinstance(m, torch.nn.BatchNorm2d) else None)
+    model.backbone.drop_path_rate = 0.0
+    loss_fn = DetectionLoss(cfg)
+
+    def step():
+        model.load_state_dict(sd)
+        model.zero_grad(set_to_none=True)
+        cls_o, box_o = model(x.to(DEV))
+        total, _, _ = loss_fn(cls_o, box_o, [t.to(DEV) for t in cls_t], [t.to(DEV) for t in box_t], npos.to(DEV))
+        total.backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.clone() for n, p in model.named_parameters()}
+
+    g1 = step()                     # records
+    eng = model._train_engine
+    g2 = step()                     # uploads the forward table, runs it
+    g3 = step()                     # both tables
+    assert model._train_engine is eng and eng._tables['bb'].gtab is not None and eng._tables['fh'].ptab is not None
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]) and torch.equal(g1[n], g3[n]), n
+    # (b) a new head: new parameters behind the recorded names
+    model.reset_head(num_classes=7)
+    model = model.to(DEV)
+    cfg7 = model.config
+    cls7 = [torch.where(t >= 7, torch.full_like(t, 6), t) for t in cls_t]
+    model.zero_grad(set_to_none=True)
+    cls_o, box_o = model(x.to(DEV))
+    assert model._train_engine is not eng
+    assert cls_o[0].shape[1] == 9 * 7
+    total, _, _ = DetectionLoss(cfg7)(cls_o, box_o, [t.to(DEV) for t in cls7], [t.to(DEV) for t in box_t], npos.to(DEV))
+    total.backward()
+    assert bool(torch.isfinite(model.class_net.predict.conv_pw.weight.grad).all())
+    eng2 = model._train_engine
+    conv = model.fpn.cell[0].fnode[0].after_combine.conv.conv_pw
+    conv.weight = torch.nn.Parameter(conv.weight.detach().clone() * 0.5)
+    model.zero_grad(set_to_none=True)
+    cls_o, box_o = model(x.to(DEV))
+    assert model._train_engine is not eng2
+    DetectionLoss(cfg7)(cls_o, box_o, [t.to(DEV) for t in cls7], [t.to(DEV) for t in box_t], npos.to(DEV))[0].backward()
+    assert conv.weight.grad is not None and bool(torch.isfinite(conv.weight.grad).all())
+    model.autograd = None
+
+
 def test_training_path_rejects_unsupported():
     model, cfg, nodes, sd, x = _train_setup(128, 2, 20, seed=23)
     model = model.to(DEV).float().train()               # backbone BN left in training mode: not built, must say so
