@@ -1191,11 +1191,20 @@ __global__ __launch_bounds__(1024) void se_bwd_kernel(SeBwdArgs p) {
     for (int c = tid; c < p.C; c += 1024) {
         float acc = 0.f;
         const float sc = s[c], dc = du[c];
-        for (int r = 0; r < p.R; ++r) {
-            const float dz = drp[r];
-            acc += p.W1[(long long)r * p.C + c] * dz;
-            dW1[(long long)r * p.C + c] = dz * sc;
-            dW2t[(long long)r * p.C + c] = silu_train(rp[r]) * dc;
+        for (int r0 = 0; r0 < p.R; r0 += 8) {                 // 8 rows of W1 requested before the first is used (same r order)
+            float w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = p.W1[(long long)(r0 + u < p.R ? r0 + u : p.R - 1) * p.C + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0 + u;
+                if (r < p.R) {
+                    const float dz = drp[r];
+                    acc += w[u] * dz;
+                    dW1[(long long)r * p.C + c] = dz * sc;
+                    dW2t[(long long)r * p.C + c] = silu_train(rp[r]) * dc;
+                }
+            }
         }
         p.ds[bc + c] = acc;
     }
