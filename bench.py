@@ -260,7 +260,7 @@ def kernels_sha16():
     import glob, hashlib
     h = hashlib.sha256()
     root = os.path.join(ROOT, 'ood_object_detection_amd', 'csrc')
-    skip = ('train_ops.hip', 'train_net.hip', 'evaluation.hip')
+    skip = ('train_ops.hip', 'train_net.hip', 'train_levels.hip', 'train_fpn.hip', 'evaluation.hip')
     for f in sorted(glob.glob(os.path.join(root, '*.hip')) + glob.glob(os.path.join(root, '*.h'))):
         if os.path.basename(f) in skip:
             continue
