@@ -501,6 +501,108 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel_v(GemmTnArgs p) {
     }
 }
 
+// Wide-N form of the pipelined kernel (N >= 256: the class head's 810 columns): a workgroup covers 128 n x 64 k and each wave owns
+// 32 of the n columns over ALL 32 rows of a step - no cross-wave reduction, X is re-read by N / 128 workgroups instead of N / 32,
+// and a row of dY is fetched in 512-byte runs (the 32-column form read 128 bytes per row and workgroup out of 3 240-byte rows).
+template <bool DENSE, int VYW>
+__global__ __launch_bounds__(256) void gemm_tn_kernel_w(GemmTnArgs p) {
+    constexpr int RT = 32, SY = 144, SX = 80;
+    __shared__ float sY[RT * SY];
+    __shared__ float sX[RT * SX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 64;
+    const long long mb = (long long)blockIdx.z * p.rows_per_slice;
+    long long me = mb + p.rows_per_slice;
+    if (me > p.M) me = p.M;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int Kx = p.K + 1;
+    const int yr = tid >> 3, yc = (tid & 7) * 16;             // dY: row yr, 16 columns from yc
+    const int xr = tid >> 4, xc = (tid & 15) * 4;
+    const int kk = k0 + xc;
+    const bool kok = kk < p.K, kone = kk == p.K;
+    const int kl = kok ? kk : 0;
+    constexpr int NP = 16 / VYW;                              // pieces of VYW floats
+    int nl[NP];
+    bool nok[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) { const int n = n0 + yc + VYW * q; nok[q] = n < p.N; nl[q] = nok[q] ? n : 0; }
+    struct Stage { float vy[16]; f32x4 vx0, vx1; };
+    auto fetch = [&](long long m0) {
+        Stage s;
+        long long my = m0 + yr, m0x = m0 + xr, m1x = m0 + xr + 16;
+        my = my < me ? my : me - 1; m0x = m0x < me ? m0x : me - 1; m1x = m1x < me ? m1x : me - 1;
+        const float* yrow = p.dY + (DENSE ? my * p.ym.ld : row_off(p.ym, my));
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            if constexpr (VYW == 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(yrow + nl[q]);
+                s.vy[4 * q] = v[0]; s.vy[4 * q + 1] = v[1]; s.vy[4 * q + 2] = v[2]; s.vy[4 * q + 3] = v[3];
+            } else {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(yrow + nl[q]);
+                s.vy[2 * q] = v[0]; s.vy[2 * q + 1] = v[1];
+            }
+        }
+        s.vx0 = *reinterpret_cast<const f32x4*>(p.X + (DENSE ? m0x * p.xm.ld : row_off(p.xm, m0x)) + kl);
+        s.vx1 = *reinterpret_cast<const f32x4*>(p.X + (DENSE ? m1x * p.xm.ld : row_off(p.xm, m1x)) + kl);
+        return s;
+    };
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f}, one4 = f32x4{1.f, 0.f, 0.f, 0.f};
+    Stage s0 = fetch(mb), s1 = fetch(mb + RT);
+    auto step = [&](Stage& sg, long long m0) {
+        __syncthreads();
+        {
+            const bool ry = m0 + yr < me, r0 = m0 + xr < me, r1 = m0 + xr + 16 < me;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (ry && nok[(4 * q4 + e) / VYW]) ? sg.vy[4 * q4 + e] : 0.f;
+                *reinterpret_cast<f32x4*>(sY + yr * SY + yc + 4 * q4) = v;
+            }
+            *reinterpret_cast<f32x4*>(sX + xr * SX + xc) = r0 ? (kok ? sg.vx0 : (kone ? one4 : zero4)) : zero4;
+            *reinterpret_cast<f32x4*>(sX + (xr + 16) * SX + xc) = r1 ? (kok ? sg.vx1 : (kone ? one4 : zero4)) : zero4;
+        }
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        sg = fetch(m0 + 2 * RT);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            const int r = 4 * st + g;
+            float a[2], b[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = sY[r * SY + 32 * wave + 16 * i + c16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = sX[r * SX + 16 * j + c16];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    for (long long m0 = mb; m0 < me; m0 += 2 * RT) {
+        step(s0, m0);
+        step(s1, m0 + RT);
+    }
+    // D[row = n local (4g + r)][col = k local (c16)]: every wave writes its own 32 x 64 block of the slice's partial row
+    float* out = p.partial + (long long)blockIdx.z * p.N * Kx;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nn = n0 + 32 * wave + 16 * i + 4 * g + r, kq = k0 + 16 * j + c16;
+                if (nn < p.N && kq < Kx) out[(long long)nn * Kx + kq] = acc[i][j][r];
+            }
+}
+
 // out[g][l] (+)= sum_s in[g][s][l] in index order
 // trC > 0: the first trC * trT entries of a row are a [trT][trC] matrix that is written transposed, [trC][trT] (depthwise tap
 // gradients [k*k][C] -> the parameter's [C][k*k]); entries behind it keep their place
@@ -1482,7 +1584,7 @@ extern "C" int effdet_train_gemm_nt_levels(void* stream, const float* A, int a_p
 }
 
 static int tn_slices(long long M, int N, int K) {
-    const long long tiles = (long long)((N + 31) / 32) * ((K + 1 + 63) / 64);
+    const long long tiles = (long long)(N >= 256 ? (N + 127) / 128 : (N + 31) / 32) * ((K + 1 + 63) / 64);   // N >= 256: the 128-column form
     long long S = (1024 + tiles - 1) / tiles;                     // aim at >= 1024 workgroups
     const long long by_rows = (M + 255) / 256;                    // at least 256 rows per slice
     if (S > by_rows) S = by_rows;
@@ -1510,6 +1612,24 @@ static int launch_gemm_tn(hipStream_t st, GemmTnArgs& p, float* out, float* work
     const bool vy = p.ym.ld % 4 == 0 && p.ym.img_stride % 4 == 0 && reinterpret_cast<uintptr_t>(p.dY) % 16 == 0;
     const bool vx = p.xm.ld % 4 == 0 && p.xm.img_stride % 4 == 0 && reinterpret_cast<uintptr_t>(p.X) % 16 == 0;
     const bool vy2 = N % 2 == 0 && p.ym.ld % 2 == 0 && p.ym.img_stride % 2 == 0 && reinterpret_cast<uintptr_t>(p.dY) % 8 == 0;
+    if (N >= 256 && vx && K % 4 == 0 && !p.x_scale && ((vy && N % 4 == 0) || vy2)) {
+        const bool dense_w = p.ym.nlev == 0 && p.xm.nlev == 0 && p.ym.img_stride == 0 && p.xm.img_stride == 0;
+        const dim3 gw((unsigned)((N + 127) / 128), (unsigned)((K + 1 + 63) / 64), (unsigned)S);
+        if (vy && N % 4 == 0) {
+            if (dense_w) hipLaunchKernelGGL((gemm_tn_kernel_w<true, 4>), gw, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_tn_kernel_w<false, 4>), gw, dim3(256), 0, st, p);
+        } else {
+            if (dense_w) hipLaunchKernelGGL((gemm_tn_kernel_w<true, 2>), gw, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_tn_kernel_w<false, 2>), gw, dim3(256), 0, st, p);
+        }
+        int rcw = effdet_check_launch();
+        if (rcw) return rcw;
+        ReduceSplitArgs rw{workspace, out, N, K, S};
+        const long long rbw = ((long long)N * (K + 1) + 15) / 16;
+        if (rbw > 0x7fffffffLL) return EFFDET_EINVAL;
+        hipLaunchKernelGGL(reduce_split_kernel, dim3((unsigned)rbw), dim3(256), 0, st, rw);
+        return effdet_check_launch();
+    }
     const bool xs_ok = !p.x_scale || (reinterpret_cast<uintptr_t>(p.x_scale) % 16 == 0 && M < 0x7fffffffLL && p.x_scale_rpi < 0x7fffffffLL);
     const bool dense = p.ym.nlev == 0 && p.xm.nlev == 0 && p.ym.img_stride == 0 && p.xm.img_stride == 0;
     if (vy && vx && N % 4 == 0 && K % 4 == 0 && xs_ok) {

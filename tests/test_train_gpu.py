@@ -63,7 +63,8 @@ def test_gemm_row_maps_packed_levels():
 
 
 @pytest.mark.parametrize('M,N,K', [(5000, 64, 64), (70000, 96, 16), (333, 810, 64), (2048, 24, 144), (100, 8, 32),
-                                   (68200, 64, 64)])           # 256 slices of 288 rows: the last 19 slices are empty
+                                   (68200, 64, 64),            # 256 slices of 288 rows: the last 19 slices are empty
+                                   (9000, 810, 64), (3000, 256, 24), (1000, 388, 64)])   # N >= 256: the 128-column form (8- / 16-byte rows)
 def test_gemm_tn(M, N, K):
     ops = _ops()
     dY, X = _rnd(3, 'dY', (M, N)), _rnd(3, 'X', (M, K))
@@ -252,6 +253,17 @@ def test_levels_ops_match_per_level_torch(hw):
     _close(dW, gl.t() @ packed.double(), 2e-5, 'dW from the head tensor')
     _close(dsum, gl.sum(0), 2e-5, 'dsum from the head tensor')
     _close(ops.gemm_nt_levels(lv, g, W.t().contiguous(), a_packed=True, pk=(lv.P * N, N)), gl @ W.double(), 1e-5, 'dX from the head tensor')
+    # a wide head (N >= 256, rows only 8-byte aligned: the 810-column class head's form) read through the level row map
+    N2 = 270
+    g2 = ops.new(B, lv.P, N2).copy_(_rnd(21, 'g2', (B, lv.P, N2)))
+    dW2, dsum2 = ops.gemm_tn_levels(lv, g2, packed, N2, C, y_packed=True, pk=(lv.P * N2, N2))
+    gl2, po = [], 0
+    for (h, w) in hw:
+        gl2.append(g2[:, po:po + h * w].reshape(-1, N2))
+        po += h * w
+    gl2 = torch.cat(gl2, 0).double()
+    _close(dW2, gl2.t() @ packed.double(), 2e-5, 'dW from a wide head tensor')
+    _close(dsum2, gl2.sum(0), 2e-5, 'dsum from a wide head tensor')
 
 
 @pytest.mark.parametrize('H,W,method', [(8, 8, 0), (5, 5, 1), (6, 10, 0), (1, 1, 0), (4, 4, 2)])
