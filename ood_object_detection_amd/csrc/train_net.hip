@@ -112,8 +112,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
     constexpr int RT = 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
-    const long long m0 = KS == 1 ? ((long long)blockIdx.x * 4 + wave) * (16 * RT) : (long long)blockIdx.x * (16 * RT);
-    const int n0 = blockIdx.y * 64;
+    // the column blocks of one row group are consecutive workgroups (n fastest): they run at the same time, so a wide row (the
+    // 810-column class head) is completed in L2 before it is evicted and its A rows are fetched from HBM once
+    const unsigned nby = (unsigned)((p.N + 63) / 64);
+    const unsigned bx = blockIdx.x / nby, by = blockIdx.x - bx * nby;
+    const long long m0 = KS == 1 ? ((long long)bx * 4 + wave) * (16 * RT) : (long long)bx * (16 * RT);
+    const int n0 = by * 64;
     if (m0 >= p.M) return;                                   // uniform per wave (KS = 1) or per workgroup (KS = 4)
     int kb = 0, ke = p.K;
     if constexpr (KS > 1) {
@@ -1514,7 +1518,8 @@ static int launch_gemm_nt(hipStream_t st, GemmNtArgs& p) {
     if (!p.vec_out && N % 2 == 0 && p.cm.ld % 2 == 0 && p.cm.img_stride % 2 == 0 && reinterpret_cast<uintptr_t>(C) % 8 == 0 &&
         (bias == nullptr || reinterpret_cast<uintptr_t>(bias) % 8 == 0) && (C2 == nullptr || reinterpret_cast<uintptr_t>(C2) % 8 == 0) &&
         (p.R == nullptr || reinterpret_cast<uintptr_t>(p.R) % 8 == 0)) p.vec_out = 2;
-    const dim3 grid((unsigned)gx, (unsigned)((N + 63) / 64));
+    if (gx * ((N + 63) / 64) > 0x7fffffffLL) return EFFDET_EINVAL;
+    const dim3 grid((unsigned)(gx * ((N + 63) / 64)));
     const bool vec2 = K % 2 == 0 && p.am.ld % 2 == 0 && p.am.img_stride % 2 == 0 &&
                       reinterpret_cast<uintptr_t>(A) % 8 == 0 && reinterpret_cast<uintptr_t>(W) % 8 == 0;
     const bool fast = vec && K >= 4 && p.am.nlev == 0 && p.am.img_stride == 0 && M < 0x7fffffffLL &&
