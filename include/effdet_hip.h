@@ -15,8 +15,9 @@
  *     1 = bfloat16 (throughput mode, fp32 accumulate); weights of the MFMA GEMMs use the same dtype,
  *     every per-channel vector (scale/shift/bias/depthwise taps/SE weights) is float32; the effdet_train_* and
  *     effdet_eval_* entry points are float32 only (channels a multiple of 4);
- *   - return value: 0 on success, -22 (EINVAL) for a rejected argument, -5 (EIO) if the launch failed;
- *   - thread-safe per stream, no global mutable state.
+ *   - return value: 0 on success, -22 (EINVAL) for a rejected argument, -5 (EIO) if the launch failed or if a kernel
+ *     of an EARLIER call flagged a failure on the device (effdet_device_error);
+ *   - thread-safe per stream; the only global mutable state is the device-side failure word.
  */
 #ifndef EFFDET_HIP_H
 #define EFFDET_HIP_H
@@ -32,6 +33,11 @@ extern "C" {
 int effdet_abi_version(void);
 /* Text of the HIP error behind the calling thread's most recent -5 return. */
 const char* effdet_last_error(void);
+/* Device-side failure word: kernels OR a bit into it when they detect a failure they cannot return (bit 0: a wave of the
+ * wide MBConv kernel ran out of spins waiting for its workgroup's X-ring hand-off - its output tile is invalid).  The word is
+ * host-coherent memory: no copy, no synchronisation.  While it is non-zero every launching entry point returns -5.
+ * Returns the word; clear != 0 resets it.  (The reference has no counterpart: PyTorch raises from the failing op itself.) */
+int effdet_device_error(int clear);
 
 /* ---- backbone (timm EfficientNet; timm call sites effdet/efficientdet.py:17-18,837) ---------------- */
 

@@ -19,6 +19,7 @@ P = ctypes.POINTER
 SIGNATURES = {
     'effdet_abi_version': (c_int, []),
     'effdet_last_error': (ctypes.c_char_p, []),
+    'effdet_device_error': (c_int, [c_int]),
     'effdet_stem_conv': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int, c_int, c_int, c_int]),
     'effdet_stem_dw_fused': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -168,6 +169,24 @@ def build(verbose=False):
     if r.returncode != 0:
         raise RuntimeError('building libeffdet_hip.so failed:\n%s\n%s' % (r.stdout, r.stderr))
     return LIB_PATH
+
+
+TEST_VARIANTS = {
+    # tag -> (translation unit, defines): libeffdet_hip_<tag>.so beside the product library.  Loaded by ONE test each, never by the
+    # package.  spin0: mbconv_wide.hip whose waves give up their hand-off poll at once, so that the device-side failure report
+    # (effdet_device_error) can be seen once (tests/test_kernels_gpu.py::test_wide_handoff_timeout_is_reported).
+    'spin0': ('mbconv_wide', '-DWIDE_SPIN_LIMIT=0'),
+}
+
+
+def build_test_variants(verbose=False):
+    paths = []
+    for tag, (unit, defs) in TEST_VARIANTS.items():
+        r = subprocess.run(['make', '-C', CSRC, 'variant', 'TAG=' + tag, 'UNIT=' + unit, 'VDEFS=' + defs], capture_output=not verbose, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('building the %s variant failed:\n%s\n%s' % (tag, r.stdout, r.stderr))
+        paths.append(os.path.join(_HERE, 'libeffdet_hip_%s.so' % tag))
+    return paths
 
 
 def load():

@@ -21,10 +21,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define EFFDET_ENTER() (void)hipGetLastError()
 
 extern thread_local int effdet_last_hip_error;      // defined in abi.hip
+#define EFFDET_DEVICE_ERROR_CODE 0x7EFFDE7          /* effdet_last_hip_error value: the device-side failure word is set */
+__attribute__((visibility("hidden"))) extern volatile int* effdet_err_host;     // abi.hip: host view of the device-side failure word
+__attribute__((visibility("hidden"))) int* effdet_device_error_word();         // abi.hip: its device pointer (null: unavailable)
 static inline int effdet_check_launch() {
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) effdet_last_hip_error = (int)e;
-    return e == hipSuccess ? EFFDET_OK : EFFDET_ELAUNCH;
+    if (e != hipSuccess) { effdet_last_hip_error = (int)e; return EFFDET_ELAUNCH; }
+    // a kernel of an EARLIER call may have flagged a device-side failure (see abi.hip): reported here, sticky until cleared
+    if (effdet_err_host && *effdet_err_host) { effdet_last_hip_error = EFFDET_DEVICE_ERROR_CODE; return EFFDET_ELAUNCH; }
+    return EFFDET_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

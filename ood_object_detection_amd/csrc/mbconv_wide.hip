@@ -21,8 +21,8 @@
 // because this wave passed poll(q), i.e. every wave has executed its commit(q), which follows its expand(q - S) in program
 // order (LDS operations of one wave execute in order).  So waves may drift apart by up to one row-step, and a slow wave only
 // ever delays the others at their next poll.  All waves of a workgroup run the same number of row steps and are co-resident
-// by construction (same workgroup), so every spin terminates; it is bounded anyway (a broken hand-off then shows up as wrong
-// results in the parity tests instead of a hung GPU).
+// by construction (same workgroup), so every spin terminates; it is bounded anyway (a broken hand-off then sets the library's device-side
+// failure word - the next effdet_* call returns -5 - instead of hanging the GPU).
 //
 // X loads and Y stores are buffer operations with hardware range checking (out-of-image pixels: offset beyond num_records,
 // the load returns zeros and the store is dropped), as in mbconv_roll.hip, so the row loop has no exec-mask branches around
@@ -43,6 +43,7 @@ struct WideArgs {
     int TWo, nstrips, band_rows, nbands, IWs, nw, ngroups, ring_bytes, per_image;
     int xpitch, xslot_bytes, pieces_row, ppr, x_off, ring_off, lds_bytes;
     FastDiv fd_ppr;
+    int* err_word;                                 // device-side failure word (abi.hip) or null
 };
 
 typedef float f32x2w __attribute__((ext_vector_type(2)));
@@ -63,6 +64,11 @@ template <int V> struct IntW { static constexpr int value = V; };
 // 1: no hand-off (no poll, no arrival count)  2: no depthwise arithmetic  4: no expand arithmetic  8: no X staging  16: SiLU -> identity
 #ifndef WIDE_ABLATE
 #define WIDE_ABLATE 0
+#endif
+// polls of an arrival counter before a wave gives up (and flags the failure); -DWIDE_SPIN_LIMIT=0 exists as a variant build for the
+// test of that report only (tests/test_kernels_gpu.py::test_wide_handoff_timeout_is_reported)
+#ifndef WIDE_SPIN_LIMIT
+#define WIDE_SPIN_LIMIT (1 << 22)
 #endif
 DEV f32x4 act4_w(const f32x4 x) {
     if constexpr ((WIDE_ABLATE & 16) != 0) return x; else return silu4_w(x);
@@ -200,12 +206,17 @@ __global__ __launch_bounds__(1024, 4) void mbconv_wide_kernel(WideArgs p) {
         if constexpr ((WIDE_ABLATE & 1) != 0) return;
         const int target = p.nw * (rel / NSX + 1);
         int* c = cnt + (rel & (NSX - 1));
+        bool arrived = false;
 #pragma unroll 1
-        for (int spin = 0; spin < (1 << 22); ++spin) {
+        for (int spin = 0; spin < WIDE_SPIN_LIMIT; ++spin) {
             const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            if (v >= target) break;
+            if (v >= target) { arrived = true; break; }
             __builtin_amdgcn_s_sleep(1);
         }
+        // Out of spins (cannot happen while the hand-off protocol holds): the wave goes on - a hung grid is worse than a wrong tile -
+        // but says so in the library's device-side failure word, which the next effdet_* call reports as -5 (abi.hip)
+        if (!arrived && lane == 0 && p.err_word != nullptr)
+            __hip_atomic_fetch_or(p.err_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         asm volatile("" ::: "memory");                               // no X read moves above the poll
     };
     auto expand_row = [&](int rel, int slot_bytes) {
@@ -551,6 +562,7 @@ int effdet_mbconv_wide_launch(hipStream_t st, const void* X, void* Y, const void
     r.xpitch = g.xpitch; r.xslot_bytes = g.xslot_bytes; r.ppr = Cin * 2 / 16; r.pieces_row = g.IWs * r.ppr;
     r.x_off = WIDE_HDR; r.ring_off = WIDE_HDR + 2 * stride * g.xslot_bytes; r.lds_bytes = (int)g.lds;
     r.fd_ppr = make_fastdiv(r.ppr);
+    r.err_word = effdet_device_error_word();
     if (k == 3) return stride == 1 ? launch_wide_ks<3, 1>(st, r, g) : launch_wide_ks<3, 2>(st, r, g);
     return stride == 1 ? launch_wide_ks<5, 1>(st, r, g) : launch_wide_ks<5, 2>(st, r, g);
 }

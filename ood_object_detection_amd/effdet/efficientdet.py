@@ -15,6 +15,8 @@ import logging
 import math
 from collections import OrderedDict
 
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -27,11 +29,17 @@ def _no_forward(self, *a, **k):
                        'EfficientDet.forward(..., mode=...)' % type(self).__name__)
 
 
-_REGISTRATIONS = [0]              # parameter / buffer / sub-module registrations anywhere in the process (weights_token)
+# Parameter / buffer / sub-module registrations on the modules of ONE model (weights_token, train_signature): every EfficientDet
+# enters its modules here with its own counter, and torch's global registration hooks bump the counter of the model that owns the
+# module being changed - a registration anywhere else in the process (a validation bench, an EMA copy, another model) leaves this
+# model's packed engine, training tables and captured graph alone.
+_MODULE_OWNER = weakref.WeakKeyDictionary()          # module -> that model's [count]
 
 
-def _count_registration(*_args):
-    _REGISTRATIONS[0] += 1
+def _count_registration(module, *_args):
+    c = _MODULE_OWNER.get(module)
+    if c is not None:
+        c[0] += 1
     return None
 
 
@@ -295,6 +303,8 @@ class EfficientDet(nn.Module):
         # [0]: bumped whenever parameters may have changed (load_state_dict, .to(), reset_head, invalidate(), PretrainStep);
         # [1]: cached (module ids, parameter + buffer tensors) behind weights_token().  Shared by shallow copies of the model.
         self._wver = [0, None]
+        self._reg = [0]             # registrations on this model's modules (see _MODULE_OWNER); shared by shallow copies
+        self._own_modules()
         self.ood_energy = None
         self.ood_max_logit = None
         # normalisation applied when a raw uint8 batch is passed to forward (effdet/data/loader.py:114-128)
@@ -304,6 +314,10 @@ class EfficientDet(nn.Module):
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
 
     # ---- engine management -----------------------------------------------------------------
+    def _own_modules(self):
+        for m in self.modules():
+            _MODULE_OWNER[m] = self._reg
+
     def invalidate(self):
         """Drop packed weights; call after changing parameters in place (load_state_dict does it)."""
         self._engine = None
@@ -338,11 +352,12 @@ class EfficientDet(nn.Module):
         pred = getattr(self.class_net, 'predict', None)
         mods = (id(self.backbone), id(self.fpn), id(self.class_net), id(self.box_net), id(getattr(pred, 'conv_pw', None)))
         c = self._wver[1]
-        # the cached tensor list is rebuilt when ANY module of the process registered a parameter, buffer or sub-module since it
-        # was made (`m.weight = nn.Parameter(...)`, `m.conv = nn.Conv2d(...)`: _REGISTRATIONS counts those through torch's global
+        # the cached tensor list is rebuilt when a module of THIS model registered a parameter, buffer or sub-module since it was
+        # made (`m.weight = nn.Parameter(...)`, `m.conv = nn.Conv2d(...)`: self._reg counts those through torch's global
         # registration hooks) - a replaced Parameter object would otherwise leave its predecessor in the list
-        if c is None or c[0] != mods or c[2] != self._wver[0] or c[3] != _REGISTRATIONS[0]:
-            c = self._wver[1] = (mods, list(self.parameters()) + list(self.buffers()), self._wver[0], _REGISTRATIONS[0])
+        if c is None or c[0] != mods or c[2] != self._wver[0] or c[3] != self._reg[0] or _MODULE_OWNER.get(self) is not self._reg:   # (last: a deep copy)
+            self._own_modules()                 # new sub-modules join the owner map
+            c = self._wver[1] = (mods, list(self.parameters()) + list(self.buffers()), self._wver[0], self._reg[0])
         v = 0
         for t in c[1]:
             v += t._version
@@ -350,10 +365,11 @@ class EfficientDet(nn.Module):
 
     def train_signature(self):
         """What the training engine's recorded tables depend on besides parameter VALUES: the identity of the sub-modules the
-        scripts swap and the process-wide count of parameter / buffer / module registrations (a replaced Parameter object, a new
-        head).  A change means: build a new TrainEngine (its first step records again)."""
+        scripts swap and the count of parameter / buffer / module registrations on this model's modules (a replaced Parameter
+        object, a new head).  A change means: build a new TrainEngine (its first step records again)."""
         pred = getattr(self.class_net, 'predict', None)
-        return (id(self.backbone), id(self.fpn), id(self.class_net), id(self.box_net), id(getattr(pred, 'conv_pw', None)), _REGISTRATIONS[0])
+        self.weights_token()                    # modules added since the last look join the owner map
+        return (id(self.backbone), id(self.fpn), id(self.class_net), id(self.box_net), id(getattr(pred, 'conv_pw', None)), self._reg[0])
 
     def prepare(self, batch_size, image_size=None, ood_out=None):
         """Fold BN, repack weights to the kernel layouts and build the launch plan."""

@@ -55,9 +55,12 @@ class PretrainStep(object):
             self.world = dist.get_world_size()
         self.last_allreduce_ms = 0.0
         self.graph = bool(graph)
-        self._graph_warmup = int(graph_warmup)
+        # the stage tables upload at the end of the first backward and at the start of the second forward (host-to-device copies,
+        # which cannot be captured): at least two eager iterations before the capture
+        self._graph_warmup = max(2, int(graph_warmup))
         self._calls = 0
         self._cap = None                        # (graph, optimizer graph or None, static inputs, static outputs)
+        self._static_base = None
 
     def targets(self, target):
         """target: {'bbox': [per-image [M,4] yxyx], 'cls': [per-image [M]]} (labelled on the GPU, effdet/anchors.py:384-438)
@@ -138,11 +141,15 @@ class PretrainStep(object):
             raise ValueError('graph mode: input shape / dtype changed (%s %s, captured %s %s)' % (tuple(x.shape), x.dtype, tuple(sx.shape), sx.dtype))
         sx.copy_(x)
         base = self._static_base
-        if base is not None and cls_t[0]._base is not None and cls_t[0]._base.shape == base[0].shape and \
-                box_t[0]._base is not None and box_t[0]._base.shape == base[1].shape and \
-                all(t._base is cls_t[0]._base for t in cls_t) and all(t._base is box_t[0]._base for t in box_t):
-            base[0].copy_(cls_t[0]._base)
-            base[1].copy_(box_t[0]._base)
+        from .effdet.loss import _pack_targets
+        # _pack_targets returns the common base only when the level tensors are the labeler's in-order views of it
+        views = base is not None and cls_t[0]._base is not None and box_t[0]._base is not None
+        cb = _pack_targets(list(cls_t), 0) if views else None
+        bb = _pack_targets(list(box_t), 4) if views else None
+        if base is not None and cb is not None and bb is not None and cb is cls_t[0]._base and bb is box_t[0]._base and \
+                cb.shape == base[0].shape and bb.shape == base[1].shape:
+            base[0].copy_(cb)
+            base[1].copy_(bb)
         else:
             for d, t in zip(s_cls, cls_t):
                 d.copy_(t)
@@ -182,6 +189,13 @@ class PretrainStep(object):
         if model._train_engine is None or model._train_engine.signature != model.train_signature():
             from .train_engine import TrainEngine
             model._train_engine = TrainEngine(model)
+            if self._cap is not None:
+                # The captured kernels hold raw addresses of the OLD engine's persistent tensors (folded weights, stage tables,
+                # gradient buffers), which return to the allocator with it: replaying the graph would read freed memory.  Drop
+                # the graph and its static buffers, run the eager warm-up again on the new engine, then re-capture.
+                self._cap = None
+                self._static_base = None
+                self._calls = 1
         self._engine_flags()
         if self.graph and evaluator is None and self._calls > self._graph_warmup:
             cls_t, box_t, npos = self.targets(target)

@@ -55,8 +55,9 @@ class _StageTables(object):
         self.ptab = self.gtab = None
         self.frozen = False                        # True once the tables are on the device
 
-    def _check_src(self, entry, src):
-        if entry[0].src != src.data_ptr():
+    def _check_src(self, entry, src, extra=()):
+        # `extra`: (recorded pointer, tensor) pairs of the other sources of the record (BN gamma / beta / running statistics)
+        if entry[0].src != src.data_ptr() or any(ptr != t.data_ptr() for ptr, t in extra):
             raise RuntimeError('a parameter was re-allocated after the training engine recorded it; build a new TrainEngine')
 
     def transpose(self, key, src2d):
@@ -87,7 +88,9 @@ class _StageTables(object):
 
     def fold(self, key, W, bn, want_wf, want_wft, want_wt, compute):
         if key in self.prep:
-            self._check_src(self.prep[key], W)
+            op = self.prep[key][0]
+            self._check_src(self.prep[key], W, ((op.gamma, bn.weight), (op.beta, bn.bias), (op.mean, bn.running_mean),
+                                                (op.var, bn.running_var)))
             return self.prep[key][1][0]
         if self.frozen:
             raise RuntimeError('unrecorded derived weight %r' % (key,))
@@ -102,6 +105,10 @@ class _StageTables(object):
     def grad_entry(self, key, rec, transposed):
         """-> (dWext buffer the backward GEMM writes, dW, dgb, deferred) for conv `key`; deferred: run_grads() will fill dW / dgb"""
         if key in self.grad:
+            op = self.grad[key][0]
+            if op.W != rec['W'].data_ptr() or op.scale != rec['scale'].data_ptr() or op.rstd != rec['rstd'].data_ptr() or \
+                    op.mean != rec['mean'].data_ptr():
+                raise RuntimeError('a parameter was re-allocated after the training engine recorded it; build a new TrainEngine')
             return self.grad[key][1][:3] + (self.gtab is not None,)
         if self.gtab is not None:
             raise RuntimeError('unrecorded gradient %r' % (key,))
@@ -1184,7 +1191,10 @@ def _param_grads(ctx, grads, first):
             src.append(g)
             out.append(None)
         else:
-            out.append(g)
+            # `g` may be (a view of) a persistent buffer of the stage tables, which the next backward overwrites: autograd's
+            # AccumulateGrad keeps the tensor it is handed as `.grad`, so it must get its own copy (two backwards without
+            # zero_grad, or two 'bb' nodes in one graph as in infer.py:345-351, would otherwise add a buffer to itself)
+            out.append(g.clone())
     if dst:
         torch._foreach_add_(dst, src)
     return out

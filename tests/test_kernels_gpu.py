@@ -179,6 +179,52 @@ def test_mbconv_expand_dw_fused(dtype, Cin, mid, H, W, k, s):
     _check_pool_against_oracle(part, Ho, Wo, ref, e, wd, s2, k, s, dtype)
 
 
+def test_wide_handoff_timeout_is_reported():
+    """mbconv_wide.hip hands X rows over through LDS arrival counters with a BOUNDED spin.  A wave that runs out of spins goes on
+    (no hung grid) but must say so: it sets the library's device-side failure word, and the next launching effdet_* call returns
+    -5 with a text that names it.  Seen once through the test-only variant build whose spin limit is 0
+    (_lib.TEST_VARIANTS['spin0'], built by __graft_entry__.build(); the package never loads it); the product library run on
+    the same problem leaves the word clear."""
+    import ctypes
+    import os
+    import _hip
+    from ood_object_detection_amd import _lib
+    lib = _lib.load()
+    vpath = os.path.join(os.path.dirname(_lib.LIB_PATH), 'libeffdet_hip_spin0.so')
+    assert os.path.exists(vpath), 'run __graft_entry__.build() (it builds the test variants)'
+    var = ctypes.CDLL(vpath)
+    B, Cin, mid, H, W, k, s = 2, 80, 480, 40, 40, 3, 1
+    assert lib.effdet_mbconv_tiles_per_image(1, H, W, Cin, mid, k, s) > 0
+    x = _rand(B, Cin, H, W, seed=50).to(torch.bfloat16)
+    xd = _hip.nhwc(x, torch.bfloat16).to(DEV)
+    y = torch.empty(B, H, W, mid, dtype=torch.bfloat16, device=DEV)
+    dv = [t.contiguous().to(DEV) for t in (_rand(mid, Cin, seed=51).to(torch.bfloat16), torch.ones(mid), torch.zeros(mid),
+                                           _rand(k * k, mid, seed=53), torch.ones(mid), torch.zeros(mid))]
+
+    def run(l):
+        fn = l.effdet_mbconv_expand_dw
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int] * 7
+        return fn(_hip.stream(DEV), 1, xd.data_ptr(), y.data_ptr(), *[t.data_ptr() for t in dv], None, B, H, W, Cin, mid, k, s)
+
+    assert run(lib) == 0
+    torch.cuda.synchronize()
+    assert lib.effdet_device_error(0) == 0 and run(lib) == 0          # the real hand-off never times out
+    torch.cuda.synchronize()
+    var.effdet_device_error.restype = ctypes.c_int
+    var.effdet_device_error.argtypes = [ctypes.c_int]
+    var.effdet_last_error.restype = ctypes.c_char_p
+    assert var.effdet_device_error(1) == 0
+    assert run(var) == 0                                              # the launch itself succeeds ...
+    torch.cuda.synchronize()
+    assert var.effdet_device_error(0) & 1                             # ... its waves gave up and said so
+    assert run(var) == -5                                             # the next call reports it
+    assert b'device-side failure' in var.effdet_last_error()
+    torch.cuda.synchronize()
+    assert var.effdet_device_error(1) & 1 and var.effdet_device_error(0) == 0     # cleared
+    assert lib.effdet_device_error(0) == 0                            # the product library's own word was never touched
+
+
 def _check_pool_against_oracle(part, Ho, Wo, ref, e, wd, s2, k, stride, dtype):
     """SE pool partial sums against the ORACLE's pooled activation (not against the kernel's own output).  float32: 1e-4.
     bf16: the bound follows from the roundings the kernel makes, it is not a measured band: the expanded map is stored as bf16

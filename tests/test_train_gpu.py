@@ -649,6 +649,117 @@ def test_training_engine_follows_structure_changes_and_table_mode_equals_recordi
     model.autograd = None
 
 
+def test_gradients_accumulate_across_backwards_and_two_backbone_nodes():
+    """(a) infer.py:305 zeroes the gradients only at the first task of a meta batch and lets `.backward()` ACCUMULATE over the
+    others: two backwards without zero_grad must give g1 + g2 - also once the stage tables hand out persistent gradient buffers
+    (third step on).  (b) infer.py:345-351 runs mode='bb' twice before one backward: two BackboneFn nodes in one graph, whose
+    parameter gradients add.  Both against gradients of the separate runs (same kernels: equal to 1e-6 of the largest entry)."""
+    from ood_object_detection_amd.effdet.loss import DetectionLoss
+    size, B, C = 128, 2, 20
+    model, cfg, nodes, sd, x = _train_setup(size, B, C, seed=29)
+    x2 = torch.from_numpy(seeded_array(31, 'input', (B, 3, size, size)))
+    cls_t, box_t, npos = _targets(cfg, size, B, C, 8)
+    model = model.to(DEV).float().train()
+    model.backbone.apply(lambda m: m.eval() if isinstance(m, torch.nn.BatchNorm2d) else None)
+    model.backbone.drop_path_rate = 0.0
+    loss_fn = DetectionLoss(cfg)
+    tg = ([t.to(DEV) for t in cls_t], [t.to(DEV) for t in box_t], npos.to(DEV))
+
+    def backward_of(xin, zero=True):
+        if zero:
+            model.zero_grad(set_to_none=True)
+        cls_o, box_o = model(xin.to(DEV))
+        loss_fn(cls_o, box_o, *tg)[0].backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.clone() for n, p in model.named_parameters()}
+
+    g1 = backward_of(x)                   # records the tables
+    g2 = backward_of(x2)
+    g1b = backward_of(x)                  # table mode: persistent gradient buffers
+    for n in g1:
+        assert torch.equal(g1[n], g1b[n]), n
+    both = backward_of(x2, zero=False)    # accumulates onto g1b's .grad tensors
+    both2 = backward_of(x, zero=False)    # and once more: g1 + g2 + g1
+    for n in g1:
+        ref = g1[n] + g2[n]
+        lim = 1e-6 * max(float(ref.abs().max()), 1e-12)
+        assert float((both[n] - ref).abs().max()) <= lim, ('two backwards', n)
+        ref3 = ref + g1[n]
+        assert float((both2[n] - ref3).abs().max()) <= 2e-6 * max(float(ref3.abs().max()), 1e-12), ('three backwards', n)
+    # zero_grad(set_to_none=False) keeps the .grad tensors: the next backward must add into zeros, not into a stale buffer
+    model.zero_grad(set_to_none=False)
+    g1c = backward_of(x, zero=False)
+    for n in g1:
+        assert torch.equal(g1c[n], g1[n]), ('zero_grad(set_to_none=False)', n)
+
+    # (b) two backbone nodes in one graph
+    def bb_loss(feats):
+        return sum((f.float() ** 2).mean() for f in feats)
+    gsep = []
+    for xin in (x, x2):
+        model.zero_grad(set_to_none=True)
+        bb_loss(model(xin.to(DEV), mode='bb')).backward()
+        gsep.append({n: p.grad.clone() for n, p in model.backbone.named_parameters() if p.grad is not None})
+    model.zero_grad(set_to_none=True)
+    fa, fb = model(x.to(DEV), mode='bb'), model(x2.to(DEV), mode='bb')
+    (bb_loss(fa) + bb_loss(fb)).backward()
+    torch.cuda.synchronize()
+    assert gsep[0]
+    for n, p in model.backbone.named_parameters():
+        if n not in gsep[0]:
+            continue
+        ref = gsep[0][n] + gsep[1][n]
+        assert float((p.grad - ref).abs().max()) <= 1e-6 * max(float(ref.abs().max()), 1e-12), ('two bb nodes', n)
+    model.autograd = None
+
+
+def test_pretrain_graph_survives_unrelated_registrations_and_recaptures_after_own():
+    """The captured hipGraph holds raw addresses of the TrainEngine's persistent tensors.  (a) A parameter registered on a module
+    that is NOT part of the model (a validation head, another network) must not rebuild the engine; (b) one registered on the
+    model itself must - and then the graph is dropped, the eager warm-up runs again on the new engine and a new graph is
+    captured: the run stays bit-identical to an all-eager run doing the same thing."""
+    from ood_object_detection_amd.pretrain import PretrainStep
+    size, B, C = 128, 2, 20
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randint(0, 256, (B, 3, size, size), generator=g, dtype=torch.uint8).to(DEV) for _ in range(9)]
+    boxes = [torch.tensor([[10., 12., 70., 90.], [40., 30., 120., 100.]]), torch.tensor([[5., 5., 60., 50.]])]
+    cls = [torch.tensor([3, 7]), torch.tensor([1])]
+    target = {'bbox': [b.to(DEV) for b in boxes], 'cls': [c.to(DEV) for c in cls]}
+    runs = []
+    for graph in (False, True):
+        model, cfg, nodes, sd, _ = _train_setup(size, B, C, seed=23)
+        model = model.to(DEV).float()
+        step = PretrainStep(model, graph=graph, graph_warmup=1)        # clamped to 2: the tables upload during the first two steps
+        assert step._graph_warmup == 2
+        hist = []
+        for i, x in enumerate(xs):
+            if i == 4:
+                eng = model._train_engine
+                cap = step._cap
+                other = torch.nn.Linear(4, 4).to(DEV)                  # unrelated registrations: nothing of this model changes
+                other.extra = torch.nn.Parameter(torch.zeros(3, device=DEV))
+            if i == 5:
+                assert model._train_engine is eng and step._cap is cap
+                conv = model.fpn.cell[0].fnode[0].after_combine.conv.conv_pw
+                with torch.no_grad():
+                    neww = torch.nn.Parameter(conv.weight.detach().clone())
+                # (FlatAdam keeps updating its own view of the old tensor; the new Parameter object stays constant - the same in
+                # both runs - but the engine's recorded pointer to the old one is stale and must not be replayed)
+                conv.weight = neww
+            o = step(x, target)
+            if i == 5:
+                assert model._train_engine is not eng
+                if graph:
+                    assert step._cap is None                           # dropped; warm-up runs again
+            hist.append((o['loss'].item(), o['grad_norm'].item()))
+        if graph:
+            assert step._cap is not None and step._cap is not cap     # re-captured on the new engine
+        runs.append((hist, {n: p.detach().clone() for n, p in model.named_parameters()}))
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    for n in runs[0][1]:
+        assert torch.equal(runs[0][1][n], runs[1][1][n]), n
+
+
 def test_training_path_rejects_unsupported():
     model, cfg, nodes, sd, x = _train_setup(128, 2, 20, seed=23)
     model = model.to(DEV).float().train()               # backbone BN left in training mode: not built, must say so
