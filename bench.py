@@ -239,6 +239,62 @@ def parity_bf16(model_f32_cpu, x_cpu, dev, soft_nms=False, candidate='bf16'):
     return out
 
 
+def parity_accurate_vs_oracle(model_f32_cpu, x_cpu, dev, image, num_classes, soft_nms=False):
+    """compute_mode='accurate' (two-term bf16) against the CPU ORACLE (float32 PyTorch restatement of the reference) on the same
+    weights and images: L-inf of class logits, box regressions, OOD energy / max-logit, and - for every detection the HIP path kept -
+    of its score and decoded box against the oracle's values for the SAME (anchor, class).  Uses oracle/: cpu_baseline leg only."""
+    import copy
+    from oracle import model as om
+    from ood_object_detection_amd.effdet.bench import DetBenchPredict
+    from ood_object_detection_amd.effdet.config import get_fpn_config
+    cfg = model_f32_cpu.config
+    if x_cpu is None:
+        x_cpu = torch.randn(2, 3, image, image, generator=torch.Generator().manual_seed(5))
+    x_cpu = x_cpu[:2]
+    B, C = x_cpu.shape[0], num_classes
+    sd = {k: v.detach().clone().float() for k, v in model_f32_cpu.state_dict().items()}
+    nodes = get_fpn_config(cfg.fpn_name, cfg.min_level, cfg.max_level).nodes
+    with torch.no_grad():
+        cls_r, box_r = om.efficientdet_forward(sd, cfg, x_cpu, nodes)
+        e_ref, m_ref = om.ood_scores(cls_r, C)
+    m = copy.deepcopy(model_f32_cpu).to(dev).float()
+    m.compute_mode = 'accurate'
+    m.config.soft_nms = bool(soft_nms)
+    b = DetBenchPredict(m, streams=1).to(dev)
+    with torch.no_grad():
+        det = b(x_cpu.to(dev)).float().cpu()
+    eng = m._engine
+    cls_g = eng.cls_all.float().cpu()
+    box_g = eng.box_all.float().cpu()
+    cls_ref = torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, C) for r in cls_r], 1)
+    box_ref = torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4) for r in box_r], 1)
+    anchors = b.anchors.boxes.float().cpu()
+    anc = b.last_ood['anchor_index'].cpu()
+
+    def decode(rel, a):
+        ya, xa, ha, wa = (a[:, 0] + a[:, 2]) / 2, (a[:, 1] + a[:, 3]) / 2, a[:, 2] - a[:, 0], a[:, 3] - a[:, 1]
+        w, h = torch.exp(rel[:, 3]) * wa, torch.exp(rel[:, 2]) * ha
+        yc, xc = rel[:, 0] * ha + ya, rel[:, 1] * wa + xa
+        return torch.stack([xc - w / 2, yc - h / 2, xc + w / 2, yc + h / 2], 1)
+    ss = sb = 0.0
+    ndet = 0
+    for i in range(B):
+        n = int(b.last_count[i])
+        ndet += n
+        if n == 0:
+            continue
+        a_idx, c_idx = anc[i, :n], det[i, :n, 5].long() - 1
+        if not soft_nms:                                     # (soft-NMS rescales the scores it keeps)
+            ss = max(ss, float((torch.sigmoid(cls_ref[i, a_idx, c_idx]) - det[i, :n, 4]).abs().max()))
+        sb = max(sb, float((decode(box_ref[i, a_idx], anchors[a_idx]) - det[i, :n, :4]).abs().max()))
+    return {'reference': 'CPU oracle (float32 PyTorch restatement of the reference)', 'images': B, 'image_px': int(x_cpu.shape[2]),
+            'class_logits_linf': round(float((cls_g - cls_ref).abs().max()), 7), 'box_outputs_linf': round(float((box_g - box_ref).abs().max()), 7),
+            'ood_energy_linf': round(float((m.ood_energy.cpu() - e_ref).abs().max()), 7),
+            'ood_max_logit_linf': round(float((m.ood_max_logit.cpu() - m_ref).abs().max()), 7),
+            'same_candidates': {'scores_linf': round(ss, 7), 'boxes_linf_px': round(sb, 5), 'detections': ndet},
+            'class_logits_absmax': round(float(cls_ref.abs().max()), 4)}
+
+
 def calibrated_model(image=512, num_classes=90, seed=11):
     """The BN-calibrated seeded network of the parity tests (tests/_models.py): every BatchNorm's running statistics are what the
     layer actually sees on seeded images (set by one pass of the CPU oracle), class logits O(1), scores spread over (0, 1) - the
@@ -364,7 +420,8 @@ def main():
     ap.add_argument('--image', type=int, default=640)
     ap.add_argument('--batch', type=int, default=64, help='images per GPU')
     ap.add_argument('--classes', type=int, default=90)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32', 'accurate'],
+                    help="accurate: float32 weights, compute_mode='accurate' (two-term bf16 values, three matrix-core products per multiply)")
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying one hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the in-flight-1 / float32 / parity_bf16 side measurements')
@@ -412,6 +469,8 @@ def main():
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline       # the CPU baseline is an N=1 item
     sd_cpu = {k: v.clone().float() for k, v in model.state_dict().items()} if want_cpu else None
     model = model.to(dev).to(dtype)
+    if args.dtype == 'accurate':
+        model.compute_mode = 'accurate'
     sub = args.sub_batches or None
     B = args.batch
     x = (torch.randn(B, 3, args.image, args.image, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + rank))).to(dtype)
@@ -574,6 +633,15 @@ def main():
             # the point between the two: bfloat16 backbone, float32 BiFPN + heads (serving.MixedPrecisionEfficientDet)
             side('mixed_images_per_sec', mixed_rate)
             torch.cuda.empty_cache()
+            def accurate_rate():
+                ma = build_model(args.model, args.image, args.classes).to(dev)
+                ma.compute_mode = 'accurate'
+                ma.config.soft_nms = bool(args.soft_nms)
+                ea, _, _ = timed_steps(ma, x.float(), dev, nfl, sub, ks, 2, not args.no_graph, barrier)
+                return round(B * ks / ea, 1)
+            # the mode that meets north_star's 1e-3: float32 master weights, two-term bf16 values, 3 MFMAs per multiply
+            side('accurate_images_per_sec', accurate_rate)
+            torch.cuda.empty_cache()
             xp = torch.randn(4, 3, args.image, args.image, generator=torch.Generator().manual_seed(5))
             side('parity_bf16', lambda: parity_bf16(build_model(args.model, args.image, args.classes), xp, dev, soft_nms=args.soft_nms))
             side('parity_mixed', lambda: parity_bf16(build_model(args.model, args.image, args.classes), xp, dev, soft_nms=args.soft_nms,
@@ -601,11 +669,15 @@ def main():
                             weights='BN-calibrated seeded d0 (tests/_models.py), 512 px, class bias -2')
             side('parity_bf16_calibrated', lambda: calibrated('bf16'))
             side('parity_mixed_calibrated', lambda: calibrated('mixed'))
+            # the accurate mode against the ORACLE itself (float32 PyTorch on the host), bench weights and calibrated weights
+            side('parity_accurate', lambda: parity_accurate_vs_oracle(build_model(args.model, args.image, args.classes), None, dev, args.image,
+                                                                         args.classes, soft_nms=args.soft_nms))
+            side('parity_accurate_calibrated', lambda: parity_accurate_vs_oracle(*calibrated_model(), dev, 512, 90, soft_nms=args.soft_nms))
     out = {
         'metric': 'images/sec, %s %dpx %s inference + OOD score (DetBenchPredict end-to-end)' % (args.model, args.image, args.dtype),
         'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': args.dtype, 'data': 'synthetic',
+        'dtype': 'bf16x2 (two-term bf16, fp32 accumulate)' if args.dtype == 'accurate' else args.dtype, 'data': 'synthetic',
         'config': {'workload': '%s %dx%d batch=%d/GPU C=%d, DetBenchPredict: backbone+BiFPN+heads+OOD energy/max-logit+top-k(5000)+decode+%s NMS'
                                % (args.model, args.image, args.image, B, args.classes, 'soft' if args.soft_nms else 'hard'),
                    'global_batch': world * B, 'parallelism': 'image-sharded dp%d, no collective' % world,

@@ -15,6 +15,16 @@
  *     1 = bfloat16 (throughput mode, fp32 accumulate); weights of the MFMA GEMMs use the same dtype,
  *     every per-channel vector (scale/shift/bias/depthwise taps/SE weights) is float32; the effdet_train_* and
  *     effdet_eval_* entry points are float32 only (channels a multiple of 4);
+ *   - `dtype` 2 = EFFDET_BF16X2, the "accurate" mode (accepted by effdet_stem_dw_fused[_u8], effdet_mbconv_expand_dw[_gated],
+ *     effdet_pw_gemm_bn_act / _group, effdet_sepconv_fused, effdet_maxpool_same and the *_parts / *_tiles queries): every
+ *     activation and GEMM weight is the unevaluated sum of two bfloat16 numbers, x ~ hi + lo with hi = bf16(x),
+ *     lo = bf16(x - hi) (16 significand bits), and a multiply is three bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate) -
+ *     float32-grade results (north_star's 1e-3 against the reference's float32 CPU path) without the 16x slower fp32 MFMA.
+ *     Layout: 8 consecutive channels (or 8 consecutive K of a weight row) are 32 bytes, [8 x bf16 hi][8 x bf16 lo]; a tensor
+ *     therefore has the shape, pitch and byte size of its float32 counterpart.  Pointers 16-byte aligned, channel counts
+ *     multiples of 8.  The kernel that PRODUCES a value splits it; ood_object_detection_amd/pairfmt.py packs weights.  The
+ *     reference computes this path in float32 (effdet/anchors.py:136, efficientdet.py:895-933): dtype 0 and dtype 2 both
+ *     stand for it, at different speeds;
  *   - return value: 0 on success, -22 (EINVAL) for a rejected argument, -5 (EIO) if the launch failed or if a kernel
  *     of an EARLIER call flagged a failure on the device (effdet_device_error);
  *   - thread-safe per stream; the only global mutable state is the device-side failure word.
@@ -28,6 +38,7 @@ extern "C" {
 
 #define EFFDET_F32 0
 #define EFFDET_BF16 1
+#define EFFDET_BF16X2 2          /* two-term bfloat16 values ("accurate" mode), see Conventions */
 
 /* ABI version of this header (bumped on any signature change). */
 int effdet_abi_version(void);
@@ -150,7 +161,9 @@ int effdet_maxpool_same(void* stream, int dtype, const void* X, long long x_imag
  *   dw_w [9][F] fp32; pw_w [N][F] (dtype); scale/shift [rows][N] fp32 indexed by affine_row[l]
  *   (scale may be NULL); out_ptr[l] + b*out_image_stride[l] + (y*W+x)*N.
  *   dtype 3 (= 1 | 2): bfloat16 inputs / weights, float32 OUTPUTS written straight from the accumulators (out pointers and
- *   strides then address float32 elements) - used for the box regressions, which decode reads as float32 (anchors.py:136). */
+ *   strides then address float32 elements) - used for the box regressions, which decode reads as float32 (anchors.py:136).
+ *   dtype 6 (= 2 | 4): two-term bf16 inputs / weights, plain float32 OUTPUTS (the accurate mode's class logits and box
+ *   regressions: what _post_process and decode read). */
 int effdet_sepconv_fused(void* stream, int dtype, int B, int nlevels, const int* level_hw, int n_in,
                          const void* const* in_ptr, const long long* in_image_stride, const int* in_hw,
                          const int* in_mode, int fuse_mode, const float* fuse_w, float fuse_den, int pre_act,

@@ -53,11 +53,14 @@ DEV float sigmoid_train(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin
 DEV float silu_train(float x) { return x * sigmoid_train(x); }
 #endif
 
+struct bf16p_t;                                     // the two-term bf16 dtype (below): hardware transcendentals like bf16
+template <typename T> struct FastMath { static constexpr bool value = sizeof(T) == 2; };
+template <> struct FastMath<bf16p_t> { static constexpr bool value = true; };
 template <typename T> DEV float silu_t(float x) {
-    if constexpr (sizeof(T) == 2) return fast_silu(x); else return silu_f(x);
+    if constexpr (FastMath<T>::value) return fast_silu(x); else return silu_f(x);
 }
 template <typename T> DEV float exp_t(float x) {
-    if constexpr (sizeof(T) == 2) return fast_exp(x); else return expf(x);
+    if constexpr (FastMath<T>::value) return fast_exp(x); else return expf(x);
 }
 
 // Folded BN + SiLU of the four accumulator values of a lane.  In bf16 throughput mode the non-transcendental part runs on
@@ -65,7 +68,7 @@ template <typename T> DEV float exp_t(float x) {
 // arithmetic - and therefore every bit of the result - is the same as four fast_silu(acc * sc + sh) calls.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <typename T> DEV f32x4 bn_silu4(const f32x4 acc, const f32x4 sc, const f32x4 sh) {
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (FastMath<T>::value) {
         const f32x2 x0 = f32x2{acc[0], acc[1]} * f32x2{sc[0], sc[1]} + f32x2{sh[0], sh[1]};
         const f32x2 x1 = f32x2{acc[2], acc[3]} * f32x2{sc[2], sc[3]} + f32x2{sh[2], sh[3]};
         const f32x2 t0 = x0 * -1.4426950408889634f, t1 = x1 * -1.4426950408889634f;
@@ -179,26 +182,102 @@ DEV void mma_chunk(const Frag<float>& a, const Frag<float>& b, f32x4& acc) {
     for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[s], b.v[s], acc, 0, 0, 0);
 }
 
+// ---------------------------------------------------------------------------------------------
+// dtype 2 (EFFDET_BF16X2, "accurate" mode): every value is the unevaluated sum of TWO bfloat16 numbers,
+//     x ~ hi + lo,   hi = bf16(x),   lo = bf16(x - hi)           (16 significand bits, relative error <= 2^-17)
+// and a product is three matrix-core instructions at the bf16 rate (hi*hi + hi*lo + lo*hi; the lo*lo term is below the
+// representation error) instead of the sixteen-times slower float32 MFMA.  Storage: 8 consecutive channels are 32 bytes,
+// [8 x bf16 hi][8 x bf16 lo] - so a tensor has the byte size and the channel pitch (4 bytes) of the float32 tensor of the same
+// shape, and a lane's MFMA operand piece (8 K values) is two adjacent 16-byte reads.  Channel counts are multiples of 8; only
+// whole groups (or their 4-channel halves) are addressable.  The splitting is done ONCE per value by the kernel that produces it.
+// ---------------------------------------------------------------------------------------------
+struct bf16p_t { unsigned raw; };                 // 4 bytes per channel: pointer arithmetic in channels works on group boundaries
+template <> struct VecTraits<bf16p_t> { static constexpr int EPC = 8; };
+template <> struct Frag<bf16p_t> { bf16x8 h, l; };
+template <> DEV Frag<bf16p_t> ld_frag<bf16p_t>(const void* p) {
+    Frag<bf16p_t> f;
+    f.h = *reinterpret_cast<const bf16x8*>(p);
+    f.l = *(reinterpret_cast<const bf16x8*>(p) + 1);
+    return f;
+}
+DEV void mma_chunk(const Frag<bf16p_t>& a, const Frag<bf16p_t>& b, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, acc, 0, 0, 0);        // small terms first
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.l, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, acc, 0, 0, 0);
+}
+// Geometry of an MFMA operand image per dtype: bytes of one lane's piece and of one K-chunk (4 pieces), elements per chunk
+template <typename T> struct OpGeom { static constexpr int PIECE = 16, CHUNK = 64, KPC = 64 / (int)sizeof(T); };
+template <> struct OpGeom<bf16p_t> { static constexpr int PIECE = 32, CHUNK = 128, KPC = 32; };
+template <typename T> struct IsPair { static constexpr bool value = false; };
+template <> struct IsPair<bf16p_t> { static constexpr bool value = true; };
+// kernels choose their bf16-style code paths (hardware transcendentals, depthwise on the matrix cores) by this, not by sizeof
+template <typename T> struct IsFast { static constexpr bool value = sizeof(T) == 2; };
+template <> struct IsFast<bf16p_t> { static constexpr bool value = true; };
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// four values -> 8 bytes of hi + 8 bytes of lo
+DEV void pair_split4(const f32x4 x, u32x2& hi, u32x2& lo) {
+    const bf16x4 h = {(bf16_t)x[0], (bf16_t)x[1], (bf16_t)x[2], (bf16_t)x[3]};
+    const bf16x4 l = {(bf16_t)(x[0] - (float)h[0]), (bf16_t)(x[1] - (float)h[1]), (bf16_t)(x[2] - (float)h[2]), (bf16_t)(x[3] - (float)h[3])};
+    hi = __builtin_bit_cast(u32x2, h); lo = __builtin_bit_cast(u32x2, l);
+}
+DEV void pair_split8(const F8& x, u32x4& hi, u32x4& lo) {
+    bf16x8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { h[e] = (bf16_t)x.v[e]; l[e] = (bf16_t)(x.v[e] - (float)h[e]); }
+    hi = __builtin_bit_cast(u32x4, h); lo = __builtin_bit_cast(u32x4, l);
+}
+DEV F8 pair_join8(const u32x4 hi, const u32x4 lo) {
+    const bf16x8 h = __builtin_bit_cast(bf16x8, hi), l = __builtin_bit_cast(bf16x8, lo);
+    F8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r.v[e] = (float)h[e] + (float)l[e];
+    return r;
+}
+template <> DEV F8 load8<bf16p_t>(const bf16p_t* p) {                      // p: a group boundary (channel % 8 == 0)
+    return pair_join8(*reinterpret_cast<const u32x4*>(p), *(reinterpret_cast<const u32x4*>(p) + 1));
+}
+template <> DEV void store8<bf16p_t>(bf16p_t* p, const F8& r) {
+    u32x4 hi, lo;
+    pair_split8(r, hi, lo);
+    *reinterpret_cast<u32x4*>(p) = hi;
+    *(reinterpret_cast<u32x4*>(p) + 1) = lo;
+}
+// 4 consecutive channels [ch, ch + 4) (ch % 4 == 0) of the row that starts at `row` (any 8-byte aligned address)
+template <typename T> DEV void row_store4(void* row, int ch, const f32x4 v) {
+    if constexpr (IsPair<T>::value) {
+        u32x2 hi, lo;
+        pair_split4(v, hi, lo);
+        char* g = reinterpret_cast<char*>(row) + (ch >> 3) * 32 + (ch & 7) * 2;
+        *reinterpret_cast<u32x2*>(g) = hi;
+        *reinterpret_cast<u32x2*>(g + 16) = lo;
+    } else {
+        store4<T>(reinterpret_cast<T*>(row) + ch, v[0], v[1], v[2], v[3]);
+    }
+}
+
 // mbconv_roll.hip (internal, hidden from the C ABI): rolling-window form of the fused MBConv front half, bf16 only.
 // parts = SE pool partial rows per image when the form applies to the geometry, 0 otherwise.
-__attribute__((visibility("hidden"))) int effdet_mbconv_roll_parts(int H, int W, int Cin, int mid, int k, int stride);
+// pair != 0: dtype 2 (two-term bf16) instead of bfloat16
+__attribute__((visibility("hidden"))) int effdet_mbconv_roll_parts(int H, int W, int Cin, int mid, int k, int stride, int pair = 0);
 __attribute__((visibility("hidden"))) int effdet_mbconv_roll_launch(hipStream_t st, const void* X, const float* in_gate, void* Y, const void* W1, const float* s1, const float* t1,
                               const float* taps, const float* s2, const float* t2, float* pool_partial,
-                              int B, int H, int W, int Cin, int mid, int k, int stride);
+                              int B, int H, int W, int Cin, int mid, int k, int stride, int pair = 0);
 
 // mbconv_wide.hip (internal): rolling-window form for inputs wider than 64 channels (X rows shared by a workgroup through an
 // LDS ring), bf16 only; parts = SE pool partial rows per image when the form applies to the geometry, 0 otherwise
-__attribute__((visibility("hidden"))) int effdet_mbconv_wide_parts(int H, int W, int Cin, int mid, int k, int stride);
+__attribute__((visibility("hidden"))) int effdet_mbconv_wide_parts(int H, int W, int Cin, int mid, int k, int stride, int pair = 0);
 __attribute__((visibility("hidden"))) int effdet_mbconv_wide_launch(hipStream_t st, const void* X, void* Y, const void* W1, const float* s1, const float* t1,
                               const float* taps, const float* s2, const float* t2, float* pool_partial,
-                              int B, int H, int W, int Cin, int mid, int k, int stride);
+                              int B, int H, int W, int Cin, int mid, int k, int stride, int pair = 0);
 
 // stem_roll.hip (internal): rolling-window form of the fused stem + stage-0 depthwise, bf16 only; parts = SE pool partial rows
 // per image when the form applies, 0 otherwise
-__attribute__((visibility("hidden"))) int effdet_stem_roll_parts(int H, int W, int C);
+__attribute__((visibility("hidden"))) int effdet_stem_roll_parts(int H, int W, int C, int pair = 0);
 __attribute__((visibility("hidden"))) int effdet_stem_roll_launch(hipStream_t st, int in_dtype, const void* X, const float* mean, const float* stdv,
                             const void* Wk, const float* s1, const float* t1, const float* taps, const float* s2, const float* t2,
-                            void* Y, float* pool_partial, int B, int H, int W, int C);
+                            void* Y, float* pool_partial, int B, int H, int W, int C, int pair = 0);
 
 // train_net.hip (internal): out[g][l] (+)= alpha * sum_s in[g][s][l], summed in a fixed order
 __attribute__((visibility("hidden"))) int effdet_launch_reduce_mid(hipStream_t st, const float* in, int G, int S, long long L, float* out,

@@ -429,7 +429,8 @@ extern "C" int effdet_train_se_gate(void* stream, const float* partial, int nblk
 extern "C" int effdet_maxpool_same(void* stream, int dtype, const void* X, long long x_image_stride,
                                    void* Y, long long y_image_stride, int B, int H, int W, int C) {
     EFFDET_ENTER();
-    if (!X || !Y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || (dtype & ~1)) return EFFDET_EINVAL;
+    if (!X || !Y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || dtype < 0 || dtype > 2) return EFFDET_EINVAL;
+    if (dtype == 2 && (reinterpret_cast<uintptr_t>(X) % 16 || reinterpret_cast<uintptr_t>(Y) % 16 || x_image_stride % 4 || y_image_stride % 4)) return EFFDET_EINVAL;
     PoolArgs a{X, Y, x_image_stride, y_image_stride, B, H, W, C, same_out(H, 2), same_out(W, 2),
                same_pad_before(H, 3, 2), same_pad_before(W, 3, 2)};
     if (a.x_image_stride <= 0) a.x_image_stride = (long long)H * W * C;
@@ -438,7 +439,8 @@ extern "C" int effdet_maxpool_same(void* stream, int dtype, const void* X, long 
     const long long blocks = (total + 255) / 256;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == 0) hipLaunchKernelGGL(maxpool_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else if (dtype == 1) hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(maxpool_kernel<bf16p_t>, dim3((unsigned)blocks), dim3(256), 0, st, a);   // two-term bf16: the maximum of stored values is a stored value
     return effdet_check_launch();
 }
 

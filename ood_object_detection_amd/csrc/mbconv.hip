@@ -848,8 +848,14 @@ int launch_mb(hipStream_t st, MbArgs& a) {
 }  // namespace
 
 extern "C" int effdet_mbconv_tiles_per_image(int dtype, int H, int W, int Cin, int mid, int k, int stride) {
-    if (H <= 0 || W <= 0 || Cin <= 0 || mid <= 0 || (k != 3 && k != 5) || (stride != 1 && stride != 2) || (dtype & ~1)) return EFFDET_EINVAL;
+    if (H <= 0 || W <= 0 || Cin <= 0 || mid <= 0 || (k != 3 && k != 5) || (stride != 1 && stride != 2) || dtype < 0 || dtype > 2) return EFFDET_EINVAL;
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
+    if (dtype == 2) {                                   // two-term bf16: the two rolling-window forms only
+        int parts = effdet_mbconv_roll_parts(H, W, Cin, mid, k, stride, 1);
+        if (parts > 0) return parts;
+        parts = effdet_mbconv_wide_parts(H, W, Cin, mid, k, stride, 1);
+        return parts > 0 ? parts : EFFDET_EINVAL;
+    }
     if (dtype == 1) {
         int parts = effdet_mbconv_roll_parts(H, W, Cin, mid, k, stride);
         if (parts > 0) return parts;
@@ -864,8 +870,12 @@ extern "C" int effdet_mbconv_tiles_per_image(int dtype, int H, int W, int Cin, i
 }
 
 extern "C" int effdet_mbconv_gated_tiles_per_image(int dtype, int H, int W, int Cin, int mid, int k, int stride) {
-    if (H <= 0 || W <= 0 || Cin <= 0 || mid <= 0 || (k != 3 && k != 5) || (stride != 1 && stride != 2) || (dtype & ~1)) return EFFDET_EINVAL;
+    if (H <= 0 || W <= 0 || Cin <= 0 || mid <= 0 || (k != 3 && k != 5) || (stride != 1 && stride != 2) || dtype < 0 || dtype > 2) return EFFDET_EINVAL;
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
+    if (dtype == 2) {
+        const int parts = effdet_mbconv_roll_parts(H, W, Cin, mid, k, stride, 1);
+        return parts > 0 ? parts : EFFDET_EINVAL;
+    }
     if (dtype == 1) {
         const int parts = effdet_mbconv_roll_parts(H, W, Cin, mid, k, stride);
         if (parts > 0) return parts;
@@ -880,7 +890,18 @@ static int mbconv_common(void* stream, int dtype, const void* X, const float* in
                          const float* s2, const float* t2, float* pool_partial,
                          int B, int H, int W, int Cin, int mid, int k, int stride) {
     if (!X || !Y || !W1 || !s1 || !t1 || !taps || !s2 || !t2 || B <= 0 || H <= 0 || W <= 0) return EFFDET_EINVAL;
-    if (Cin <= 0 || Cin % 8 || mid <= 0 || mid % 8 || (k != 3 && k != 5) || (stride != 1 && stride != 2) || (dtype & ~1)) return EFFDET_EINVAL;
+    if (Cin <= 0 || Cin % 8 || mid <= 0 || mid % 8 || (k != 3 && k != 5) || (stride != 1 && stride != 2) || dtype < 0 || dtype > 2) return EFFDET_EINVAL;
+    if (dtype == 2) {
+        // two-term bf16 (the "accurate" mode): the rolling-window forms with every operand in two terms; geometries outside them
+        // (no such layer in tf_efficientdet_d0 ... d2 at their sizes) are rejected - the caller then runs expand GEMM + depthwise
+        if (reinterpret_cast<uintptr_t>(X) % 16 || reinterpret_cast<uintptr_t>(Y) % 16 || reinterpret_cast<uintptr_t>(W1) % 16) return EFFDET_EINVAL;
+        hipStream_t st2 = reinterpret_cast<hipStream_t>(stream);
+        if (effdet_mbconv_roll_parts(H, W, Cin, mid, k, stride, 1) > 0)
+            return effdet_mbconv_roll_launch(st2, X, in_gate, Y, W1, s1, t1, taps, s2, t2, pool_partial, B, H, W, Cin, mid, k, stride, 1);
+        if (!in_gate && effdet_mbconv_wide_parts(H, W, Cin, mid, k, stride, 1) > 0)
+            return effdet_mbconv_wide_launch(st2, X, Y, W1, s1, t1, taps, s2, t2, pool_partial, B, H, W, Cin, mid, k, stride, 1);
+        return EFFDET_EINVAL;
+    }
     MbArgs a;
     a.X = X; a.in_gate = in_gate; a.Y = Y; a.W1 = W1; a.s1 = s1; a.t1 = t1; a.taps = taps; a.s2 = s2; a.t2 = t2; a.pool_partial = pool_partial;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.mid = mid; a.k = k; a.stride = stride;

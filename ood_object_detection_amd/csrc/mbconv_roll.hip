@@ -51,10 +51,14 @@ template <int V> struct IntC { static constexpr int value = V; };
 
 // NO = output tiles (16 px) per strip row: a compile-time count, so that every output row issues the same number of loads
 // and stores and the compiler can count them in its waits
-template <int KS, int S, int NKC, int MT, int NO>
-__global__ __launch_bounds__(512, (NKC <= 2 ? 4 : 3)) void mbconv_roll_kernel(RollArgs p) {
+// T: bf16_t, or bf16p_t (dtype 2, two-term bf16: X, W1, the expanded ring and Y carry hi + lo, every MFMA becomes three; NKC then
+// counts 128-byte chunks - still 32 channels each - and a ring pixel is 64 bytes = two 8-channel groups [8 hi][8 lo])
+template <int KS, int S, int NKC, int MT, int NO, typename T>
+__global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : (NKC <= 2 ? 4 : 3))) void mbconv_roll_kernel(RollArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    typedef bf16_t T;
+    constexpr bool PAIR = IsPair<T>::value;
+    constexpr int PB = OpGeom<T>::PIECE, CHB = OpGeom<T>::CHUNK;     // bytes of a lane's operand piece / of a 32-channel K-chunk
+    constexpr int PXB = 16 * (int)sizeof(T);                         // bytes of a ring pixel (16 channels)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: everything derived from it stays scalar
     const int frow = lane & 15, kg = lane >> 4;
     // blocks are dealt round-robin over the 8 XCDs: image = (round, xcd), so one image's workgroups share an L2
@@ -65,9 +69,9 @@ __global__ __launch_bounds__(512, (NKC <= 2 ? 4 : 3)) void mbconv_roll_kernel(Ro
     const int group = q % p.ngroups; q /= p.ngroups;
     const int strip = q % p.nstrips, band = q / p.nstrips;
     const int c0 = 16 * (group * p.wpg + wave);
-    const int cbytes = p.Cin * 2, mid = p.mid;
+    const int cbytes = p.Cin * (int)sizeof(T), mid = p.mid;
     char* ring = lds + wave * p.ring_bytes;
-    constexpr int rowbytes = MT * 512;                            // [MT * 16 px][16 ch] bf16
+    constexpr int rowbytes = MT * 16 * PXB;                       // [MT * 16 px][16 ch]
     constexpr int NTAP = KS * KS, NPAIR = (NTAP + 1) / 2;
     constexpr int OTN = NO;
 
@@ -79,11 +83,11 @@ __global__ __launch_bounds__(512, (NKC <= 2 ? 4 : 3)) void mbconv_roll_kernel(Ro
     f32x4 g0[NKC], g1[NKC];
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
-        const int off = kc * 64 + kg * 16;
+        const int off = kc * CHB + kg * PB;
         const bool kv = off < cbytes;
         wf[kc] = ld_frag<T>(reinterpret_cast<const char*>(p.W1) + (long long)(c0 + frow) * cbytes + (kv ? off : 0));
         if (gated) {
-            const float* g = p.in_gate + (long long)b * p.Cin + (kv ? off / 2 : 0);
+            const float* g = p.in_gate + (long long)b * p.Cin + (kv ? off / (int)sizeof(T) : 0);
             g0[kc] = *reinterpret_cast<const f32x4*>(g); g1[kc] = *reinterpret_cast<const f32x4*>(g + 4);
         }
     }
@@ -102,25 +106,52 @@ __global__ __launch_bounds__(512, (NKC <= 2 ? 4 : 3)) void mbconv_roll_kernel(Ro
     // is the SE gate of the producing block along K where that block's project conv was composed into W1
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
-        const bool kv = kc * 64 + kg * 16 < cbytes;
+        const bool kv = kc * CHB + kg * PB < cbytes;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float ge = gated ? (e < 4 ? g0[kc][e & 3] : g1[kc][e & 3]) : 1.f;
-            wf[kc].v[e] = kv ? (bf16_t)((float)wf[kc].v[e] * (rs1 * ge)) : (bf16_t)0.f;
+            if constexpr (PAIR) {                                 // scale the VALUE in float32, then split again
+                const float w = ((float)wf[kc].h[e] + (float)wf[kc].l[e]) * (rs1 * ge);
+                const bf16_t wh = (bf16_t)w;
+                wf[kc].h[e] = kv ? wh : (bf16_t)0.f;
+                wf[kc].l[e] = kv ? (bf16_t)(w - (float)wh) : (bf16_t)0.f;
+            } else {
+                wf[kc].v[e] = kv ? (bf16_t)((float)wf[kc].v[e] * (rs1 * ge)) : (bf16_t)0.f;
+            }
         }
     }
     // diagonal tap operands: the lane's single non-zero dword of diag(w[t0]) | diag(w[t1]), BN2's scale folded in
-    unsigned abits[NPAIR];
+    unsigned abits[NPAIR], abitl[PAIR ? NPAIR : 1];
 #pragma unroll
     for (int pr = 0; pr < NPAIR; ++pr) {
         const bool on = dactive && 2 * pr + hi < NTAP;
-        abits[pr] = on ? (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)(tapv[pr] * rs2)) << (16 * (frow & 1)) : 0u;
+        const float tw_ = tapv[pr] * rs2;
+        const bf16_t th_ = (bf16_t)tw_;
+        abits[pr] = on ? (unsigned)__builtin_bit_cast(unsigned short, th_) << (16 * (frow & 1)) : 0u;
+        if constexpr (PAIR) abitl[pr] = on ? (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)(tw_ - (float)th_)) << (16 * (frow & 1)) : 0u;
     }
+    // the lane's diagonal operand of tap pair pr, expanded from its one non-zero dword (two-term: one per term)
+    auto diag = [&](int pr) {
+        unsigned bits = abits[pr];
+        if constexpr (KS == 5) asm volatile("" : "+v"(bits));     // 13 resident operands (52 registers) do not fit: expanded at use
+        const u32x4 fr = {dq == 0 ? bits : 0u, dq == 1 ? bits : 0u, dq == 2 ? bits : 0u, dq == 3 ? bits : 0u};
+        Frag<T> af;
+        if constexpr (PAIR) {
+            unsigned bl = abitl[pr];
+            if constexpr (KS == 5) asm volatile("" : "+v"(bl));
+            const u32x4 fl = {dq == 0 ? bl : 0u, dq == 1 ? bl : 0u, dq == 2 ? bl : 0u, dq == 3 ? bl : 0u};
+            af.h = __builtin_bit_cast(bf16x8, fr);
+            af.l = __builtin_bit_cast(bf16x8, fl);
+        } else {
+            af.v = __builtin_bit_cast(bf16x8, fr);
+        }
+        return af;
+    };
 
     const int oy_b = band * p.band_rows, oy_e = min(p.Ho, oy_b + p.band_rows);
     const int ox0 = strip * p.TWo, tw = min(p.TWo, p.Wo - ox0);
     const int ix0 = ox0 * S - p.pad_l, iy_top = oy_b * S - p.pad_t;
-    char* const ring_e = ring + frow * 32 + kg * 8;           // expand store: pixel frow of a tile, channels 4*kg..
+    char* const ring_e = ring + frow * PXB;                   // expand store: pixel frow of a tile (channels 4*kg.. by row_store4)
     // Lane constants per tile, the same for every row.  Expand: column validity and byte offset inside an X row.  The loads
     // are UNCONDITIONAL (no exec branches between them and the waits): a pixel outside the strip / image reads a clamped,
     // valid pixel and is zeroed by the mask after the SiLU; the K tail beyond Cin of the last chunk reads the pixel's first
@@ -133,8 +164,8 @@ __global__ __launch_bounds__(512, (NKC <= 2 ? 4 : 3)) void mbconv_roll_kernel(Ro
         const int c = 16 * t + frow, ix = ix0 + c;
         const bool inside = c < p.IWs && ix >= 0 && ix < p.W;
         cmask[t] = inside ? 1.f : 0.f;
-        xoff[t] = inside ? ix * cbytes + kg * 16 : OOB;
-        xoffl[t] = (inside && (NKC - 1) * 64 + kg * 16 < cbytes) ? ix * cbytes + (NKC - 1) * 64 + kg * 16 : OOB;
+        xoff[t] = inside ? ix * cbytes + kg * PB : OOB;
+        xoffl[t] = (inside && (NKC - 1) * CHB + kg * PB < cbytes) ? ix * cbytes + (NKC - 1) * CHB + kg * PB : OOB;
     }
     const char* dl[OTN];
     const char* dlh[KS == 5 ? OTN : 1];                          // 5 x 5: base of a tap pair inside one window row (second tap = next pixel)
@@ -143,15 +174,16 @@ __global__ __launch_bounds__(512, (NKC <= 2 ? 4 : 3)) void mbconv_roll_kernel(Ro
     for (int u = 0; u < OTN; ++u) {
         const int oxl = 16 * u + frow;
         const bool ok = oxl < tw;
-        dl[u] = ring + (ok ? oxl * S * 32 : 0) + (kg & 1) * 16;   // invalid lanes read pixel 0 (finite), dropped at the store
-        if constexpr (KS == 5) dlh[u] = dl[u] + hi * 32;
-        yoff[u] = ok ? ((ox0 + oxl) * mid + c0 + 4 * kg) * 2 : OOB;
+        dl[u] = ring + (ok ? oxl * S * PXB : 0) + (kg & 1) * (PXB / 2);   // invalid lanes read pixel 0 (finite), dropped at the store
+        if constexpr (KS == 5) dlh[u] = dl[u] + hi * PXB;
+        // two-term: byte offset of the hi half of the lane's 4 channels inside their 8-channel group (lo: + 16)
+        yoff[u] = ok ? (PAIR ? (ox0 + oxl) * mid * 4 + ((c0 + 4 * kg) >> 3) * 32 + ((c0 + 4 * kg) & 7) * 2 : ((ox0 + oxl) * mid + c0 + 4 * kg) * 2) : OOB;
     }
     // buffer descriptors of this image's X and Y (wave-uniform: kernel arguments and blockIdx only)
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(p.X)) + (long long)b * p.H * p.W * cbytes, 0, p.H * p.W * cbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<char*>(p.Y) + (long long)b * p.Ho * p.Wo * mid * 2, 0, p.Ho * p.Wo * mid * 2, 0x00020000);
+        reinterpret_cast<char*>(p.Y) + (long long)b * p.Ho * p.Wo * mid * (int)sizeof(T), 0, p.Ho * p.Wo * mid * (int)sizeof(T), 0x00020000);
     // One input row = MT x NKC operand fragments, loaded a whole output row ahead of their use
     Frag<T> xq[S][MT][NKC];
     auto load_row = [&](int rel, Frag<T> (&dst)[MT][NKC]) {
@@ -162,9 +194,16 @@ __global__ __launch_bounds__(512, (NKC <= 2 ? 4 : 3)) void mbconv_roll_kernel(Ro
         for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int kc = 0; kc < NKC; ++kc) {
-                const u32x4 v = kc + 1 < NKC ? __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff[t] + kc * 64, rowoff, 0)
-                                             : __builtin_amdgcn_raw_buffer_load_b128(xrs, xoffl[t], rowoff, 0);
-                dst[t][kc].v = __builtin_bit_cast(bf16x8, v);
+                const int xo = kc + 1 < NKC ? xoff[t] + kc * CHB : xoffl[t];
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, xo, rowoff, 0);
+                if constexpr (PAIR) {
+                    // (an out-of-range offset + 16 stays out of range: OOB is far beyond num_records)
+                    const u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(xrs, xo + 16, rowoff, 0);
+                    dst[t][kc].h = __builtin_bit_cast(bf16x8, v);
+                    dst[t][kc].l = __builtin_bit_cast(bf16x8, v2);
+                } else {
+                    dst[t][kc].v = __builtin_bit_cast(bf16x8, v);
+                }
             }
     };
     auto expand_row = [&](int rel, int slot_bytes, const Frag<T> (&src)[MT][NKC]) {
@@ -176,10 +215,22 @@ __global__ __launch_bounds__(512, (NKC <= 2 ? 4 : 3)) void mbconv_roll_kernel(Ro
 #pragma unroll
             for (int kc = 0; kc < NKC; ++kc) mma_chunk(wf[kc], src[t][kc], acc);
             const f32x4 v = silu4_fast(acc) * (cmask[t] * rmask);
-            store4<T>(reinterpret_cast<T*>(ring_e + slot_bytes + 512 * t), v[0], v[1], v[2], v[3]);
+            row_store4<T>(ring_e + slot_bytes + 16 * PXB * t, 4 * kg, v);
         }
     };
 
+    // 4 channels of one output pixel -> Y (range-checked: an out-of-range offset drops the store; OOB + 16 is out of range too)
+    auto store_out = [&](const f32x4 ov, int yo, int yrow_) {
+        if constexpr (PAIR) {
+            u32x2 oh, ol;
+            pair_split4(ov, oh, ol);
+            __builtin_amdgcn_raw_buffer_store_b64(oh, yrs, yo, yrow_, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(ol, yrs, yo + 16, yrow_, 0);
+        } else {
+            const bf16x4 ob = {(bf16_t)ov[0], (bf16_t)ov[1], (bf16_t)ov[2], (bf16_t)ov[3]};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), yrs, yo, yrow_, 0);
+        }
+    };
     float pl[4] = {0.f, 0.f, 0.f, 0.f};
     int next_rel = 0;
     // prologue: the first KS - S rows of the band's window (ring slots 0 .. KS-S-1), loaded and expanded on the spot
@@ -190,8 +241,8 @@ __global__ __launch_bounds__(512, (NKC <= 2 ? 4 : 3)) void mbconv_roll_kernel(Ro
     }
 #pragma unroll
     for (int r = 0; r < S; ++r) load_row(next_rel + r, xq[r]);
-    int yrow = oy_b * p.Wo * mid * 2;                         // byte offset of the output row inside the image (scalar offset)
-    const int ypitch = p.Wo * mid * 2;
+    int yrow = oy_b * p.Wo * mid * (int)sizeof(T);            // byte offset of the output row inside the image (scalar offset)
+    const int ypitch = p.Wo * mid * (int)sizeof(T);
     int oy = oy_b;
     // One output row.  PH = ring slot of the first row of its KS-row window.
     auto step = [&](auto PHC) {
@@ -218,7 +269,7 @@ __global__ __launch_bounds__(512, (NKC <= 2 ? 4 : 3)) void mbconv_roll_kernel(Ro
             f32x4 acc[OTN];
 #pragma unroll
             for (int u = 0; u < OTN; ++u) acc[u] = t2v;
-            constexpr int G = 8 / OTN < NPAIR ? 8 / OTN : NPAIR;      // 8 B-operand fragments in flight: the X rows prefetched for the next step keep 24 - 32 registers
+            constexpr int G = 8 / OTN < NPAIR ? 8 / OTN : NPAIR;      // (two-term: the same count of twice as large fragments, with twice the registers)      // 8 B-operand fragments in flight: the X rows prefetched for the next step keep 24 - 32 registers
 #pragma unroll
             for (int p0 = 0; p0 < NPAIR; p0 += G) {
                 Frag<T> bq[G][OTN];
@@ -227,8 +278,8 @@ __global__ __launch_bounds__(512, (NKC <= 2 ? 4 : 3)) void mbconv_roll_kernel(Ro
                     const int pr = p0 + g;
                     if (pr < NPAIR) {
                         const int ta = 2 * pr, tb = 2 * pr + 1 < NTAP ? 2 * pr + 1 : 2 * pr;        // constants after unrolling
-                        const int offa = ((PH + ta / KS) % KS) * rowbytes + (ta % KS) * 32;
-                        const int offb = ((PH + tb / KS) % KS) * rowbytes + (tb % KS) * 32;
+                        const int offa = ((PH + ta / KS) % KS) * rowbytes + (ta % KS) * PXB;
+                        const int offb = ((PH + tb / KS) % KS) * rowbytes + (tb % KS) * PXB;
                         const bool same_row = ta / KS == tb / KS;
 #pragma unroll
                         for (int u = 0; u < OTN; ++u)
@@ -239,10 +290,7 @@ __global__ __launch_bounds__(512, (NKC <= 2 ? 4 : 3)) void mbconv_roll_kernel(Ro
                 for (int g = 0; g < G; ++g) {
                     const int pr = p0 + g;
                     if (pr < NPAIR) {
-                        unsigned bits = abits[pr];
-                        asm volatile("" : "+v"(bits));          // expanded at use: 13 resident operands (52 registers) do not fit
-                        const u32x4 fr = {dq == 0 ? bits : 0u, dq == 1 ? bits : 0u, dq == 2 ? bits : 0u, dq == 3 ? bits : 0u};
-                        Frag<T> af; af.v = __builtin_bit_cast(bf16x8, fr);
+                        const Frag<T> af = diag(pr);
 #pragma unroll
                         for (int u = 0; u < OTN; ++u) mma_chunk(af, bq[g][u], acc[u]);
                     }
@@ -256,10 +304,7 @@ __global__ __launch_bounds__(512, (NKC <= 2 ? 4 : 3)) void mbconv_roll_kernel(Ro
                 const float vm = yo == OOB ? 0.f : 1.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pl[r] += ov[r] * vm;
-                typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
-                typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
-                const bf16x4_ ob = {(bf16_t)ov[0], (bf16_t)ov[1], (bf16_t)ov[2], (bf16_t)ov[3]};
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, ob), yrs, yo, yrow, 0);
+                store_out(ov, yo, yrow);
             }
         } else {
 #pragma unroll
@@ -270,12 +315,9 @@ __global__ __launch_bounds__(512, (NKC <= 2 ? 4 : 3)) void mbconv_roll_kernel(Ro
                 for (int u = 0; u < OT; ++u) acc[u] = t2v;
 #pragma unroll
                 for (int pr = 0; pr < NPAIR; ++pr) {
-                    unsigned bits = abits[pr];
-                    if constexpr (KS == 5) asm volatile("" : "+v"(bits));   // 13 expanded operands would not fit the registers: expand at use
-                    const u32x4 fr = {dq == 0 ? bits : 0u, dq == 1 ? bits : 0u, dq == 2 ? bits : 0u, dq == 3 ? bits : 0u};
-                    Frag<T> af; af.v = __builtin_bit_cast(bf16x8, fr);
+                    const Frag<T> af = diag(pr);
                     const int ta = 2 * pr, tb = 2 * pr + 1 < NTAP ? 2 * pr + 1 : 0;        // constants after unrolling
-                    const int offa = ((PH + ta / KS) % KS) * rowbytes + (ta % KS) * 32, offb = ((PH + tb / KS) % KS) * rowbytes + (tb % KS) * 32;
+                    const int offa = ((PH + ta / KS) % KS) * rowbytes + (ta % KS) * PXB, offb = ((PH + tb / KS) % KS) * rowbytes + (tb % KS) * PXB;
                     const int off = hsel ? offb : offa;
 #pragma unroll
                     for (int u = 0; u < OT; ++u) {
@@ -292,10 +334,7 @@ __global__ __launch_bounds__(512, (NKC <= 2 ? 4 : 3)) void mbconv_roll_kernel(Ro
                         const float vm = yo == OOB ? 0.f : 1.f;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) pl[r] += ov[r] * vm;
-                        typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
-                        typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
-                        const bf16x4_ ob = {(bf16_t)ov[0], (bf16_t)ov[1], (bf16_t)ov[2], (bf16_t)ov[3]};
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, ob), yrs, yo, yrow, 0);
+                        store_out(ov, yo, yrow);
                     }
                 }
             }
@@ -336,11 +375,10 @@ struct RollGeometry { bool use; int TWo, nstrips, IWs, IWa, band_rows, nbands, w
 
 // Geometry depends on the map and channel sizes only - never on the batch - so that an image's result (including the order
 // in which its SE pool partials are summed) is the same at every batch size.
-RollGeometry pick_roll(int H, int W, int Cin, int mid, int k, int stride) {
+RollGeometry pick_roll(int H, int W, int Cin, int mid, int k, int stride, bool pair = false) {
     RollGeometry g{};
     g.use = false;
-    const int cbytes = Cin * 2;
-    g.nkc = (cbytes + 63) / 64;
+    g.nkc = (Cin + 31) / 32;                                    // K-chunks of 32 channels (64 bytes; two-term bf16: 128 bytes)
     // Inputs wider than 64 channels stay with mbconv.hip's band x channel-slice form.  Both ways of feeding such a layer to
     // 16-channel waves were built and measured on d0 (40 x 40 and 20 x 20 maps, round 2): X through each wave's own registers
     // (Cin / 32 fragments per pixel tile: no registers left to prefetch, 3 waves per SIMD) ran 1.3 - 2x slower, and X staged
@@ -368,7 +406,7 @@ RollGeometry pick_roll(int H, int W, int Cin, int mid, int k, int stride) {
         if (best < 0 || cost < best) { best = cost; g.TWo = two; g.nstrips = ns; g.IWs = iws; g.IWa = iwa; }
     }
     if (best < 0) return g;
-    g.ring_bytes = k * g.IWa * 32;
+    g.ring_bytes = k * g.IWa * (pair ? 64 : 32);
     // waves per workgroup: a divisor of the channel-tile count that packs the CU's 16 wave slots
     const int tiles = mid / 16;
     int bestfill = -1;
@@ -386,38 +424,38 @@ RollGeometry pick_roll(int H, int W, int Cin, int mid, int k, int stride) {
     return g;
 }
 
-template <int KS, int S, int NKC>
+template <int KS, int S, int NKC, typename T>
 void (*roll_kernel_for(int mt, int no))(RollArgs) {
     // MT = ceil(IWs / 16) input tiles, NO = ceil(TWo / 16) output tiles: stride 1 -> NO in {MT - 1, MT}; stride 2 -> MT in {2 NO - 1 .. 2 NO + 1}
     if constexpr (S == 1) {
-        if (mt == 2) return no == 1 ? mbconv_roll_kernel<KS, S, NKC, 2, 1> : no == 2 ? mbconv_roll_kernel<KS, S, NKC, 2, 2> : nullptr;
+        if (mt == 2) return no == 1 ? mbconv_roll_kernel<KS, S, NKC, 2, 1, T> : no == 2 ? mbconv_roll_kernel<KS, S, NKC, 2, 2, T> : nullptr;
         if constexpr (NKC <= 4) {
-            if (mt == 3) return no == 2 ? mbconv_roll_kernel<KS, S, NKC, 3, 2> : no == 3 ? mbconv_roll_kernel<KS, S, NKC, 3, 3> : nullptr;
+            if (mt == 3) return no == 2 ? mbconv_roll_kernel<KS, S, NKC, 3, 2, T> : no == 3 ? mbconv_roll_kernel<KS, S, NKC, 3, 3, T> : nullptr;
         }
         if constexpr (NKC <= 3 && KS == 3) {
-            if (mt == 4) return no == 3 ? mbconv_roll_kernel<KS, S, NKC, 4, 3> : no == 4 ? mbconv_roll_kernel<KS, S, NKC, 4, 4> : nullptr;
+            if (mt == 4) return no == 3 ? mbconv_roll_kernel<KS, S, NKC, 4, 3, T> : no == 4 ? mbconv_roll_kernel<KS, S, NKC, 4, 4, T> : nullptr;
         }
     } else {
         if constexpr (NKC <= 4) {
-            if (mt == 2) return no == 1 ? mbconv_roll_kernel<KS, S, NKC, 2, 1> : nullptr;
+            if (mt == 2) return no == 1 ? mbconv_roll_kernel<KS, S, NKC, 2, 1, T> : nullptr;
         }
         if constexpr (NKC == 1) {
-            if (mt == 3) return no == 1 ? mbconv_roll_kernel<KS, S, NKC, 3, 1> : no == 2 ? mbconv_roll_kernel<KS, S, NKC, 3, 2> : nullptr;
+            if (mt == 3) return no == 1 ? mbconv_roll_kernel<KS, S, NKC, 3, 1, T> : no == 2 ? mbconv_roll_kernel<KS, S, NKC, 3, 2, T> : nullptr;
             if constexpr (KS == 3) {
-                if (mt == 4) return no == 2 ? mbconv_roll_kernel<KS, S, NKC, 4, 2> : nullptr;
+                if (mt == 4) return no == 2 ? mbconv_roll_kernel<KS, S, NKC, 4, 2, T> : nullptr;
             }
         }
     }
     return nullptr;
 }
 
-template <int KS, int S>
+template <int KS, int S, typename T>
 int launch_roll_ks(hipStream_t st, const RollArgs& r, const RollGeometry& g) {
     void (*kern)(RollArgs) = nullptr;
     const int mt = g.IWa / 16, no = (g.TWo + 15) / 16;
     switch (g.nkc) {
-        case 1: kern = roll_kernel_for<KS, S, 1>(mt, no); break;
-        case 2: kern = roll_kernel_for<KS, S, 2>(mt, no); break;
+        case 1: kern = roll_kernel_for<KS, S, 1, T>(mt, no); break;
+        case 2: kern = roll_kernel_for<KS, S, 2, T>(mt, no); break;
         default: break;
     }
     if (kern == nullptr) return EFFDET_EINVAL;
@@ -433,19 +471,23 @@ int launch_roll_ks(hipStream_t st, const RollArgs& r, const RollGeometry& g) {
 }  // namespace
 
 // internal (not part of the C ABI): used by mbconv.hip's launcher
-int effdet_mbconv_roll_parts(int H, int W, int Cin, int mid, int k, int stride) {
-    const RollGeometry g = pick_roll(H, W, Cin, mid, k, stride);
+int effdet_mbconv_roll_parts(int H, int W, int Cin, int mid, int k, int stride, int pair) {
+    const RollGeometry g = pick_roll(H, W, Cin, mid, k, stride, pair != 0);
     return g.use ? g.nstrips * g.nbands : 0;
 }
 
 int effdet_mbconv_roll_launch(hipStream_t st, const void* X, const float* in_gate, void* Y, const void* W1, const float* s1, const float* t1,
                               const float* taps, const float* s2, const float* t2, float* pool_partial,
-                              int B, int H, int W, int Cin, int mid, int k, int stride) {
-    const RollGeometry g = pick_roll(H, W, Cin, mid, k, stride);
+                              int B, int H, int W, int Cin, int mid, int k, int stride, int pair) {
+    const RollGeometry g = pick_roll(H, W, Cin, mid, k, stride, pair != 0);
     if (!g.use) return EFFDET_EINVAL;
     RollArgs r{X, Y, W1, in_gate, s1, t1, taps, s2, t2, pool_partial, B, H, W, Cin, mid, same_out(H, stride), same_out(W, stride),
                same_pad_before(H, k, stride), same_pad_before(W, k, stride), g.TWo, g.nstrips, g.band_rows, g.nbands, g.IWs,
                g.wpg, g.ngroups, g.ring_bytes, g.nstrips * g.nbands * g.ngroups};
-    if (k == 3) return stride == 1 ? launch_roll_ks<3, 1>(st, r, g) : launch_roll_ks<3, 2>(st, r, g);
-    return stride == 1 ? launch_roll_ks<5, 1>(st, r, g) : launch_roll_ks<5, 2>(st, r, g);
+    if (pair) {
+        if (k == 3) return stride == 1 ? launch_roll_ks<3, 1, bf16p_t>(st, r, g) : launch_roll_ks<3, 2, bf16p_t>(st, r, g);
+        return stride == 1 ? launch_roll_ks<5, 1, bf16p_t>(st, r, g) : launch_roll_ks<5, 2, bf16p_t>(st, r, g);
+    }
+    if (k == 3) return stride == 1 ? launch_roll_ks<3, 1, bf16_t>(st, r, g) : launch_roll_ks<3, 2, bf16_t>(st, r, g);
+    return stride == 1 ? launch_roll_ks<5, 1, bf16_t>(st, r, g) : launch_roll_ks<5, 2, bf16_t>(st, r, g);
 }

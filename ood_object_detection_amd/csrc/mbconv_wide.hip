@@ -78,10 +78,14 @@ constexpr int WIDE_HDR = 64 + 1024;                // LDS header: arrival counte
 
 // KS taps per side, S stride, NKC = 64-byte K chunks of Cin, MT input tiles (16 px) per strip row, NO output tiles per strip
 // row, NPL = 16-byte X pieces a lane stages per row.  Register budget: 128 (up to 16 waves per CU)
-template <int KS, int S, int NKC, int MT, int NO, int NPL>
-__global__ __launch_bounds__(1024, 4) void mbconv_wide_kernel(WideArgs p) {
+// T: bf16_t, or bf16p_t (dtype 2, two-term bf16: X, W1, both rings and Y carry hi + lo, every MFMA becomes three; NKC then counts
+// 128-byte chunks - still 32 channels each; register budget 256, up to 8 waves per CU)
+template <int KS, int S, int NKC, int MT, int NO, int NPL, typename T>
+__global__ __launch_bounds__(1024, (IsPair<T>::value ? 2 : 4)) void mbconv_wide_kernel(WideArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    typedef bf16_t T;
+    constexpr bool PAIR = IsPair<T>::value;
+    constexpr int PB = OpGeom<T>::PIECE, CHB = OpGeom<T>::CHUNK;     // bytes of a lane's operand piece / of a 32-channel K-chunk
+    constexpr int PXB = 16 * (int)sizeof(T);                         // bytes of a ring pixel (16 channels)
     constexpr int NSX = 2 * S;                                 // X ring slots (rows)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: everything derived from it stays scalar
     const int frow = lane & 15, kg = lane >> 4;
@@ -93,11 +97,11 @@ __global__ __launch_bounds__(1024, 4) void mbconv_wide_kernel(WideArgs p) {
     const int group = q_ % p.ngroups; q_ /= p.ngroups;
     const int strip = q_ % p.nstrips, band = q_ / p.nstrips;
     const int c0 = 16 * (group * p.nw + wave);
-    const int cbytes = p.Cin * 2, mid = p.mid;
+    const int cbytes = p.Cin * (int)sizeof(T), mid = p.mid;
     int* const cnt = reinterpret_cast<int*>(lds);
     char* const xring = lds + p.x_off;
     char* const ring = lds + p.ring_off + wave * p.ring_bytes;
-    constexpr int rowbytes = MT * 512;                            // [MT * 16 px][16 ch] bf16
+    constexpr int rowbytes = MT * 16 * PXB;                       // [MT * 16 px][16 ch]
     constexpr int NTAP = KS * KS, NPAIR = (NTAP + 1) / 2;
 
     // ---- the whole LDS allocation starts as zeros: ring padding, K tails and the pixels beyond a strip are read (against
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(1024, 4) void mbconv_wide_kernel(WideArgs p) {
     const float rs1 = p.s1[c0 + frow], rs2 = p.s2[c0 + frow];
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
-        const int off = kc * 64 + kg * 16;
+        const int off = kc * CHB + kg * PB;
         wf[kc] = ld_frag<T>(reinterpret_cast<const char*>(p.W1) + (long long)(c0 + frow) * cbytes + (off < cbytes ? off : 0));
     }
     const int hi = kg >> 1;
@@ -125,25 +129,51 @@ __global__ __launch_bounds__(1024, 4) void mbconv_wide_kernel(WideArgs p) {
     const f32x4 t2v = *reinterpret_cast<const f32x4*>(p.t2 + c0 + 4 * kg);
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
-        const bool kv = kc * 64 + kg * 16 < cbytes;
+        const bool kv = kc * CHB + kg * PB < cbytes;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) wf[kc].v[e] = kv ? (bf16_t)((float)wf[kc].v[e] * rs1) : (bf16_t)0.f;
+        for (int e = 0; e < 8; ++e) {
+            if constexpr (PAIR) {                                 // scale the VALUE in float32, then split again
+                const float w = ((float)wf[kc].h[e] + (float)wf[kc].l[e]) * rs1;
+                const bf16_t wh = (bf16_t)w;
+                wf[kc].h[e] = kv ? wh : (bf16_t)0.f;
+                wf[kc].l[e] = kv ? (bf16_t)(w - (float)wh) : (bf16_t)0.f;
+            } else {
+                wf[kc].v[e] = kv ? (bf16_t)((float)wf[kc].v[e] * rs1) : (bf16_t)0.f;
+            }
+        }
     }
-    unsigned abits[NPAIR];
+    unsigned abits[NPAIR], abitl[PAIR ? NPAIR : 1];
 #pragma unroll
     for (int pr = 0; pr < NPAIR; ++pr) {
         const bool on = dactive && 2 * pr + hi < NTAP;
-        abits[pr] = on ? (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)(tapv[pr] * rs2)) << (16 * (frow & 1)) : 0u;
+        const float tw_ = tapv[pr] * rs2;
+        const bf16_t th_ = (bf16_t)tw_;
+        abits[pr] = on ? (unsigned)__builtin_bit_cast(unsigned short, th_) << (16 * (frow & 1)) : 0u;
+        if constexpr (PAIR) abitl[pr] = on ? (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)(tw_ - (float)th_)) << (16 * (frow & 1)) : 0u;
     }
+    // the lane's diagonal operand of tap pair pr, expanded from its one non-zero dword (two-term: one per term)
+    auto diag = [&](int pr, bool opaque) {
+        unsigned bits = abits[pr];
+        if (opaque) asm volatile("" : "+v"(bits));              // expanded at use: 13 resident operands (52 registers) do not fit
+        const u32x4 fr = {dq == 0 ? bits : 0u, dq == 1 ? bits : 0u, dq == 2 ? bits : 0u, dq == 3 ? bits : 0u};
+        Frag<T> af;
+        if constexpr (PAIR) {
+            unsigned bl = abitl[pr];
+            if (opaque) asm volatile("" : "+v"(bl));
+            const u32x4 fl = {dq == 0 ? bl : 0u, dq == 1 ? bl : 0u, dq == 2 ? bl : 0u, dq == 3 ? bl : 0u};
+            af.h = __builtin_bit_cast(bf16x8, fr);
+            af.l = __builtin_bit_cast(bf16x8, fl);
+        } else {
+            af.v = __builtin_bit_cast(bf16x8, fr);
+        }
+        return af;
+    };
     // 3 x 3: the five diagonal A operands stay expanded in registers for the whole band
     constexpr bool ARES = KS == 3;
     Frag<T> afr[ARES ? NPAIR : 1];
     if constexpr (ARES) {
 #pragma unroll
-        for (int pr = 0; pr < NPAIR; ++pr) {
-            const u32x4 fr = {dq == 0 ? abits[pr] : 0u, dq == 1 ? abits[pr] : 0u, dq == 2 ? abits[pr] : 0u, dq == 3 ? abits[pr] : 0u};
-            afr[pr].v = __builtin_bit_cast(bf16x8, fr);
-        }
+        for (int pr = 0; pr < NPAIR; ++pr) afr[pr] = diag(pr, false);
     }
 
     const int oy_b = band * p.band_rows, oy_e = min(p.Ho, oy_b + p.band_rows);
@@ -157,20 +187,21 @@ __global__ __launch_bounds__(1024, 4) void mbconv_wide_kernel(WideArgs p) {
         const int c = 16 * t + frow, ix = ix0 + c;
         cmask[t] = (c < p.IWs && ix >= 0 && ix < p.W) ? 0xFFFFFFFFu : 0u;
     }
-    const int xlane = frow * p.xpitch + kg * 16;                  // B operand of the expand: pixel frow of a tile, 16-byte piece kg of a chunk
+    const int xlane = frow * p.xpitch + kg * PB;                  // B operand of the expand: pixel frow of a tile, piece kg of a chunk
     const int xtile = 16 * p.xpitch;
-    char* const ring_e = ring + frow * 32 + kg * 8;               // expand store: pixel frow of a tile, channels 4*kg..
-    const char* const dl = ring + frow * S * 32 + (kg & 1) * 16;  // depthwise B operand of tile 0; tile u: + u * 16 * S * 32
-    const char* const dlh = dl + hi * 32;                         // ... for a pair of taps in one window row (second tap = next pixel)
+    char* const ring_e = ring + frow * PXB;                       // expand store: pixel frow of a tile (channels 4*kg.. by row_store4)
+    const char* const dl = ring + frow * S * PXB + (kg & 1) * (PXB / 2);  // depthwise B operand of tile 0; tile u: + u * 16 * S * PXB
+    const char* const dlh = dl + hi * PXB;                        // ... for a pair of taps in one window row (second tap = next pixel)
     // output offsets: all lanes of the tiles before the last are inside the strip
-    const int yoff0 = ((ox0 + frow) * mid + c0 + 4 * kg) * 2;
+    // (two-term: byte offset of the hi half of the lane's 4 channels inside their 8-channel group; lo: + 16)
+    const int yoff0 = PAIR ? (ox0 + frow) * mid * 4 + ((c0 + 4 * kg) >> 3) * 32 + ((c0 + 4 * kg) & 7) * 2 : ((ox0 + frow) * mid + c0 + 4 * kg) * 2;
     const bool ylast_ok = 16 * (NO - 1) + frow < tw;
     const float vlast = ylast_ok ? 1.f : 0.f;
     const int yoff_last = ylast_ok ? yoff0 : OOB;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(p.X)) + (long long)b * p.H * p.W * cbytes, 0, p.H * p.W * cbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<char*>(p.Y) + (long long)b * p.Ho * p.Wo * mid * 2, 0, p.Ho * p.Wo * mid * 2, 0x00020000);
+        reinterpret_cast<char*>(p.Y) + (long long)b * p.Ho * p.Wo * mid * (int)sizeof(T), 0, p.Ho * p.Wo * mid * (int)sizeof(T), 0x00020000);
 
     // ---- X staging: this lane's pieces of a row (the same for every row)
     int sgoff[NPL], sloff[NPL];
@@ -223,14 +254,14 @@ __global__ __launch_bounds__(1024, 4) void mbconv_wide_kernel(WideArgs p) {
         const int iy = iy_top + rel;
         if ((WIDE_ABLATE & 4) != 0 || iy < 0 || iy >= p.H) {       // TF-SAME pads the EXPANDED map: rows outside the image are zeros
 #pragma unroll
-            for (int t = 0; t < MT; ++t) store4<T>(reinterpret_cast<T*>(ring_e + slot_bytes + 512 * t), 0.f, 0.f, 0.f, 0.f);
+            for (int t = 0; t < MT; ++t) row_store4<T>(ring_e + slot_bytes + 16 * PXB * t, 4 * kg, f32x4{0.f, 0.f, 0.f, 0.f});
             return;
         }
         const char* xb = xring + (rel & (NSX - 1)) * p.xslot_bytes + xlane;
         // the B operands of tile t + 1 are requested right after the MFMAs of tile t, so their LDS latency hides behind tile t's SiLU
         Frag<T> xf[NKC];
 #pragma unroll
-        for (int kc = 0; kc < NKC; ++kc) xf[kc] = ld_frag<T>(xb + kc * 64);
+        for (int kc = 0; kc < NKC; ++kc) xf[kc] = ld_frag<T>(xb + kc * CHB);
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             f32x4 acc = sh1;
@@ -239,7 +270,7 @@ __global__ __launch_bounds__(1024, 4) void mbconv_wide_kernel(WideArgs p) {
             if (t + 1 < MT) {
                 xb += xtile;
 #pragma unroll
-                for (int kc = 0; kc < NKC; ++kc) xf[kc] = ld_frag<T>(xb + kc * 64);
+                for (int kc = 0; kc < NKC; ++kc) xf[kc] = ld_frag<T>(xb + kc * CHB);
             }
             __builtin_amdgcn_sched_barrier(0);
             // the inside-the-image mask as a bitwise AND with one register per tile (a packed multiply wants the mask duplicated into
@@ -248,9 +279,9 @@ __global__ __launch_bounds__(1024, 4) void mbconv_wide_kernel(WideArgs p) {
             const f32x4 a_ = act4_w(acc);
             const unsigned cm = cmask[t];
             const float e0 = a_[0], e1 = a_[1], e2 = a_[2], e3 = a_[3];
-            store4<T>(reinterpret_cast<T*>(ring_e + slot_bytes + 512 * t), __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e0) & cm),
-                      __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e1) & cm), __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e2) & cm),
-                      __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e3) & cm));
+            row_store4<T>(ring_e + slot_bytes + 16 * PXB * t, 4 * kg,
+                          f32x4{__builtin_bit_cast(float, __builtin_bit_cast(unsigned, e0) & cm), __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e1) & cm),
+                                __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e2) & cm), __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e3) & cm)});
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -275,9 +306,9 @@ __global__ __launch_bounds__(1024, 4) void mbconv_wide_kernel(WideArgs p) {
     next_rel = KS - S;
 
     float pl[4] = {0.f, 0.f, 0.f, 0.f};
-    int yrow = oy_b * p.Wo * mid * 2;                         // byte offset of the output row inside the image (scalar offset)
-    const int ypitch = p.Wo * mid * 2;
-    const int ytile = 16 * mid * 2;
+    int yrow = oy_b * p.Wo * mid * (int)sizeof(T);            // byte offset of the output row inside the image (scalar offset)
+    const int ypitch = p.Wo * mid * (int)sizeof(T);
+    const int ytile = 16 * mid * (int)sizeof(T);
     int oy = oy_b;
     // One output row.  PH = ring slot of the first row of its KS-row window.
     auto step = [&](auto PHC) {
@@ -299,7 +330,7 @@ __global__ __launch_bounds__(1024, 4) void mbconv_wide_kernel(WideArgs p) {
 #ifndef WIDE_G
 #define WIDE_G 12
 #endif
-        constexpr int G = WIDE_G / NO < NPAIR ? WIDE_G / NO : NPAIR;
+        constexpr int G = WIDE_G / NO < NPAIR ? WIDE_G / NO : NPAIR;     // (two-term: the same count of twice as large fragments, at twice the register budget)
 #pragma unroll
         for (int p0 = 0; p0 < ((WIDE_ABLATE & 2) ? 0 : NPAIR); p0 += G) {
             Frag<T> bq[G][NO];
@@ -308,12 +339,12 @@ __global__ __launch_bounds__(1024, 4) void mbconv_wide_kernel(WideArgs p) {
                 const int pr = p0 + g;
                 if (pr < NPAIR) {
                     const int ta = 2 * pr, tb = 2 * pr + 1 < NTAP ? 2 * pr + 1 : 2 * pr;        // constants after unrolling
-                    const int offa = ((PH + ta / KS) % KS) * rowbytes + (ta % KS) * 32;
-                    const int offb = ((PH + tb / KS) % KS) * rowbytes + (tb % KS) * 32;
+                    const int offa = ((PH + ta / KS) % KS) * rowbytes + (ta % KS) * PXB;
+                    const int offb = ((PH + tb / KS) % KS) * rowbytes + (tb % KS) * PXB;
                     const bool same_row = ta / KS == tb / KS;
                     const char* src = same_row ? dlh + offa : dl + offa + hsel * (offb - offa);
 #pragma unroll
-                    for (int u = 0; u < NO; ++u) bq[g][u] = ld_frag<T>(src + u * (16 * S * 32));
+                    for (int u = 0; u < NO; ++u) bq[g][u] = ld_frag<T>(src + u * (16 * S * PXB));
                 }
             }
 #pragma unroll
@@ -321,14 +352,7 @@ __global__ __launch_bounds__(1024, 4) void mbconv_wide_kernel(WideArgs p) {
                 const int pr = p0 + g;
                 if (pr < NPAIR) {
                     Frag<T> af;
-                    if constexpr (ARES) {
-                        af = afr[pr];
-                    } else {
-                        unsigned bits = abits[pr];
-                        asm volatile("" : "+v"(bits));          // expanded at use: 13 resident operands (52 registers) do not fit
-                        const u32x4 fr = {dq == 0 ? bits : 0u, dq == 1 ? bits : 0u, dq == 2 ? bits : 0u, dq == 3 ? bits : 0u};
-                        af.v = __builtin_bit_cast(bf16x8, fr);
-                    }
+                    if constexpr (ARES) af = afr[pr]; else af = diag(pr, true);
 #pragma unroll
                     for (int u = 0; u < NO; ++u) mma_chunk(af, bq[g][u], acc[u]);
                 }
@@ -346,10 +370,16 @@ __global__ __launch_bounds__(1024, 4) void mbconv_wide_kernel(WideArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pl[r] += ov[r];
             }
-            typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
-            typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
-            const bf16x4_ ob = {(bf16_t)ov[0], (bf16_t)ov[1], (bf16_t)ov[2], (bf16_t)ov[3]};
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, ob), yrs, last ? yoff_last : yoff0, yrow + u * ytile, 0);
+            const int yo = last ? yoff_last : yoff0;
+            if constexpr (PAIR) {                               // (an out-of-range offset + 16 is out of range too: the store is dropped)
+                u32x2 oh, ol;
+                pair_split4(ov, oh, ol);
+                __builtin_amdgcn_raw_buffer_store_b64(oh, yrs, yo, yrow + u * ytile, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(ol, yrs, yo + 16, yrow + u * ytile, 0);
+            } else {
+                const bf16x4 ob = {(bf16_t)ov[0], (bf16_t)ov[1], (bf16_t)ov[2], (bf16_t)ov[3]};
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), yrs, yo, yrow + u * ytile, 0);
+            }
         }
         yrow += ypitch;
         ++oy;
@@ -388,11 +418,12 @@ struct WideGeometry {
 
 // Geometry depends on the map and channel sizes only - never on the batch - so that an image's result (including the order
 // in which its SE pool partials are summed) is the same at every batch size.
-WideGeometry pick_wide(int H, int W, int Cin, int mid, int k, int stride) {
+WideGeometry pick_wide(int H, int W, int Cin, int mid, int k, int stride, bool pair = false) {
     WideGeometry g{};
     g.use = false;
-    const int cbytes = Cin * 2;
-    g.nkc = (cbytes + 63) / 64;
+    const int esz = pair ? 4 : 2, pxb = 16 * esz;                  // bytes per channel / per 16-channel ring pixel
+    const int cbytes = Cin * esz;
+    g.nkc = (Cin + 31) / 32;                                    // K-chunks of 32 channels (64 bytes; two-term bf16: 128 bytes)
     if ((g.nkc < 3 || g.nkc > 6) || mid % 16 || Cin % 8) return g;        // narrower inputs: mbconv_roll.hip; wider: the band x slice form
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
     // one strip per row where the row fits 64 input pixels, else equal strips
@@ -401,7 +432,7 @@ WideGeometry pick_wide(int H, int W, int Cin, int mid, int k, int stride) {
         const int two = (Wo + ns - 1) / ns;
         if ((ns - 1) * two >= Wo) continue;
         const int iws = (two - 1) * stride + k;
-        if (iws > (k == 5 ? 48 : 64)) continue;
+        if (iws > (pair ? 32 : (k == 5 ? 48 : 64))) continue;       // (two-term: rings are twice as large per pixel - narrower strips)
         best_ns = ns; g.TWo = two; g.IWs = iws; g.IWa = (iws + 15) / 16 * 16;
         break;
     }
@@ -415,9 +446,9 @@ WideGeometry pick_wide(int H, int W, int Cin, int mid, int k, int stride) {
     {
         const double we = stride * mt * (1.0 + 0.06 * g.nkc), wd = no * (1.2 + 0.05 * ((k * k + 1) / 2));   // relative cost of the two phases
         const double use = (we * g.IWs / (16.0 * mt) + wd * g.TWo / (16.0 * no)) / (we + wd);
-        if (use < 0.75) return g;
+        if (use < 0.75 && !pair) return g;                          // (the two-term mode has no band x slice form to fall back to)
     }
-    g.ring_bytes = k * g.IWa * 32;
+    g.ring_bytes = k * g.IWa * pxb;
     // X ring: pixel pitch = Cin bytes rounded up to 16 * (2 mod 4): the 16-lane groups of ds_read_b128 then touch 16 distinct
     // 16-byte slots of the 256-byte bank row (conflict-free B operand reads)
     int P = cbytes / 16;
@@ -435,7 +466,7 @@ WideGeometry pick_wide(int H, int W, int Cin, int mid, int k, int stride) {
     const size_t budget = 160 * 1024;
     // lanes beyond the strip's last output pixel read (and drop) ring pixels up to (16 NO - 1) S + k - 1: the last wave's last
     // ring row needs that much readable, zeroed LDS behind it
-    const int over = ((16 * no - 1) * stride + k) * 32 - g.IWa * 32;
+    const int over = ((16 * no - 1) * stride + k) * pxb - g.IWa * pxb;
     const size_t tail_pad = (size_t)((over > 0 ? over : 0) + 64 + 15) / 16 * 16;
     const int npair = (k * k + 1) / 2;
     const double ce = mt * (1.0 + 0.06 * g.nkc), cd = no * (1.2 + 0.05 * npair);
@@ -444,9 +475,11 @@ WideGeometry pick_wide(int H, int W, int Cin, int mid, int k, int stride) {
         if (tiles % d) continue;
         const size_t l = WIDE_HDR + xbytes + (size_t)d * g.ring_bytes + tail_pad;
         if (l > budget) continue;
-        if ((g.IWs * (cbytes / 16) + d * 64 - 1) / (d * 64) > 1) continue;       // one 16-byte piece per lane and row
+        const int npl = (g.IWs * (cbytes / 16) + d * 64 - 1) / (d * 64);          // 16-byte X pieces a lane stages per row
+        if (npl > (pair ? 4 : 1)) continue;                                        // bf16: one piece per lane and row
         int cap = (int)(budget / l);
-        const int rcap = 16 / d;                                                   // register budget: 128 VGPRs = 16 waves per CU
+        const int rcap = (pair ? 8 : 16) / d;                                      // register budget: 128 (two-term: 256) VGPRs = 16 (8) waves per CU
+        if (rcap < 1) continue;
         if (cap > rcap) cap = rcap;
         for (int per_cu = 1; per_cu <= cap; ++per_cu) {
             for (int nb = 1; nb <= 4; ++nb) {
@@ -459,7 +492,7 @@ WideGeometry pick_wide(int H, int W, int Cin, int mid, int k, int stride) {
                 const int waves = conc * d;
                 const double cost = (double)((L + per_cu - 1) / per_cu) * (rows * (stride * ce + cd) + (k - stride) * ce) * (waves > 8 ? waves : 8);
                 if (best < 0 || cost < best * 0.999 || (cost < best * 1.001 && d > g.nw)) {
-                    best = cost; g.nw = d; g.wg_per_cu = per_cu; g.lds = l; g.nbands = nbe; g.band_rows = rows;
+                    best = cost; g.nw = d; g.wg_per_cu = per_cu; g.lds = l; g.nbands = nbe; g.band_rows = rows; g.npl = npl;
                 }
             }
         }
@@ -479,40 +512,59 @@ WideGeometry pick_wide(int H, int W, int Cin, int mid, int k, int stride) {
     }
 #endif
     g.ngroups = tiles / g.nw;
-    g.npl = 1;
     g.use = true;
     return g;
 }
 
-template <int KS, int S, int NKC, int MT, int NO>
+template <int KS, int S, int NKC, int MT, int NO, typename T>
 void (*wide_kernel_npl(int npl))(WideArgs) {
-    return npl == 1 ? mbconv_wide_kernel<KS, S, NKC, MT, NO, 1> : nullptr;
+    if constexpr (IsPair<T>::value) {
+        switch (npl) {
+            case 1: return mbconv_wide_kernel<KS, S, NKC, MT, NO, 1, T>;
+            case 2: return mbconv_wide_kernel<KS, S, NKC, MT, NO, 2, T>;
+            case 3: return mbconv_wide_kernel<KS, S, NKC, MT, NO, 3, T>;
+            case 4: return mbconv_wide_kernel<KS, S, NKC, MT, NO, 4, T>;
+            default: return nullptr;
+        }
+    } else {
+        return npl == 1 ? mbconv_wide_kernel<KS, S, NKC, MT, NO, 1, T> : nullptr;
+    }
 }
 
-template <int KS, int S, int NKC>
+template <int KS, int S, int NKC, typename T>
 void (*wide_kernel_for(int mt, int no, int npl))(WideArgs) {
     // MT = ceil(IWs / 16) input tiles, NO = ceil(TWo / 16) output tiles
     if constexpr (S == 1) {
-        if (mt == 2) return no == 1 ? wide_kernel_npl<KS, S, NKC, 2, 1>(npl) : no == 2 ? wide_kernel_npl<KS, S, NKC, 2, 2>(npl) : nullptr;
-        if (mt == 3) return no == 2 ? wide_kernel_npl<KS, S, NKC, 3, 2>(npl) : no == 3 ? wide_kernel_npl<KS, S, NKC, 3, 3>(npl) : nullptr;
-        if (mt == 4) return no == 3 ? wide_kernel_npl<KS, S, NKC, 4, 3>(npl) : no == 4 ? wide_kernel_npl<KS, S, NKC, 4, 4>(npl) : nullptr;
+        if (mt == 2) return no == 1 ? wide_kernel_npl<KS, S, NKC, 2, 1, T>(npl) : no == 2 ? wide_kernel_npl<KS, S, NKC, 2, 2, T>(npl) : nullptr;
+        if (mt == 3) return no == 2 ? wide_kernel_npl<KS, S, NKC, 3, 2, T>(npl) : no == 3 ? wide_kernel_npl<KS, S, NKC, 3, 3, T>(npl) : nullptr;
+        if (mt == 4) return no == 3 ? wide_kernel_npl<KS, S, NKC, 4, 3, T>(npl) : no == 4 ? wide_kernel_npl<KS, S, NKC, 4, 4, T>(npl) : nullptr;
     } else {
-        if (mt == 2) return no == 1 ? wide_kernel_npl<KS, S, NKC, 2, 1>(npl) : nullptr;
-        if (mt == 3) return no == 1 ? wide_kernel_npl<KS, S, NKC, 3, 1>(npl) : no == 2 ? wide_kernel_npl<KS, S, NKC, 3, 2>(npl) : nullptr;
-        if (mt == 4) return no == 2 ? wide_kernel_npl<KS, S, NKC, 4, 2>(npl) : nullptr;
+        if (mt == 2) return no == 1 ? wide_kernel_npl<KS, S, NKC, 2, 1, T>(npl) : nullptr;
+        if (mt == 3) return no == 1 ? wide_kernel_npl<KS, S, NKC, 3, 1, T>(npl) : no == 2 ? wide_kernel_npl<KS, S, NKC, 3, 2, T>(npl) : nullptr;
+        if (mt == 4) return no == 2 ? wide_kernel_npl<KS, S, NKC, 4, 2, T>(npl) : nullptr;
     }
     return nullptr;
 }
 
-template <int KS, int S>
+template <int KS, int S, typename T>
 int launch_wide_ks(hipStream_t st, const WideArgs& r, const WideGeometry& g) {
     void (*kern)(WideArgs) = nullptr;
     const int mt = g.IWa / 16, no = (g.TWo + 15) / 16;
+    if constexpr (IsPair<T>::value) {
+        if (mt != 2) return EFFDET_EINVAL;                        // two-term strips are at most 32 input pixels wide
+        switch (g.nkc) {
+            case 3: kern = no == 1 ? wide_kernel_npl<KS, S, 3, 2, 1, T>(g.npl) : (no == 2 && S == 1) ? wide_kernel_npl<KS, S, 3, 2, 2, T>(g.npl) : nullptr; break;
+            case 4: kern = no == 1 ? wide_kernel_npl<KS, S, 4, 2, 1, T>(g.npl) : (no == 2 && S == 1) ? wide_kernel_npl<KS, S, 4, 2, 2, T>(g.npl) : nullptr; break;
+            case 5: kern = no == 1 ? wide_kernel_npl<KS, S, 5, 2, 1, T>(g.npl) : (no == 2 && S == 1) ? wide_kernel_npl<KS, S, 5, 2, 2, T>(g.npl) : nullptr; break;
+            case 6: kern = no == 1 ? wide_kernel_npl<KS, S, 6, 2, 1, T>(g.npl) : (no == 2 && S == 1) ? wide_kernel_npl<KS, S, 6, 2, 2, T>(g.npl) : nullptr; break;
+            default: break;
+        }
+    } else
     switch (g.nkc) {
-        case 3: kern = wide_kernel_for<KS, S, 3>(mt, no, g.npl); break;
-        case 4: kern = wide_kernel_for<KS, S, 4>(mt, no, g.npl); break;
-        case 5: kern = wide_kernel_for<KS, S, 5>(mt, no, g.npl); break;
-        case 6: kern = wide_kernel_for<KS, S, 6>(mt, no, g.npl); break;
+        case 3: kern = wide_kernel_for<KS, S, 3, T>(mt, no, g.npl); break;
+        case 4: kern = wide_kernel_for<KS, S, 4, T>(mt, no, g.npl); break;
+        case 5: kern = wide_kernel_for<KS, S, 5, T>(mt, no, g.npl); break;
+        case 6: kern = wide_kernel_for<KS, S, 6, T>(mt, no, g.npl); break;
         default: break;
     }
     if (kern == nullptr) return EFFDET_EINVAL;
@@ -535,15 +587,15 @@ bool wide_supported(const WideGeometry& g, int k, int stride) {
 }  // namespace
 
 // internal (not part of the C ABI): used by mbconv.hip's launcher
-int effdet_mbconv_wide_parts(int H, int W, int Cin, int mid, int k, int stride) {
-    const WideGeometry g = pick_wide(H, W, Cin, mid, k, stride);
+int effdet_mbconv_wide_parts(int H, int W, int Cin, int mid, int k, int stride, int pair) {
+    const WideGeometry g = pick_wide(H, W, Cin, mid, k, stride, pair != 0);
     return wide_supported(g, k, stride) ? g.nstrips * g.nbands : 0;
 }
 
 int effdet_mbconv_wide_launch(hipStream_t st, const void* X, void* Y, const void* W1, const float* s1, const float* t1,
                               const float* taps, const float* s2, const float* t2, float* pool_partial,
-                              int B, int H, int W, int Cin, int mid, int k, int stride) {
-    const WideGeometry g = pick_wide(H, W, Cin, mid, k, stride);
+                              int B, int H, int W, int Cin, int mid, int k, int stride, int pair) {
+    const WideGeometry g = pick_wide(H, W, Cin, mid, k, stride, pair != 0);
     if (!wide_supported(g, k, stride)) return EFFDET_EINVAL;
 #ifdef WIDE_TUNE
     static thread_local long long printed_ = -1;
@@ -559,10 +611,14 @@ int effdet_mbconv_wide_launch(hipStream_t st, const void* X, void* Y, const void
     r.pad_t = same_pad_before(H, k, stride); r.pad_l = same_pad_before(W, k, stride);
     r.TWo = g.TWo; r.nstrips = g.nstrips; r.band_rows = g.band_rows; r.nbands = g.nbands; r.IWs = g.IWs; r.nw = g.nw; r.ngroups = g.ngroups;
     r.ring_bytes = g.ring_bytes; r.per_image = g.nstrips * g.nbands * g.ngroups;
-    r.xpitch = g.xpitch; r.xslot_bytes = g.xslot_bytes; r.ppr = Cin * 2 / 16; r.pieces_row = g.IWs * r.ppr;
+    r.xpitch = g.xpitch; r.xslot_bytes = g.xslot_bytes; r.ppr = Cin * (pair ? 4 : 2) / 16; r.pieces_row = g.IWs * r.ppr;
     r.x_off = WIDE_HDR; r.ring_off = WIDE_HDR + 2 * stride * g.xslot_bytes; r.lds_bytes = (int)g.lds;
     r.fd_ppr = make_fastdiv(r.ppr);
     r.err_word = effdet_device_error_word();
-    if (k == 3) return stride == 1 ? launch_wide_ks<3, 1>(st, r, g) : launch_wide_ks<3, 2>(st, r, g);
-    return stride == 1 ? launch_wide_ks<5, 1>(st, r, g) : launch_wide_ks<5, 2>(st, r, g);
+    if (pair) {
+        if (k == 3) return stride == 1 ? launch_wide_ks<3, 1, bf16p_t>(st, r, g) : launch_wide_ks<3, 2, bf16p_t>(st, r, g);
+        return stride == 1 ? launch_wide_ks<5, 1, bf16p_t>(st, r, g) : launch_wide_ks<5, 2, bf16p_t>(st, r, g);
+    }
+    if (k == 3) return stride == 1 ? launch_wide_ks<3, 1, bf16_t>(st, r, g) : launch_wide_ks<3, 2, bf16_t>(st, r, g);
+    return stride == 1 ? launch_wide_ks<5, 1, bf16_t>(st, r, g) : launch_wide_ks<5, 2, bf16_t>(st, r, g);
 }

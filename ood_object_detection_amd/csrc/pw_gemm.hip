@@ -48,16 +48,20 @@ constexpr int PW_PIX = 128;                      // pixels per workgroup: 4 wave
 template <typename T, int BN, int PT, int NTH, bool GATED>
 DEV void pw_gemm_body(const PwArgs& p, const int bid) {
     // 64-byte K-chunks per pipeline stage (PW_KCH_SMALL: the 512-thread small-map form; 4 in a variant build for A/B timing)
-    constexpr int KCH = (PT == 1 && NTH == 512) ? PW_KCH_SMALL : 2;
-    constexpr int EPC = VecTraits<T>::EPC;          // elements per 16-byte piece
-    constexpr int KPC = 64 / (int)sizeof(T);        // elements per 64-byte K-chunk
+    // (two-term bf16: ONE 128-byte chunk = 32 K values in two terms per stage - the same bytes per pixel and stage, and the same
+    // number of operand registers in the A ring, as the two 64-byte chunks of the other dtypes)
+    constexpr bool PAIR = IsPair<T>::value;
+    constexpr int KCH = PAIR ? 1 : ((PT == 1 && NTH == 512) ? PW_KCH_SMALL : 2);
+    constexpr int EPC = VecTraits<T>::EPC;          // elements per operand piece
+    constexpr int KPC = OpGeom<T>::KPC;             // elements per K-chunk
+    constexpr int PB = OpGeom<T>::PIECE, CB = OpGeom<T>::CHUNK;   // bytes of a lane's operand piece / of a K-chunk (16 / 64; two-term: 32 / 128)
     constexpr int NT = BN / 16, NP = NT / 2;
     static_assert(NT % 2 == 0, "tile pairs");
     // A stages (128 bytes of K per pixel) in flight ahead of the one being multiplied: as many as the registers
     // left over by the accumulators allow - the late layers are latency bound, not bandwidth bound
     // two stages everywhere; PW_PF_SMALL = 4 (a variant build) deepens the ring of the 512-thread small-map form - measured slower
     constexpr int PF = (PT == 1 && NTH == 512) ? PW_PF_SMALL : 2;
-    constexpr int ROWB = KCH * 64 + 16;             // bytes per LDS row: one stage of K + 16 pad
+    constexpr int ROWB = KCH * CB + 16;             // bytes per LDS row: one stage of K + 16 pad
     constexpr int W_BYTES = BN * ROWB;
     __shared__ __attribute__((aligned(16))) char lds[2 * W_BYTES];
     extern __shared__ __attribute__((aligned(16))) float gate_lds[];   // GATED: this image's SE gate, all K channels (dynamic: K floats)
@@ -72,7 +76,7 @@ DEV void pw_gemm_body(const PwArgs& p, const int bid) {
     const int n0 = nt * BN;
     const int n_count = (N - n0) < BN ? (N - n0) : BN;
     const long long pitch = (long long)K * (long long)sizeof(T);
-    const int nkc = (K + KPC - 1) / KPC;            // 64-byte chunks
+    const int nkc = (K + KPC - 1) / KPC;            // K-chunks
     const int nst = (nkc + KCH - 1) / KCH;          // pipeline stages
     const int kbytes = K * (int)sizeof(T);
 
@@ -92,7 +96,7 @@ DEV void pw_gemm_body(const PwArgs& p, const int bid) {
     auto a_load = [&](int stg, int slot) {
 #pragma unroll
         for (int sub = 0; sub < KCH; ++sub) {
-            const int off = (stg * KCH + sub) * 64 + fpiece * 16;
+            const int off = (stg * KCH + sub) * CB + fpiece * PB;
             // a lane past the end of K re-reads the row start (always in bounds, finite activations): its products meet the zeroed
             // W pieces of the K tail.  No select on the loaded value here - it would make the stage wait for its own prefetch.
             const int offc = off < kbytes ? off : 0;
@@ -107,7 +111,8 @@ DEV void pw_gemm_body(const PwArgs& p, const int bid) {
     constexpr int PPR = KCH * 4;
     constexpr int W_PER_THREAD = (BN * PPR + NTH - 1) / NTH;
     auto lds_row = [](int co) { return 16 * (2 * (co >> 5) + ((co >> 2) & 1)) + 4 * ((co >> 3) & 3) + (co & 3); };
-    u32x4 w_reg[W_PER_THREAD];
+    constexpr int WV = PB / 16;                      // 16-byte loads per piece
+    u32x4 w_reg[W_PER_THREAD][WV];
     if constexpr (GATED) {                          // the gate goes to LDS once (published by the barrier in the prologue)
         for (int k = tid * 4; k < K; k += NTH * 4) *reinterpret_cast<f32x4*>(gate_lds + k) = *reinterpret_cast<const f32x4*>(gate + k);
     }
@@ -125,7 +130,9 @@ DEV void pw_gemm_body(const PwArgs& p, const int bid) {
             const int ke = stg * KCH * KPC + piece * EPC;
             const bool ok = co < n_count && ke < K;
             const int coc = ok ? co : 0, kec = ok ? ke : 0;
-            w_reg[q] = *reinterpret_cast<const u32x4*>(Wb + (long long)(n0 + coc) * pitch + (long long)kec * sizeof(T));
+            const u32x4* src = reinterpret_cast<const u32x4*>(Wb + (long long)(n0 + coc) * pitch + (long long)kec * sizeof(T));
+#pragma unroll
+            for (int h = 0; h < WV; ++h) w_reg[q][h] = src[h];
         }
     };
     auto w_store = [&](int buf, int stg) {            // the out-of-range pieces (N tail rows, K tail) become zeros HERE, not at the load
@@ -134,29 +141,39 @@ DEV void pw_gemm_body(const PwArgs& p, const int bid) {
         for (int q = 0; q < W_PER_THREAD; ++q) {
             const int idx = tid + NTH * q < BN * PPR ? tid + NTH * q : BN * PPR - 1;
             {
-                u32x4 v = w_reg[q];
                 // (a bitwise AND, not a select: a select lets the compiler sink the LOAD into the in-range branch, and a load behind an
                 // exec-mask branch ends every counted wait)
                 const unsigned keep = (idx / PPR < n_count && stg * KCH * KPC + (idx % PPR) * EPC < K) ? 0xFFFFFFFFu : 0u;
-                v = v & u32x4{keep, keep, keep, keep};
+                u32x4 v[WV];
+#pragma unroll
+                for (int h = 0; h < WV; ++h) v[h] = w_reg[q][h] & u32x4{keep, keep, keep, keep};
                 if constexpr (GATED) {
                     const int kg_ = stg * KCH * KPC + (idx % PPR) * EPC;
                     const int kgc = kg_ < K ? kg_ : 0;
                     const f32x4 g0 = *reinterpret_cast<const f32x4*>(gate_lds + kgc);
-                    if constexpr (sizeof(T) == 4) {
-                        f32x4 x = __builtin_bit_cast(f32x4, v);
+                    if constexpr (PAIR) {
+                        // two-term weights: gate the VALUE (hi + lo) in float32 and split again - gating the terms separately would
+                        // round each to 8 bits
+                        const f32x4 g1 = *reinterpret_cast<const f32x4*>(gate_lds + kgc + 4);
+                        F8 x = pair_join8(v[0], v[1]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x.v[e] *= (e < 4 ? g0[e] : g1[e - 4]);
+                        pair_split8(x, v[0], v[1]);
+                    } else if constexpr (sizeof(T) == 4) {
+                        f32x4 x = __builtin_bit_cast(f32x4, v[0]);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) x[e] *= g0[e];
-                        v = __builtin_bit_cast(u32x4, x);
+                        v[0] = __builtin_bit_cast(u32x4, x);
                     } else {
                         const f32x4 g1 = *reinterpret_cast<const f32x4*>(gate_lds + kgc + 4);
-                        bf16x8 x = __builtin_bit_cast(bf16x8, v);
+                        bf16x8 x = __builtin_bit_cast(bf16x8, v[0]);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) x[e] = (bf16_t)((float)x[e] * (e < 4 ? g0[e] : g1[e - 4]));
-                        v = __builtin_bit_cast(u32x4, x);
+                        v[0] = __builtin_bit_cast(u32x4, x);
                     }
                 }
-                *reinterpret_cast<u32x4*>(Wd + lds_row(idx / PPR) * ROWB + (idx % PPR) * 16) = v;
+#pragma unroll
+                for (int h = 0; h < WV; ++h) *reinterpret_cast<u32x4*>(Wd + lds_row(idx / PPR) * ROWB + (idx % PPR) * PB + h * 16) = v[h];
             }
         }
     };
@@ -188,7 +205,7 @@ DEV void pw_gemm_body(const PwArgs& p, const int bid) {
         for (int sub = 0; sub < KCH; ++sub) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const Frag<T> wf = ld_frag<T>(Ws + (16 * j + frow) * ROWB + sub * 64 + fpiece * 16);
+                const Frag<T> wf = ld_frag<T>(Ws + (16 * j + frow) * ROWB + sub * CB + fpiece * PB);
 #pragma unroll
                 for (int i = 0; i < PT; ++i) mma_chunk(wf, areg[u][sub][i], acc[i][j]);
             }
@@ -260,7 +277,7 @@ DEV void pw_gemm_body(const PwArgs& p, const int bid) {
                             const F8 rv = load8<T>(rsrc);
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] += rv.v[e];
-                        } else {
+                        } else if constexpr (!PAIR) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += to_f<T>(rsrc[e]);
                         }
@@ -270,7 +287,7 @@ DEV void pw_gemm_body(const PwArgs& p, const int bid) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o.v[e] = v[e];
                         store8<T>(dst, o);
-                    } else {
+                    } else if constexpr (!PAIR) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) if (e < nvalid) dst[e] = from_f<T>(v[e]);
                     }
@@ -389,6 +406,11 @@ extern "C" int effdet_pw_gemm_bn_act(void* stream, int dtype,
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == 0) return launch_pw<float>(st, a);
     if (dtype == 1) return launch_pw<bf16_t>(st, a);
+    if (dtype == 2) {                                              // two-term bf16: whole 8-channel groups, 32-byte aligned rows
+        if (N % 8 || ldc % 8 || c_image_stride % 8 || reinterpret_cast<uintptr_t>(A) % 32 || reinterpret_cast<uintptr_t>(W) % 32 ||
+            reinterpret_cast<uintptr_t>(C) % 32 || (residual && reinterpret_cast<uintptr_t>(residual) % 32)) return EFFDET_EINVAL;
+        return launch_pw<bf16p_t>(st, a);
+    }
     return EFFDET_EINVAL;
 }
 
@@ -408,5 +430,11 @@ extern "C" int effdet_pw_gemm_group(void* stream, int dtype, int n, const void* 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == 0) return launch_pw_group<float>(st, g);
     if (dtype == 1) return launch_pw_group<bf16_t>(st, g);
+    if (dtype == 2) {
+        for (int i = 0; i < n; ++i)
+            if (N[i] % 8 || reinterpret_cast<uintptr_t>(A[i]) % 32 || reinterpret_cast<uintptr_t>(W[i]) % 32 || reinterpret_cast<uintptr_t>(C[i]) % 32)
+                return EFFDET_EINVAL;
+        return launch_pw_group<bf16p_t>(st, g);
+    }
     return EFFDET_EINVAL;
 }

@@ -72,7 +72,9 @@ template <typename T> DEV Raw8<T> load_raw8(const T* p) {
 }
 template <typename T> DEV F8 unpack8(const Raw8<T>& r) {
     F8 o;
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (IsPair<T>::value) {
+        return pair_join8(r.v[0], r.v[1]);
+    } else if constexpr (sizeof(T) == 2) {
         const bf16x8 a = __builtin_bit_cast(bf16x8, r.v[0]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o.v[e] = (float)a[e];
@@ -85,7 +87,9 @@ template <typename T> DEV F8 unpack8(const Raw8<T>& r) {
 }
 template <typename T> DEV Raw8<T> pack8(const F8& f) {
     Raw8<T> r;
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (IsPair<T>::value) {
+        pair_split8(f, r.v[0], r.v[1]);
+    } else if constexpr (sizeof(T) == 2) {
         bf16x8 a;
 #pragma unroll
         for (int e = 0; e < 8; ++e) a[e] = (bf16_t)f.v[e];
@@ -129,6 +133,18 @@ DEV Raw8<T> fetch_input(const T* base, const SepInput& in, int y, int x, int F, 
 // rows), which global_store_dwordx4 accepts.
 template <typename T>
 DEV void store_piece(T* dst, const float (&v)[8], int nvalid, bool vec_ok) {
+    if constexpr (IsPair<T>::value) {                            // whole groups only (N % 8 == 0 is checked on the host)
+        typedef unsigned u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+        F8 f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f.v[e] = v[e];
+        u32x4 hi, lo;
+        pair_split8(f, hi, lo);
+        if (nvalid >= 8) {
+            *reinterpret_cast<u32x4_a4*>(dst) = hi;
+            *(reinterpret_cast<u32x4_a4*>(dst) + 1) = lo;
+        }
+    } else
     if (vec_ok && nvalid >= 8) {
         if constexpr (sizeof(T) == 2) {
             typedef unsigned u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -142,9 +158,11 @@ DEV void store_piece(T* dst, const float (&v)[8], int nvalid, bool vec_ok) {
             *reinterpret_cast<f32x4_a4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
         }
     } else {
+        if constexpr (!IsPair<T>::value) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (e < nvalid) dst[e] = from_f<T>(v[e]);
+            for (int e = 0; e < 8; ++e)
+                if (e < nvalid) dst[e] = from_f<T>(v[e]);
+        }
     }
 }
 
@@ -155,7 +173,7 @@ DEV void store_piece(T* dst, const float (&v)[8], int nvalid, bool vec_ok) {
 // next chunk's W prefetch is a counted `vmcnt(N)` that does not drain the chunk's own stores (the exec-mask branches around them
 // made it `vmcnt(0)`: every chunk waited for its 884 MB share to be acknowledged before the next could start).
 template <typename T, int TH, int TW, int BN, bool OOD, int NTH, int FT, bool META = false, int NIN = 3, bool BST = false>
-__global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META ? 8 : 4) : 2) void sepconv_kernel(SepArgs p) {
+__global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META && !IsPair<T>::value ? 8 : 4) : 2) void sepconv_kernel(SepArgs p) {
     constexpr int BM = TH * TW;
     constexpr int HW_ = (TH + 2) * (TW + 2);
     constexpr int NWAVE = NTH / 64;
@@ -167,13 +185,14 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META ? 8 : 
 
     const int F = FT ? FT : p.F, N = p.N;
     const int fbytes = F * (int)sizeof(T);
-    const int nkc = (fbytes + 63) / 64;
-    const int arow = nkc * 64 + 16;              // A / W row pitch in bytes
+    constexpr int PB = OpGeom<T>::PIECE, CHB = OpGeom<T>::CHUNK;   // bytes of a lane's operand piece / of a K-chunk
+    const int nkc = (fbytes + CHB - 1) / CHB;
+    const int arow = nkc * CHB + 16;             // A / W row pitch in bytes
     // LDS carve (all multiples of 16): the halo tile (phases 1-2) and the W chunk (phase 3) share a region
     // bf16 runs the depthwise taps on the matrix cores (see mbconv.hip): 16 pixels x 16 bytes per operand read, so the
     // halo rows get 16 bytes of padding to spread the pixels over the LDS banks
-    constexpr bool MF = sizeof(T) == 2 && TW == 16 && NTH == 512;
-    constexpr int HROW = FC + (MF ? 8 : 0);          // halo row pitch in elements
+    constexpr bool MF = IsFast<T>::value && TW == 16 && NTH == 512;
+    constexpr int HROW = FC + (MF ? 16 / (int)sizeof(T) : 0);          // halo row pitch in elements (+16 bytes)
     constexpr int HALO_BYTES = HW_ * HROW * (int)sizeof(T);
     // 64-channel layers (one halo pass): the depthwise output waits in registers until every wave has read the halo and
     // then overwrites it, with the W chunk behind it -> 30 KB instead of 47 KB per workgroup, four workgroups per CU
@@ -206,8 +225,8 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META ? 8 : 
         dpre[q] = (d_pref && i < 9 * F) ? p.dw_w[i] : 0.f;
     }
     // zero the K padding of the A tile rows once (columns [fbytes, nkc*64))
-    if (nkc * 64 > fbytes) {
-        const int padb = nkc * 64 - fbytes;
+    if (nkc * CHB > fbytes) {
+        const int padb = nkc * CHB - fbytes;
         for (int i = tid; i < BM * (padb / 16); i += NTH) {
             const int row = i / (padb / 16), piece = i % (padb / 16);
             *reinterpret_cast<u32x4*>(At + row * arow + fbytes + piece * 16) = u32x4{0u, 0u, 0u, 0u};
@@ -221,8 +240,8 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META ? 8 : 
     }
     float fwm[3];                                         // per-input multiplier of the fused sum
 #pragma unroll
-    for (int i = 0; i < 3; ++i) fwm[i] = i < p.n_in ? ((sizeof(T) == 2 && p.fuse_mode == 1) ? p.fwn[i] : p.fw[i]) : 0.f;
-    const bool divide = sizeof(T) == 4 && p.fuse_mode == 1;   // parity mode keeps the reference's (x*w)/sum order
+    for (int i = 0; i < 3; ++i) fwm[i] = i < p.n_in ? ((IsFast<T>::value && p.fuse_mode == 1) ? p.fwn[i] : p.fw[i]) : 0.f;
+    const bool divide = !IsFast<T>::value && p.fuse_mode == 1;   // parity mode keeps the reference's (x*w)/sum order
 
     // ------------------------------------------------------------------ phases 1 + 2 per 64 channels
     for (int fc0 = 0; fc0 < F; fc0 += FC) {
@@ -324,9 +343,17 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META ? 8 : 
                     const int t = 2 * pr + hi;
                     const bool on = active && t < 9 && 16 * j + frow_ < fcn;
                     const float wv = on ? dww[(t < 9 ? t : 0) * F + fc0 + 16 * j + frow_] : 0.f;
-                    const unsigned bits = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)wv) << (16 * (frow_ & 1));
+                    const bf16_t wh = (bf16_t)wv;
+                    const unsigned bits = (unsigned)__builtin_bit_cast(unsigned short, wh) << (16 * (frow_ & 1));
                     const u32x4 fr = {dq == 0 ? bits : 0u, dq == 1 ? bits : 0u, dq == 2 ? bits : 0u, dq == 3 ? bits : 0u};
-                    afr[pr].v = __builtin_bit_cast(bf16x8, fr);
+                    if constexpr (IsPair<T>::value) {
+                        const unsigned bl = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)(wv - (float)wh)) << (16 * (frow_ & 1));
+                        const u32x4 fl = {dq == 0 ? bl : 0u, dq == 1 ? bl : 0u, dq == 2 ? bl : 0u, dq == 3 ? bl : 0u};
+                        afr[pr].h = __builtin_bit_cast(bf16x8, fr);
+                        afr[pr].l = __builtin_bit_cast(bf16x8, fl);
+                    } else {
+                        afr[pr].v = __builtin_bit_cast(bf16x8, fr);
+                    }
                 }
                 const char* hb = halo + (frow_ * HROW + 16 * j + 8 * (fp_ & 1)) * (int)sizeof(T);
 #pragma unroll
@@ -343,7 +370,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META ? 8 : 
                     }
                     if constexpr (CP) keep[pt] = acc;
                     else if (16 * j + 4 * fp_ < fcn)
-                        store4<T>(reinterpret_cast<T*>(At + (16 * ty + frow_) * arow) + fc0 + 16 * j + 4 * fp_, acc[0], acc[1], acc[2], acc[3]);
+                        row_store4<T>(At + (16 * ty + frow_) * arow, fc0 + 16 * j + 4 * fp_, acc);
                 }
             }
             if constexpr (CP) {
@@ -352,7 +379,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META ? 8 : 
 #pragma unroll
                     for (int pt = 0; pt < TH / 2; ++pt) {
                         const int ty = part * (TH / 2) + pt;
-                        store4<T>(reinterpret_cast<T*>(At + (16 * ty + frow_) * arow) + fc0 + 16 * j + 4 * fp_, keep[pt][0], keep[pt][1], keep[pt][2], keep[pt][3]);
+                        row_store4<T>(At + (16 * ty + frow_) * arow, fc0 + 16 * j + 4 * fp_, keep[pt]);
                     }
                 }
             }
@@ -383,8 +410,8 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META ? 8 : 
     const float* scale = p.scale ? p.scale + (long long)L.affine_row * N : nullptr;
     const float* shift = p.shift + (long long)L.affine_row * N;
     T* out = reinterpret_cast<T*>(L.out) + (long long)b * L.out_image_stride;
-    const int ppr = nkc * 4;                           // 16-byte pieces per W row
-    constexpr int WPC = (BN * 8 + NTH - 1) / NTH;      // W pieces a thread prefetches when a row has <= 8 pieces
+    const int ppr = nkc * (CHB / 16);                  // 16-byte pieces per W row
+    constexpr int WPC = (BN * (CHB / 8) + NTH - 1) / NTH;      // W pieces a thread prefetches when a row has <= 8 (two-term: 16) pieces
     u32x4 wpre[WPC];
     float cpre_s = 1.0f, cpre_t = 0.0f;                // next chunk's scale / shift for channel `tid`
 
@@ -520,11 +547,11 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META ? 8 : 
             Frag<T> xb[WPT];
 #pragma unroll
             for (int i = 0; i < WPT; ++i)
-                xb[i] = ld_frag<T>(At + (16 * WPT * wave + 16 * i + frow) * arow + kc * 64 + fpiece * 16);
+                xb[i] = ld_frag<T>(At + (16 * WPT * wave + 16 * i + frow) * arow + kc * CHB + fpiece * PB);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 if (j < 2 * njp) {
-                    const Frag<T> wf = ld_frag<T>(Wt + (16 * j + frow) * arow + kc * 64 + fpiece * 16);
+                    const Frag<T> wf = ld_frag<T>(Wt + (16 * j + frow) * arow + kc * CHB + fpiece * PB);
 #pragma unroll
                     for (int i = 0; i < WPT; ++i) mma_chunk(wf, xb[i], acc[i][j]);
                 }
@@ -582,7 +609,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META ? 8 : 
 #else
                     if (pix_in[i] && nvalid > 0 && !OOD) {
 #endif
-                        if (sizeof(T) == 2 && p.out_f32)
+                        if (IsFast<T>::value && p.out_f32)
                             store_piece<float>(reinterpret_cast<float*>(L.out) + (long long)b * L.out_image_stride + pix_off[i] + n_begin + cb,
                                                vals[J], nvalid, true);
                         else
@@ -592,7 +619,8 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META ? 8 : 
                         if (p.stat_partial != nullptr && pix_in[i]) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
-                                const float q = to_f<T>(from_f<T>(vals[J][e]));   // statistics of what the next layer reads
+                                float q = vals[J][e];
+                                if constexpr (!IsPair<T>::value) q = to_f<T>(from_f<T>(vals[J][e]));   // statistics of what the next layer reads
                                 st1[J][e] += q; st2[J][e] += q * q;
                             }
                         }
@@ -614,7 +642,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META ? 8 : 
 #pragma unroll
                 for (int J = 0; J < NP; ++J) {
                     if (J < njp) {
-                        if constexpr (sizeof(T) == 2) {
+                        if constexpr (IsFast<T>::value) {
                             const float tl = tm * LOG2E;
 #pragma unroll
                             for (int e = 0; e < 8; ++e) ssum += __builtin_amdgcn_exp2f(fmaf(vals[J][e], LOG2E, -tl));   // exp2(-inf) = 0
@@ -681,9 +709,9 @@ template <typename T, int TH, int TW, int BN>
 size_t sep_lds_bytes(int F, bool cp = false) {
     constexpr int BM = TH * TW;
     constexpr int HW_ = (TH + 2) * (TW + 2);
-    const int nkc = (F * (int)sizeof(T) + 63) / 64;
-    const int arow = nkc * 64 + 16;
-    const size_t halo = (size_t)HW_ * (FC + (sizeof(T) == 2 && TW == 16 ? 8 : 0)) * sizeof(T);
+    const int nkc = (F * (int)sizeof(T) + OpGeom<T>::CHUNK - 1) / OpGeom<T>::CHUNK;
+    const int arow = nkc * OpGeom<T>::CHUNK + 16;
+    const size_t halo = (size_t)HW_ * (FC + (IsFast<T>::value && TW == 16 ? 16 / (int)sizeof(T) : 0)) * sizeof(T);
     const size_t wt = (size_t)BN * arow;
     if (cp) return (halo > wt + (size_t)BM * arow ? halo : wt + (size_t)BM * arow) + (size_t)9 * F * 4 + (size_t)2 * BN * 4;
     return (halo > wt ? halo : wt) + (size_t)BM * arow + (size_t)9 * F * 4 + (size_t)2 * BN * 4;
@@ -698,7 +726,7 @@ int launch_sep(hipStream_t st, SepArgs& a, int B) {
         a.lv[i].tile_begin = tiles;
         tiles += a.lv[i].tiles_x * a.lv[i].tiles_y;
     }
-    const size_t lds = sep_lds_bytes<T, TH, TW, BN>(a.F, sizeof(T) == 2 && TW == 16 && NTH == 512 && FT == 64 && !META) + (META ? (size_t)(NTH / 64) * 2 * BN * 4 : 0);   // + statistics scratch
+    const size_t lds = sep_lds_bytes<T, TH, TW, BN>(a.F, IsFast<T>::value && TW == 16 && NTH == 512 && FT == 64 && !META) + (META ? (size_t)(NTH / 64) * 2 * BN * 4 : 0);   // + statistics scratch
     if (lds > 160 * 1024) return EFFDET_EINVAL;
     a.tiles_total = tiles;
     auto kern = sepconv_kernel<T, TH, TW, BN, OOD, NTH, FT, META, NIN, BST>;
@@ -778,8 +806,11 @@ static int sepconv_common(
     if (nlevels < 1 || nlevels > 5 || n_in < 1 || n_in > 3 || B <= 0) return EFFDET_EINVAL;
     if (!level_hw || !in_ptr || !in_image_stride || !in_hw || !in_mode || !dw_w || !pw_w || !shift || !affine_row ||
         !out_ptr || !out_image_stride) return EFFDET_EINVAL;
-    const int out_f32 = (dtype & 2) ? 1 : 0;          // dtype | 2: compute in bf16 / f32 as bit 0 says, write float32 outputs
-    dtype &= 1;
+    // dtype 3 (= 1 | 2): bfloat16 compute, float32 outputs; dtype 6 (= 2 | 4): two-term bf16 compute, float32 outputs
+    if (dtype != 0 && dtype != 1 && dtype != 2 && dtype != 3 && dtype != 6) return EFFDET_EINVAL;
+    const int out_f32 = (dtype == 3 || dtype == 6) ? 1 : 0;
+    dtype = dtype == 3 ? 1 : (dtype == 6 ? 2 : dtype);
+    if (dtype == 2 && (meta || (!out_f32 && N % 8))) return EFFDET_EINVAL;      // two-term outputs: whole 8-channel groups; no MetaHead form
     if (F <= 0 || F % 8 || N <= 0 || fuse_mode < 0 || fuse_mode > 2) return EFFDET_EINVAL;
     if (fuse_mode != 0 && !fuse_w) return EFFDET_EINVAL;
     if (fuse_mode == 0 && n_in != 1) return EFFDET_EINVAL;
@@ -834,6 +865,14 @@ static int sepconv_common(
                           : launch_sep<bf16_t, 8, 16, 64, false, 512, 0, true>(st, a, B);
     }
     if (dtype == 0) return dispatch_sep<float, 8, 8, 256>(st, a, B);
+    if (dtype == 2) {
+        for (int l = 0; l < nlevels; ++l) {                      // 16-byte aligned groups
+            if (!out_f32 && (reinterpret_cast<uintptr_t>(a.lv[l].out) % 16 || a.lv[l].out_image_stride % 4)) return EFFDET_EINVAL;
+            for (int i = 0; i < n_in; ++i)
+                if (reinterpret_cast<uintptr_t>(a.lv[l].in[i].ptr) % 16 || a.lv[l].in[i].image_stride % 4) return EFFDET_EINVAL;
+        }
+        return dispatch_sep<bf16p_t, 8, 16, 512>(st, a, B);
+    }
     // bf16: 512 threads per 8x16 tile - the LDS footprint allows two workgroups per CU, so four waves per SIMD
     // share the VALU-heavy halo and epilogue phases
     return dispatch_sep<bf16_t, 8, 16, 512>(st, a, B);
@@ -877,7 +916,7 @@ extern "C" int effdet_sepconv_meta(
 
 // Tiles per image of a multi-level launch (rows of stat_partial per image) and the first tile of every level
 extern "C" int effdet_sepconv_tiles(int dtype, int nlevels, const int* level_hw, int* level_tile_begin) {
-    if (nlevels < 1 || nlevels > 5 || !level_hw || (dtype & ~1)) return EFFDET_EINVAL;
+    if (nlevels < 1 || nlevels > 5 || !level_hw || dtype < 0 || dtype > 2) return EFFDET_EINVAL;
     const int TH = 8, TW = dtype == 0 ? 8 : 16;
     int tiles = 0;
     for (int l = 0; l < nlevels; ++l) {

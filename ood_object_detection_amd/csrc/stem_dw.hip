@@ -275,7 +275,11 @@ size_t sd_lds_bytes(int C) {
 
 // SE pool partial rows per image of the kernel effdet_stem_dw_fused[_u8] will run for (dtype, H, W, C)
 extern "C" int effdet_stem_dw_parts(int dtype, int H, int W, int C) {
-    if (H <= 0 || W <= 0 || C <= 0 || (dtype & ~1)) return EFFDET_EINVAL;
+    if (H <= 0 || W <= 0 || C <= 0 || dtype < 0 || dtype > 2) return EFFDET_EINVAL;
+    if (dtype == 2) {                                                // two-term bf16: the rolling-window form only
+        const int parts = effdet_stem_roll_parts(H, W, C, 1);
+        return parts > 0 ? parts : EFFDET_EINVAL;
+    }
     if (dtype == 1) {
         const int parts = effdet_stem_roll_parts(H, W, C);
         if (parts > 0) return parts;
@@ -295,7 +299,12 @@ static int stem_dw_common(void* stream, int in_dtype, int dtype, const void* X, 
                           const float* s2, const float* t2, void* Y, float* pool_partial,
                           int B, int H, int W, int C) {
     if (!X || !Wk || !s1 || !t1 || !taps || !s2 || !t2 || !Y || B <= 0 || H <= 0 || W <= 0) return EFFDET_EINVAL;
-    if (C <= 0 || C % 8 || C > 64 || in_dtype < 0 || in_dtype > 2 || (dtype & ~1) || (in_dtype == 2 && (!mean || !stdv))) return EFFDET_EINVAL;
+    if (C <= 0 || C % 8 || C > 64 || in_dtype < 0 || in_dtype > 2 || dtype < 0 || dtype > 2 || (in_dtype == 2 && (!mean || !stdv))) return EFFDET_EINVAL;
+    if (dtype == 2) {
+        // two-term bf16 (the "accurate" mode): Wk is float32 [C][32], Y two-term; float32 or uint8 images; C = 32 and an even width
+        if (effdet_stem_roll_parts(H, W, C, 1) <= 0 || reinterpret_cast<uintptr_t>(Y) % 16) return EFFDET_EINVAL;
+        return effdet_stem_roll_launch(reinterpret_cast<hipStream_t>(stream), in_dtype, X, mean, stdv, Wk, s1, t1, taps, s2, t2, Y, pool_partial, B, H, W, C, 1);
+    }
     SdArgs a;
     for (int i = 0; i < 3; ++i) { a.nmean[i] = in_dtype == 2 ? mean[i] : 0.f; a.nstd[i] = in_dtype == 2 ? stdv[i] : 1.f; }
     a.X = X; a.in_dtype = in_dtype; a.Wk = Wk; a.s1 = s1; a.t1 = t1; a.taps = taps; a.s2 = s2; a.t2 = t2;

@@ -17,6 +17,7 @@
 // Every input row is read from HBM once per strip (the tile form re-read a 37 x 37 patch per 16 x 16 outputs: 4.4x).
 // Needs an even pad_l (even W) and C = 32 (the b0 .. b2 stems); anything else takes stem_dw.hip's tile form.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -45,13 +46,17 @@ template <int V> struct IntS { static constexpr int value = V; };
 constexpr int SR_TW = 30;                   // output columns per strip: 32 stem columns with the halo = 2 pixel tiles
 constexpr int SR_IPX = 72;                  // input pixels staged per row (2 * 32 + 1 = 65 used), 8 bytes each
 constexpr int SR_IROW = SR_IPX * 8;         // 576 bytes
-constexpr int SR_RING = 3 * 1024;           // per channel tile: 3 stem rows x 32 px x 16 ch bf16
-
 // IN: 0 float32, 1 bfloat16, 2 uint8 (normalised on the fly).  NJ = C / 16 channel tiles.
-template <int IN, int NJ>
-__global__ __launch_bounds__(512, 4) void stem_roll_kernel(SrArgs p) {
+// T: bf16_t, or bf16p_t (dtype 2, two-term bf16: the staged image, the stem weights, the stem ring and Y carry hi + lo and every
+// MFMA becomes three; Wk is then plain float32 [C][32]; the image's hi and lo planes are staged as two sets of input rows)
+template <int IN, int NJ, typename T>
+__global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : 4)) void stem_roll_kernel(SrArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    typedef bf16_t T;
+    constexpr bool PAIR = IsPair<T>::value;
+    constexpr int PXB = 16 * (int)sizeof(T);        // bytes of a ring pixel (16 channels)
+    constexpr int SR_ROWB = 32 * PXB;               // one stem row of a channel tile in its ring
+    constexpr int SR_RING = 3 * SR_ROWB;            // per channel tile: 3 stem rows x 32 px x 16 ch
+    constexpr int IPL = PAIR ? 2 : 1;               // staged image planes (hi | hi, lo)
     // readfirstlane: the wave index is wave-uniform, but the compiler cannot know that of threadIdx.x >> 6 - and this kernel's band
     // and strip (hence the scalar offsets of every buffer load and store) derive from it.  Left as a vector value each buffer
     // operation was wrapped in a waterfall loop (readfirstlane + exec mask + branch) and waited for on the spot: the input rows
@@ -65,15 +70,16 @@ __global__ __launch_bounds__(512, 4) void stem_roll_kernel(SrArgs p) {
     const int strip = q % p.nstrips, band = q / p.nstrips;
     if (band >= p.nbands) return;                                   // waves are autonomous: no barrier follows
     const int C = p.C;
-    char* const wl = lds + wave * (4 * SR_IROW + NJ * SR_RING);
-    char* const irows = wl;                                         // [4][SR_IPX][4] bf16 interleaved input rows
-    char* const rings = wl + 4 * SR_IROW;                           // [NJ][3][32 px][16 ch]
+    char* const wl = lds + wave * (IPL * 4 * SR_IROW + NJ * SR_RING);
+    char* const irows = wl;                                         // [IPL][4][SR_IPX][4] bf16 interleaved input rows
+    char* const rings = wl + IPL * 4 * SR_IROW;                     // [NJ][3][32 px][16 ch]
+    constexpr int ILO = 4 * SR_IROW;                                // two-term: the lo plane's rows follow the hi plane's
 
     // ---- constants.  Stem weights as MFMA A operands: chunk 0 = (ky 0 | ky 1), chunk 1 = (ky 2 | zero); inside a ky the 16
     // K slots are (kx, c4) = 12 real values + 4 zeros; the lane (row m = frow, pieces of 8 K) holds K = 8*kg .. 8*kg + 7.
     Frag<T> wf[NJ][2];
     f32x4 sh1[NJ], t2v[NJ];
-    unsigned abits[NJ][5];
+    unsigned abits[NJ][5], abitl[PAIR ? NJ : 1][5];
     const int hi = kg >> 1;
     const bool dactive = (kg & 1) == (frow >> 3);
     const int dq = (frow & 7) >> 1;
@@ -81,7 +87,8 @@ __global__ __launch_bounds__(512, 4) void stem_roll_kernel(SrArgs p) {
     for (int j = 0; j < NJ; ++j) {
         const int ch = 16 * j + frow;
         const float rs1 = p.s1[ch], rs2 = p.s2[ch];
-        const bf16_t* wrow = reinterpret_cast<const bf16_t*>(p.Wk) + (long long)ch * 32;
+        typedef typename std::conditional<PAIR, float, bf16_t>::type WT;
+        const WT* wrow = reinterpret_cast<const WT*>(p.Wk) + (long long)ch * 32;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int ky = 2 * c + (kg >> 1);                       // kernel row of this lane's half of the chunk
@@ -90,7 +97,14 @@ __global__ __launch_bounds__(512, 4) void stem_roll_kernel(SrArgs p) {
                 const int slot = 8 * (kg & 1) + e;                  // 0..15 inside the ky: kx = slot / 4, ci = slot % 4
                 const int kx = slot >> 2, ci = slot & 3;
                 const bool real = ky < 3 && kx < 3 && ci < 3;
-                wf[j][c].v[e] = real ? (bf16_t)((float)wrow[(ky * 3 + kx) * 3 + ci] * rs1) : (bf16_t)0.f;
+                const float w = real ? (float)wrow[(ky * 3 + kx) * 3 + ci] * rs1 : 0.f;
+                if constexpr (PAIR) {
+                    const bf16_t wh = (bf16_t)w;
+                    wf[j][c].h[e] = wh;
+                    wf[j][c].l[e] = (bf16_t)(w - (float)wh);
+                } else {
+                    wf[j][c].v[e] = (bf16_t)w;
+                }
             }
         }
         sh1[j] = *reinterpret_cast<const f32x4*>(p.t1 + 16 * j + 4 * kg);
@@ -100,7 +114,9 @@ __global__ __launch_bounds__(512, 4) void stem_roll_kernel(SrArgs p) {
             const int t = 2 * pr + hi;
             const bool on = dactive && t < 9;
             const float wv = on ? p.taps[(long long)(t < 9 ? t : 0) * C + ch] * rs2 : 0.f;
-            abits[j][pr] = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)wv) << (16 * (frow & 1));
+            const bf16_t wvh = (bf16_t)wv;
+            abits[j][pr] = (unsigned)__builtin_bit_cast(unsigned short, wvh) << (16 * (frow & 1));
+            if constexpr (PAIR) abitl[j][pr] = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)(wv - (float)wvh)) << (16 * (frow & 1));
         }
     }
     const int oy_b = band * p.band_rows, oy_e = min(p.Ho, oy_b + p.band_rows);
@@ -125,7 +141,7 @@ __global__ __launch_bounds__(512, 4) void stem_roll_kernel(SrArgs p) {
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(p.X)) + (long long)b * 3 * p.H * p.W * esz, 0, 3 * p.H * p.W * esz, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<char*>(p.Y) + (long long)b * p.Ho * p.Wo * C * 2, 0, p.Ho * p.Wo * C * 2, 0x00020000);
+        reinterpret_cast<char*>(p.Y) + (long long)b * p.Ho * p.Wo * C * (int)sizeof(T), 0, p.Ho * p.Wo * C * (int)sizeof(T), 0x00020000);
     const int plane = p.H * p.W * esz;
     const char* dl[2];
     int yoff[2];
@@ -133,10 +149,11 @@ __global__ __launch_bounds__(512, 4) void stem_roll_kernel(SrArgs p) {
     for (int u = 0; u < 2; ++u) {
         const int oxl = 16 * u + frow;
         const bool ok = oxl < tw;
-        dl[u] = rings + (ok ? oxl * 32 : 0) + (kg & 1) * 16;
-        yoff[u] = ok ? ((ox0 + oxl) * C + 4 * kg) * 2 : OOB;
+        dl[u] = rings + (ok ? oxl * PXB : 0) + (kg & 1) * (PXB / 2);
+        // (two-term: byte offset of the hi half of channels 4 kg .. inside their 8-channel group; channel tile j adds 64 bytes)
+        yoff[u] = ok ? (PAIR ? (ox0 + oxl) * C * 4 + ((4 * kg) >> 3) * 32 + ((4 * kg) & 7) * 2 : ((ox0 + oxl) * C + 4 * kg) * 2) : OOB;
     }
-    char* const ring_e = rings + frow * 32 + kg * 8;
+    char* const ring_e = rings + frow * PXB;
     // im2col operand address inside a staged input row: pixel 2 * (16 t + frow) + 2 * (kg & 1), i.e. 16-byte aligned
     const int xf_lane = (2 * frow + 2 * (kg & 1)) * 8;
 
@@ -205,7 +222,11 @@ __global__ __launch_bounds__(512, 4) void stem_roll_kernel(SrArgs p) {
                 const int c = lane + 64 * h;
                 if (c < SR_IPX) {
                     typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
-                    *reinterpret_cast<bf16x4_*>(dst + c * 8) = bf16x4_{(bf16_t)raw[SL][r][0][h], (bf16_t)raw[SL][r][1][h], (bf16_t)raw[SL][r][2][h], (bf16_t)0.f};
+                    const bf16x4_ vh = bf16x4_{(bf16_t)raw[SL][r][0][h], (bf16_t)raw[SL][r][1][h], (bf16_t)raw[SL][r][2][h], (bf16_t)0.f};
+                    *reinterpret_cast<bf16x4_*>(dst + c * 8) = vh;
+                    if constexpr (PAIR)
+                        *reinterpret_cast<bf16x4_*>(dst + ILO + c * 8) = bf16x4_{(bf16_t)(raw[SL][r][0][h] - (float)vh[0]), (bf16_t)(raw[SL][r][1][h] - (float)vh[1]),
+                                                                                 (bf16_t)(raw[SL][r][2][h] - (float)vh[2]), (bf16_t)0.f};
                 }
             }
         }
@@ -218,14 +239,20 @@ __global__ __launch_bounds__(512, 4) void stem_roll_kernel(SrArgs p) {
         const char* r1 = irows + ((iy0 + 2) & 3) * SR_IROW + xf_lane;                  // chunk 1: ky = 2 (upper half: zero weights)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const Frag<T> x0 = ld_frag<T>(r0 + t * 256), x1 = ld_frag<T>(r1 + t * 256);
+            Frag<T> x0, x1;
+            if constexpr (PAIR) {                                     // hi and lo planes of the staged image
+                x0.h = *reinterpret_cast<const bf16x8*>(r0 + t * 256); x0.l = *reinterpret_cast<const bf16x8*>(r0 + ILO + t * 256);
+                x1.h = *reinterpret_cast<const bf16x8*>(r1 + t * 256); x1.l = *reinterpret_cast<const bf16x8*>(r1 + ILO + t * 256);
+            } else {
+                x0 = ld_frag<T>(r0 + t * 256); x1 = ld_frag<T>(r1 + t * 256);
+            }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 f32x4 acc = sh1[j];
                 mma_chunk(wf[j][0], x0, acc);
                 mma_chunk(wf[j][1], x1, acc);
                 const f32x4 v = silu4r(acc) * (cmask[t] * rmask);
-                store4<T>(reinterpret_cast<T*>(ring_e + j * SR_RING + slot_bytes + 512 * t), v[0], v[1], v[2], v[3]);
+                row_store4<T>(ring_e + j * SR_RING + slot_bytes + 16 * PXB * t, 4 * kg, v);
             }
         }
     };
@@ -243,7 +270,7 @@ __global__ __launch_bounds__(512, 4) void stem_roll_kernel(SrArgs p) {
         fetch_rows(iyA + 2, IntS<0>{}); commit_rows(iyA + 2, IntS<0>{});
         stem_row(s_first, 0);
         fetch_rows(iyA + 3, IntS<0>{}); commit_rows(iyA + 3, IntS<0>{});   // (row iyA + 3 again with iyA + 4: rows are committed in pairs)
-        stem_row(s_first + 1, 1024);
+        stem_row(s_first + 1, SR_ROWB);
     }
     int snext = s_first + 2;                                          // next stem row to compute
     // the two new input rows of the next three stem rows (the first row of each was committed with its predecessor)
@@ -252,15 +279,15 @@ __global__ __launch_bounds__(512, 4) void stem_roll_kernel(SrArgs p) {
         fetch_rows(2 * (snext + 1) - p.pad_t + 1, IntS<1>{});
         fetch_rows(2 * (snext + 2) - p.pad_t + 1, IntS<2>{});
     }
-    int yrow = oy_b * p.Wo * C * 2;
-    const int ypitch = p.Wo * C * 2;
+    int yrow = oy_b * p.Wo * C * (int)sizeof(T);
+    const int ypitch = p.Wo * C * (int)sizeof(T);
     int oy = oy_b;
     auto step = [&](auto PHC) {
         constexpr int PH = decltype(PHC)::value;                      // ring slot of stem row oy - 1
         const int iyn = 2 * snext - p.pad_t + 1;
         constexpr int SLOT = PFD == 3 ? PH : 0;
         commit_rows(iyn, IntS<SLOT>{});                              // fetched PFD steps ago into register slot SLOT
-        stem_row(snext, ((PH + 2) % 3) * 1024);
+        stem_row(snext, ((PH + 2) % 3) * SR_ROWB);
         ++snext;
         fetch_rows(2 * (snext + PFD - 1) - p.pad_t + 1, IntS<SLOT>{});   // rows of the step PFD ahead, into the slot just emptied
         __builtin_amdgcn_sched_barrier(0);
@@ -274,9 +301,18 @@ __global__ __launch_bounds__(512, 4) void stem_roll_kernel(SrArgs p) {
                 unsigned bits = abits[j][pr];
                 asm volatile("" : "+v"(bits));        // expand the diagonal operand at use: NJ x 5 hoisted fragments would spill
                 const u32x4 fr = {dq == 0 ? bits : 0u, dq == 1 ? bits : 0u, dq == 2 ? bits : 0u, dq == 3 ? bits : 0u};
-                Frag<T> af; af.v = __builtin_bit_cast(bf16x8, fr);
+                Frag<T> af;
+                if constexpr (PAIR) {
+                    unsigned bl = abitl[j][pr];
+                    asm volatile("" : "+v"(bl));
+                    const u32x4 fl = {dq == 0 ? bl : 0u, dq == 1 ? bl : 0u, dq == 2 ? bl : 0u, dq == 3 ? bl : 0u};
+                    af.h = __builtin_bit_cast(bf16x8, fr);
+                    af.l = __builtin_bit_cast(bf16x8, fl);
+                } else {
+                    af.v = __builtin_bit_cast(bf16x8, fr);
+                }
                 const int ta = 2 * pr, tb = 2 * pr + 1 < 9 ? 2 * pr + 1 : 0;
-                const int offa = ((PH + ta / 3) % 3) * 1024 + (ta % 3) * 32, offb = ((PH + tb / 3) % 3) * 1024 + (tb % 3) * 32;
+                const int offa = ((PH + ta / 3) % 3) * SR_ROWB + (ta % 3) * PXB, offb = ((PH + tb / 3) % 3) * SR_ROWB + (tb % 3) * PXB;
                 const int off = (hsel ? offb : offa) + j * SR_RING;
 #pragma unroll
                 for (int u = 0; u < 2; ++u) mma_chunk(af, ld_frag<T>(dl[u] + off), acc[u]);
@@ -287,10 +323,16 @@ __global__ __launch_bounds__(512, 4) void stem_roll_kernel(SrArgs p) {
                 const float vm = yoff[u] == OOB ? 0.f : 1.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pl[j][r] += ov[r] * vm;
-                typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
-                typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
-                const bf16x4_ ob = {(bf16_t)ov[0], (bf16_t)ov[1], (bf16_t)ov[2], (bf16_t)ov[3]};
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, ob), yrs, yoff[u] == OOB ? OOB : yoff[u] + 32 * j, yrow, 0);
+                if constexpr (PAIR) {                   // (an out-of-range offset + 16 is out of range too: the store is dropped)
+                    u32x2 oh, ol;
+                    pair_split4(ov, oh, ol);
+                    const int yo = yoff[u] == OOB ? OOB : yoff[u] + 64 * j;
+                    __builtin_amdgcn_raw_buffer_store_b64(oh, yrs, yo, yrow, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(ol, yrs, yo + 16, yrow, 0);
+                } else {
+                    const bf16x4 ob = {(bf16_t)ov[0], (bf16_t)ov[1], (bf16_t)ov[2], (bf16_t)ov[3]};
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), yrs, yoff[u] == OOB ? OOB : yoff[u] + 32 * j, yrow, 0);
+                }
             }
         }
         yrow += ypitch;
@@ -322,7 +364,7 @@ __global__ __launch_bounds__(512, 4) void stem_roll_kernel(SrArgs p) {
 struct SrGeometry { bool use; int TWo, nstrips, band_rows, nbands, wpg, per_image; size_t lds; };
 
 // map sizes only (never the batch): an image's result is the same at every batch size
-SrGeometry pick_stem_roll(int H, int W, int C) {
+SrGeometry pick_stem_roll(int H, int W, int C, bool pair = false) {
     SrGeometry g{};
     g.use = false;
     if (C != 32) return g;                                            // 2 channel tiles (b0 .. b2 stems); wider stems spill at 128 registers
@@ -336,23 +378,24 @@ SrGeometry pick_stem_roll(int H, int W, int C) {
     g.nbands = (Ho + g.band_rows - 1) / g.band_rows;
     g.wpg = 4;
     g.per_image = (g.nstrips * g.nbands + g.wpg - 1) / g.wpg;
-    g.lds = (size_t)g.wpg * (4 * SR_IROW + (C / 16) * SR_RING);
+    g.lds = (size_t)g.wpg * ((pair ? 2 : 1) * 4 * SR_IROW + (C / 16) * 3 * 32 * (pair ? 64 : 32));
     g.use = true;
     return g;
 }
 
 }  // namespace
 
-int effdet_stem_roll_parts(int H, int W, int C) {
-    const SrGeometry g = pick_stem_roll(H, W, C);
+int effdet_stem_roll_parts(int H, int W, int C, int pair) {
+    const SrGeometry g = pick_stem_roll(H, W, C, pair != 0);
     return g.use ? g.nstrips * g.nbands : 0;
 }
 
 int effdet_stem_roll_launch(hipStream_t st, int in_dtype, const void* X, const float* mean, const float* stdv, const void* Wk,
                             const float* s1, const float* t1, const float* taps, const float* s2, const float* t2,
-                            void* Y, float* pool_partial, int B, int H, int W, int C) {
-    const SrGeometry g = pick_stem_roll(H, W, C);
+                            void* Y, float* pool_partial, int B, int H, int W, int C, int pair) {
+    const SrGeometry g = pick_stem_roll(H, W, C, pair != 0);
     if (!g.use) return EFFDET_EINVAL;
+    if (pair && in_dtype == 1) return EFFDET_EINVAL;                 // two-term mode takes float32 or raw uint8 images
     SrArgs a;
     a.X = X; a.Wk = Wk;
     for (int i = 0; i < 3; ++i) { a.nmean[i] = in_dtype == 2 ? mean[i] : 0.f; a.nstd[i] = in_dtype == 2 ? stdv[i] : 1.f; }
@@ -362,9 +405,14 @@ int effdet_stem_roll_launch(hipStream_t st, int in_dtype, const void* X, const f
     a.TWo = g.TWo; a.nstrips = g.nstrips; a.band_rows = g.band_rows; a.nbands = g.nbands; a.wpg = g.wpg; a.per_image = g.per_image;
     void (*kern)(SrArgs) = nullptr;
     const int nj = C / 16;
-#define SR_PICK(IN_) (nj == 2 ? stem_roll_kernel<IN_, 2> : nullptr)
-    kern = in_dtype == 0 ? SR_PICK(0) : in_dtype == 1 ? SR_PICK(1) : SR_PICK(2);
+#define SR_PICK(IN_, T_) (nj == 2 ? stem_roll_kernel<IN_, 2, T_> : nullptr)
+    if (pair) kern = in_dtype == 0 ? SR_PICK(0, bf16p_t) : SR_PICK(2, bf16p_t);
+    else kern = in_dtype == 0 ? SR_PICK(0, bf16_t) : in_dtype == 1 ? SR_PICK(1, bf16_t) : SR_PICK(2, bf16_t);
 #undef SR_PICK
+    if (g.lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return EFFDET_ELAUNCH;
+    }
     if (kern == nullptr) return EFFDET_EINVAL;
     const int rounds = (B + 7) / 8;
     hipLaunchKernelGGL(kern, dim3(rounds * g.per_image * 8), dim3(g.wpg * 64), g.lds, st, a);

@@ -300,6 +300,9 @@ class EfficientDet(nn.Module):
         self._engine = None
         self._train_engine = None
         self.autograd = None        # None: differentiable forward iff self.training and grad mode and trainable params; True/False forces
+        # 'native': the kernels compute in the parameters' dtype (float32 parity / bfloat16 throughput).  'accurate' (float32
+        # parameters): two-term bf16 values everywhere - float32-grade results (north_star's 1e-3) at matrix-core speed.
+        self.compute_mode = 'native'
         # [0]: bumped whenever parameters may have changed (load_state_dict, .to(), reset_head, invalidate(), PretrainStep);
         # [1]: cached (module ids, parameter + buffer tensors) behind weights_token().  Shared by shallow copies of the model.
         self._wver = [0, None]
@@ -489,8 +492,8 @@ def _run(model, x, mode):
         return cls_o, box_o
 
     if mode in ('full_net', 'fpn', 'supp_bb'):
-        feats = eng.run_backbone(x)
-        activs = eng.run_fpn(None)
+        feats = eng.run_backbone(x, ret=mode == 'fpn')
+        activs = eng.run_fpn(None, ret=mode != 'full_net' or eng._cls_plan is None)
         if mode == 'fpn':
             return feats, activs
         if mode == 'supp_bb':
@@ -499,7 +502,7 @@ def _run(model, x, mode):
     if mode == 'only_fpn':
         return eng.run_fpn(x)
     if mode in ('fpn_and_head', 'not_cls'):
-        activs = eng.run_fpn(x)
+        activs = eng.run_fpn(x, ret=mode == 'not_cls' or eng._cls_plan is None)
         if mode == 'not_cls':
             return activs, heads(None, False, True)[1]
         return heads(None, True, True)

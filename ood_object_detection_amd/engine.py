@@ -7,7 +7,9 @@ Running a stage replays that list on torch's current HIP stream (so a stage can 
 hipGraph with torch.cuda.graph).  PyTorch is used for device memory and streams only.
 
 Data layout in HBM
-  activations        NHWC, dtype = the model's parameter dtype (float32 parity / bfloat16 throughput)
+  activations        NHWC, dtype = the model's parameter dtype (float32 parity / bfloat16 throughput); a float32 model with
+                     `model.compute_mode = 'accurate'` runs dtype 2 of the C ABI instead: two-term bf16 values (pairfmt.py: 16
+                     significand bits, three matrix-core products per multiply) in float32-sized storage, float32 logits / boxes
   pyramid features   one packed tensor [B, P, F] (P = sum_l H_l*W_l), level l at pixel offset off_l
   class / box heads  [B, N, C] and [B, N, 4] with N = 9*P: exactly the concatenated layout that
                      `_post_process` builds with permute/reshape/cat (effdet/bench.py:36-42)
@@ -19,8 +21,10 @@ import math
 import torch
 
 from . import _lib
+from . import pairfmt
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
+_PAIR = 2                    # dtype code of the two-term bf16 ("accurate") mode
 
 
 def _same_out(n, s):
@@ -43,6 +47,14 @@ class Engine(object):
             raise RuntimeError('supported parameter dtypes: float32, bfloat16 (got %s)' % p0.dtype)
         self.lib = _lib.load()
         self.device, self.dtype, self.dt = p0.device, p0.dtype, _DT[p0.dtype]
+        self.mode = getattr(model, 'compute_mode', 'native') or 'native'
+        if self.mode not in ('native', 'accurate'):
+            raise ValueError("compute_mode must be 'native' or 'accurate' (got %r)" % (self.mode,))
+        self.pair = self.mode == 'accurate'
+        if self.pair:
+            if p0.dtype != torch.float32:
+                raise RuntimeError("compute_mode='accurate' splits float32 master weights into two bf16 terms: it needs a float32 model")
+            self.dt = _PAIR
         self.B, self.image_size = B, tuple(image_size)
         self.cfg = cfg
         self.F = cfg.fpn_channels
@@ -66,7 +78,8 @@ class Engine(object):
 
     def matches(self, model):
         p0 = model.backbone.conv_stem.weight
-        return p0.device == self.device and p0.dtype == self.dtype and model.config.num_classes == self.C
+        return p0.device == self.device and p0.dtype == self.dtype and model.config.num_classes == self.C and \
+            (getattr(model, 'compute_mode', 'native') or 'native') == self.mode
 
     # ------------------------------------------------------------------------------------ utils
     def _new(self, *shape, dtype=None):
@@ -80,9 +93,21 @@ class Engine(object):
         return t
 
     def _w(self, t):
-        t = t.detach().to(device=self.device, dtype=self.dtype).contiguous()
+        """weight matrix [N, K] of an MFMA GEMM in the engine's dtype (accurate mode: the two-term layout along K)"""
+        if self.pair:
+            t = pairfmt.encode(t.detach().to(device=self.device, dtype=torch.float32))
+        else:
+            t = t.detach().to(device=self.device, dtype=self.dtype).contiguous()
         self._keep.append(t)
         return t
+
+    def _act_in(self, t):
+        """values -> the engine's activation storage (accurate mode: encode); t is NHWC-shaped"""
+        return pairfmt.encode(t.float()) if self.pair else t
+
+    def _act_out(self, t):
+        """the engine's activation storage -> values (accurate mode: a decoded copy)"""
+        return pairfmt.decode(t) if self.pair else t
 
     def _fold(self, bn, conv_bias=None):
         """BatchNorm (eval) -> scale, shift with an optional preceding conv bias folded in."""
@@ -144,6 +169,9 @@ class Engine(object):
                 if b['type'] == 'ir':
                     nblk = lib.effdet_mbconv_tiles_per_image(dt, h, w, b['cin'], b['mid'], b['k'], b['s'])
                     if nblk <= 0:        # no fused geometry (very wide fp32 inputs): expand GEMM + depthwise kernels
+                        if self.pair:
+                            raise NotImplementedError("compute_mode='accurate': block (cin %d, mid %d, %dx%d map, k %d, stride %d) is outside the "
+                                                      "two-term MBConv kernels' range" % (b['cin'], b['mid'], h, w, b['k'], b['s']))
                         nblk = lib.effdet_dwconv_blocks_per_image(ho, wo, b['mid'])
                         exp_max = max(exp_max, B * h * w * b['mid'])
                 else:
@@ -178,11 +206,13 @@ class Engine(object):
         s, t = self._f32(s), self._f32(t)
         b00 = stages[0][0]
         self._fuse_stem = (b00['type'] == 'ds' and b00['k'] == 3 and b00['s'] == 1 and stem_c <= 64)
+        if self.pair and not (self._fuse_stem and lib.effdet_stem_dw_parts(dt, H, W, stem_c) > 0):
+            raise NotImplementedError("compute_mode='accurate' needs the fused stem's rolling-window form (32 stem channels, even image width)")
         if self._fuse_stem:
             # conv_stem + bn1 + SiLU + blocks.0.0.conv_dw + bn1 + SiLU in one launch (stem map stays in LDS)
             wk = torch.zeros(stem_c, 32, dtype=torch.float32, device=self.device)
             wk[:, :27] = bb.conv_stem.weight.detach().float().permute(0, 2, 3, 1).reshape(stem_c, 27).to(self.device)
-            wk = self._w(wk)
+            wk = self._f32(wk) if self.pair else self._w(wk)          # (two-term mode: the kernel splits the float32 stem weights itself)
             m0 = bb.blocks[0][0]
             s2, t2 = self._fold(m0.bn1)
             taps0 = self._f32(self._dw_taps(m0.conv_dw.weight))
@@ -305,15 +335,17 @@ class Engine(object):
         self._bb_plan = plan
         self.feat_hw = [(f.shape[1], f.shape[2]) for f in self.feats]
 
-    def run_backbone(self, x):
+    def run_backbone(self, x, ret=True):
         if tuple(x.shape) != self.x_shape:
             raise ValueError('engine was prepared for input %s, got %s' % (self.x_shape, tuple(x.shape)))
         if x.device != self.device or (x.dtype not in _DT and x.dtype != torch.uint8):
             raise RuntimeError('input must be a float32/bfloat16 (normalised) or uint8 (raw) tensor on %s' % (self.device,))
+        if self.pair and x.dtype == torch.bfloat16:
+            x = x.float()
         x = x.contiguous()
         self._stem_call(x)
         self._run(self._bb_plan)
-        return [f.permute(0, 3, 1, 2) for f in self.feats]
+        return [self._act_out(f).permute(0, 3, 1, 2) for f in self.feats] if ret else None
 
     def _stem_call(self, x):
         st = torch.cuda.current_stream(self.device).cuda_stream
@@ -511,7 +543,7 @@ class Engine(object):
             self._keep.append(c_ooff)
             ood_args = (ood['classes'], self.A, ood['energy'].data_ptr(), ood['maxlogit'].data_ptr(), ood['stride'], c_ooff)
         self._keep += [c_hw, c_ptr, c_str, c_ihw, c_mode, c_fw, c_aff, c_out, c_ostr]
-        args = (self.dt | (2 if (out_f32 and self.dt == 1) else 0), self.B, nl, c_hw, n_in, c_ptr, c_str, c_ihw, c_mode, fuse_mode, c_fw, ctypes.c_float(den), pre_act,
+        args = (self.dt | (2 if (out_f32 and self.dt == 1) else 0) | (4 if (out_f32 and self.dt == _PAIR) else 0), self.B, nl, c_hw, n_in, c_ptr, c_str, c_ihw, c_mode, fuse_mode, c_fw, ctypes.c_float(den), pre_act,
                 taps.data_ptr(), wq.data_ptr(), scale.data_ptr() if scale is not None else None, shift.data_ptr(),
                 c_aff, post_act, F, N, c_out, c_ostr) + ood_args
         es = self.pyr_es
@@ -527,21 +559,22 @@ class Engine(object):
         for src, dst in zip(xs, dst_tensors):
             if src.device != self.device:
                 raise RuntimeError('feature maps must live on %s' % (self.device,))
-            dst.copy_(src.permute(0, 2, 3, 1))
+            dst.copy_(self._act_in(src.permute(0, 2, 3, 1)))
 
     def pyramid_views(self):
         out = []
+        pyr = self._act_out(self.pyr)
         for (h, w), off in zip(self.level_hw, self.level_off):
-            out.append(self.pyr[:, off:off + h * w, :].unflatten(1, (h, w)).permute(0, 3, 1, 2))
+            out.append(pyr[:, off:off + h * w, :].unflatten(1, (h, w)).permute(0, 3, 1, 2))
         return out
 
-    def run_fpn(self, feats):
+    def run_fpn(self, feats, ret=True):
         if feats is not None:
             if len(feats) != len(self.feats):
                 raise ValueError('expected %d backbone feature maps' % len(self.feats))
             self._load_feature_list(feats, self.feats)
         self._run(self._fpn_plan)
-        return self.pyramid_views()
+        return self.pyramid_views() if ret else None
 
     # ------------------------------------------------------------------------------------- heads
     def _build_heads(self, model):
@@ -549,6 +582,7 @@ class Engine(object):
         A, C, L, P = self.A, self.C, self.L, self.P
         N = A * P
         self.N = N
+        # (accurate mode: the logits leave the class head as plain float32, like the box regressions)
         self.cls_all = self._new(B, N, C)
         # box regressions are written as float32 straight from the accumulators, whatever the model dtype (1.2 MB / image): decode
         # (anchors.py:136 `.float()`) then sees unrounded values
@@ -599,7 +633,7 @@ class Engine(object):
                 oodd = dict(classes=K, energy=self.ood_energy, maxlogit=self.ood_max_logit, stride=N,
                             level_off=[off * A for off in self.level_off])
             plan.append(self._sepconv_call(self.level_hw, ins, 0, [], 1.0, 0, taps, wq, None, t, [0] * L, 0, F, NO,
-                                           outs, [P * NO] * L, '%s.predict' % name, ood=oodd, out_f32=out_f32))
+                                           outs, [P * NO] * L, '%s.predict' % name, ood=oodd, out_f32=out_f32 or self.pair))
             return plan
 
         # infer.py:186-191 replaces `model.class_net` by a MetaHead (functional head, own launches in effdet/meta_head.py):
@@ -620,7 +654,7 @@ class Engine(object):
             if len(activs) != self.L:
                 raise ValueError('expected %d pyramid levels' % self.L)
             for src, (h, w), off in zip(activs, self.level_hw, self.level_off):
-                self.pyr[:, off:off + h * w, :].copy_(src.permute(0, 2, 3, 1).reshape(self.B, h * w, self.F))
+                self.pyr[:, off:off + h * w, :].copy_(self._act_in(src.permute(0, 2, 3, 1).reshape(self.B, h * w, self.F)))
         cls_o = box_o = None
         if want_cls:
             if self._cls_plan is None:

@@ -63,7 +63,7 @@ def sepconv(dtype, B, level_hw, level_inputs, fuse_mode, fw, den, pre_act, taps,
     else:
         oa = (ood['classes'], A, ptr(ood['energy']), ptr(ood['maxlogit']), ood['stride'], arr(ctypes.c_longlong, ood['level_off']))
     dev = taps.device
-    rc = lib.effdet_sepconv_fused(stream(dev), DT[dtype], B, nl, c_hw, n_in, c_ptr, c_str, c_ihw, c_mode, fuse_mode, c_fw,
+    rc = lib.effdet_sepconv_fused(stream(dev), dtype if isinstance(dtype, int) else DT[dtype], B, nl, c_hw, n_in, c_ptr, c_str, c_ihw, c_mode, fuse_mode, c_fw,
                                   den, pre_act, ptr(taps), ptr(wq), ptr(scale), ptr(shift), c_aff, post_act, F, N,
                                   c_out, c_ostr, *oa)
     assert rc == 0, rc

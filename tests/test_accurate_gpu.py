@@ -1,0 +1,448 @@
+"""dtype 2 of the C ABI (EFFDET_BF16X2, the "accurate" mode: two-term bf16 values, three matrix-core products per multiply):
+every kernel against float64 arithmetic on the SAME (representable) inputs, then the whole network against the float32 CPU oracle
+at north_star's 1e-3.  Tolerances: a stored value carries a relative error <= 2^-17 (7.6e-6), a product drops the lo*lo term
+(~2^-18); kernel outputs are checked to 4e-5 of max|ref| (float32 kernels: 2e-5, bf16: 3e-2)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import model as om
+
+DEV = 'cuda:0'
+PAIR = 2
+TOLP = 4e-5
+
+
+def _rel(a, b):
+    return float((a.double().cpu() - b.double().cpu()).abs().max() / (b.double().abs().max() + 1e-12))
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _enc(x):
+    from ood_object_detection_amd import pairfmt
+    return pairfmt.encode(x)
+
+
+def _dec(t):
+    from ood_object_detection_amd import pairfmt
+    return pairfmt.decode(t.cpu())
+
+
+def _q(x):
+    """the value the two-term layout holds for x"""
+    return _dec(_enc(x))
+
+
+def test_pair_format_round_trip():
+    x = _rand(5, 7, 24, seed=1, scale=3.0)
+    q = _q(x)
+    assert float(((q - x).abs() / x.abs().clamp_min(1e-30)).max()) <= 2.0 ** -16      # two 8-bit significands, round to nearest each
+    assert torch.equal(_q(q), q)                                                        # representable values are fixed points
+    e = _enc(x)
+    assert e.shape == x.shape and e.dtype == torch.float32
+
+
+@pytest.mark.parametrize('M,K,N,rpi', [(300, 16, 96, 0), (1000, 96, 24, 250), (257, 240, 40, 0), (513, 1152, 320, 0), (128, 40, 240, 64),
+                                       (800, 672, 192, 400), (77, 64, 88, 0), (300, 8, 16, 0), (25600, 16, 8, 6400)])
+def test_pw_gemm_pair(M, K, N, rpi):
+    import _hip
+    from ood_object_detection_amd import _lib
+    lib = _lib.load()
+    A, W = _q(_rand(M, K, seed=1)), _q(_rand(N, K, seed=2, scale=K ** -0.5))
+    scale, shift = torch.rand(N) + 0.5, _rand(N, seed=3, scale=0.1)
+    res = _q(_rand(M, N, seed=4))
+    imgs = M // rpi if rpi else 1
+    gate = torch.sigmoid(_rand(imgs, K, seed=5))
+    Ad, Wd, Rd = _enc(A).to(DEV), _enc(W).to(DEV), _enc(res).to(DEV)
+    sd, td, gd = scale.to(DEV), shift.to(DEV), gate.to(DEV)           # (kept alive: a temporary's block would be handed to the next one)
+    for act, use_res, use_gate, use_scale in ((0, False, False, True), (1, False, False, True), (0, True, True, False), (0, False, True, True)):
+        if use_gate and not rpi:
+            continue
+        Ag = A.double()
+        if use_gate:
+            Ag = (A.double().reshape(imgs, -1, K) * gate.double()[:, None, :]).reshape(M, K)
+        ref = Ag @ W.double().t()
+        ref = ref * (scale.double() if use_scale else 1.0) + shift.double()
+        if act:
+            ref = ref * torch.sigmoid(ref)
+        if use_res:
+            ref = ref + res.double()
+        out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+        rc = lib.effdet_pw_gemm_bn_act(_hip.stream(DEV), PAIR, Ad.data_ptr(), M, K, Wd.data_ptr(), N,
+                                       sd.data_ptr() if use_scale else None, td.data_ptr(), act,
+                                       Rd.data_ptr() if use_res else None, gd.data_ptr() if use_gate else None, rpi,
+                                       out.data_ptr(), 0, 0)
+        assert rc == 0
+        torch.cuda.synchronize()
+        err = _rel(_dec(out), ref)
+        assert err < TOLP, (act, use_res, use_gate, err)
+
+
+def test_pw_gemm_pair_rejects_partial_groups():
+    import _hip
+    from ood_object_detection_amd import _lib
+    lib = _lib.load()
+    A = torch.zeros(64, 16, device=DEV)
+    W = torch.zeros(12, 16, device=DEV)
+    C = torch.zeros(64, 16, device=DEV)
+    sh = torch.zeros(16, device=DEV)
+    assert lib.effdet_pw_gemm_bn_act(_hip.stream(DEV), PAIR, A.data_ptr(), 64, 16, W.data_ptr(), 12, None, sh.data_ptr(), 0, None, None, 0,
+                                     C.data_ptr(), 0, 0) == -22
+
+
+def test_pw_gemm_group_pair_equals_single_launches():
+    import _hip
+    from ood_object_detection_amd import _lib
+    lib = _lib.load()
+    st = _hip.stream(DEV)
+    N = 64
+    probs = [(2 * 400, 320), (2 * 1600, 112), (2 * 6400, 40), (77, 8)]
+    keep, single, grouped = [], [], []
+    for i, (M, K) in enumerate(probs):
+        A = _enc(_rand(M, K, seed=30 + i)).to(DEV)
+        W = _enc(_rand(N, K, seed=40 + i, scale=K ** -0.5)).to(DEV)
+        sh = _rand(N, seed=50 + i, scale=0.1).to(DEV)
+        c0, c1 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+        assert lib.effdet_pw_gemm_bn_act(st, PAIR, A.data_ptr(), M, K, W.data_ptr(), N, None, sh.data_ptr(), 0, None, None, 0, c0.data_ptr(), 0, 0) == 0
+        keep.append((A, W, sh))
+        single.append(c0)
+        grouped.append(c1)
+    n = len(probs)
+    arr = lambda ct, v: (ct * n)(*v)
+    rc = lib.effdet_pw_gemm_group(st, PAIR, n, arr(ctypes.c_void_p, [k[0].data_ptr() for k in keep]),
+                                  arr(ctypes.c_longlong, [p[0] for p in probs]), arr(ctypes.c_int, [p[1] for p in probs]),
+                                  arr(ctypes.c_void_p, [k[1].data_ptr() for k in keep]), arr(ctypes.c_int, [N] * n),
+                                  arr(ctypes.c_void_p, [None] * n), arr(ctypes.c_void_p, [k[2].data_ptr() for k in keep]), 0,
+                                  arr(ctypes.c_void_p, [c.data_ptr() for c in grouped]))
+    assert rc == 0
+    torch.cuda.synchronize()
+    for a, b in zip(single, grouped):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# fused separable conv (BiFPN node / head layers / class predict + OOD epilogue)
+# ------------------------------------------------------------------------------------------------------------------
+def _sep_ref(ins, modes, fw, den, fuse_mode, pre_act, dw, pw, bias, scale, shift, post_act):
+    """float64 arithmetic of one fused node: combine -> act -> dw3x3 -> pw -> affine -> act"""
+    xs = []
+    for x, m in zip(ins, modes):
+        x = x.double()
+        if m == 1:
+            x = F.interpolate(x, scale_factor=2.0, mode='nearest')
+        elif m == 2:
+            x = om.maxpool_pad(x, 3, 2, 'same')
+        xs.append(x)
+    if fuse_mode == 0:
+        y = xs[0]
+    elif fuse_mode == 1:
+        y = sum((x * w) / den for x, w in zip(xs, fw))
+    else:
+        y = sum(x * w for x, w in zip(xs, fw))
+    if pre_act:
+        y = y * torch.sigmoid(y)
+    y = om.conv2d_pad(y, dw.double(), None, 1, 'same', groups=y.shape[1])
+    y = F.conv2d(y, pw.double(), None if bias is None else bias.double())
+    if scale is not None:
+        y = y * scale.double()[None, :, None, None]
+    y = y + shift.double()[None, :, None, None]
+    return y * torch.sigmoid(y) if post_act else y
+
+
+def _nhwc_q(x):
+    """NCHW float -> (representable NCHW values, encoded NHWC device tensor)"""
+    xl = x.permute(0, 2, 3, 1).contiguous()
+    e = _enc(xl)
+    return _dec(e).permute(0, 3, 1, 2).contiguous(), e.to(DEV)
+
+
+@pytest.mark.parametrize('Fc', [64, 88, 112])
+def test_sepconv_bifpn_node_pair(Fc):
+    import _hip
+    B, H, W = 2, 20, 12
+    x_same, e_same = _nhwc_q(_rand(B, Fc, H, W, seed=20))
+    x_up, e_up = _nhwc_q(_rand(B, Fc, H // 2, W // 2, seed=21))
+    x_dn, e_dn = _nhwc_q(_rand(B, Fc, 2 * H, 2 * W - 1, seed=22))      # odd width: SAME pad on one side only
+    dw = _rand(Fc, 1, 3, 3, seed=23, scale=0.3)
+    pw = _q(_rand(Fc, Fc, seed=24, scale=Fc ** -0.5))
+    scale, shift = torch.rand(Fc) + 0.5, _rand(Fc, seed=25, scale=0.1)
+    fw, den = [0.7, 1.3, 0.4], 2.4001
+    ref = _sep_ref([x_same, x_up, x_dn], [0, 1, 2], fw, den, 1, 1, dw, pw.reshape(Fc, Fc, 1, 1), None, scale, shift, 0)
+    ins_d = [e_same, e_up, e_dn]
+    out = torch.empty(B, H, W, Fc, dtype=torch.float32, device=DEV)
+    taps = dw.permute(2, 3, 0, 1).reshape(9, Fc).contiguous().to(DEV)
+    wq = _enc(pw).to(DEV)
+    li = [[(t.data_ptr(), t.shape[1] * t.shape[2] * t.shape[3], (t.shape[1], t.shape[2]), m) for t, m in zip(ins_d, (0, 1, 2))]]
+    _hip.sepconv(PAIR, B, [(H, W)], li, 1, fw, den, 1, taps, wq, scale.to(DEV), shift.to(DEV), [0], 0, Fc, Fc, [out.data_ptr()], [H * W * Fc])
+    torch.cuda.synchronize()
+    err = _rel(_dec(out).permute(0, 3, 1, 2), ref)
+    assert err < TOLP, err
+
+
+@pytest.mark.parametrize('C', [90, 7, 1, 150])
+def test_sepconv_head_levels_and_ood_pair(C):
+    """all pyramid levels in one launch, per-level affine; class predict writes FLOAT32 logits (dtype 6 = 2 | 4) + OOD epilogue"""
+    import _hip
+    B, Fc, A = 2, 64, 9
+    hw = [(16, 16), (8, 8), (4, 4), (2, 2), (1, 1)]
+    offs = np.cumsum([0] + [h * w for h, w in hw]).tolist()
+    P = offs[-1]
+    fq, fe = zip(*[_nhwc_q(_rand(B, Fc, h, w, seed=30 + i)) for i, (h, w) in enumerate(hw)])
+    pyr = torch.cat([e.reshape(B, -1, Fc) for e in fe], 1).contiguous()
+    dw = _rand(Fc, 1, 3, 3, seed=36, scale=0.3)
+    taps = dw.permute(2, 3, 0, 1).reshape(9, Fc).contiguous().to(DEV)
+    es = 4
+    pw = _q(_rand(Fc, Fc, seed=37, scale=Fc ** -0.5))
+    scale, shift = torch.rand(5, Fc) + 0.5, _rand(5, Fc, seed=38, scale=0.1)
+    out = torch.empty(B, P, Fc, dtype=torch.float32, device=DEV)
+    li = [[(pyr.data_ptr() + offs[l] * Fc * es, P * Fc, hw[l], 0)] for l in range(5)]
+    _hip.sepconv(PAIR, B, hw, li, 0, [], 1.0, 0, taps, _enc(pw).to(DEV), scale.to(DEV), shift.to(DEV),
+                 list(range(5)), 1, Fc, Fc, [out.data_ptr() + offs[l] * Fc * es for l in range(5)], [P * Fc] * 5)
+    torch.cuda.synchronize()
+    got_all = _dec(out)
+    for l in range(5):
+        ref = _sep_ref([fq[l]], [0], [], 1.0, 0, 0, dw, pw.reshape(Fc, Fc, 1, 1), None, scale[l], shift[l], 1)
+        got = got_all[:, offs[l]:offs[l + 1], :].reshape(B, hw[l][0], hw[l][1], Fc).permute(0, 3, 1, 2)
+        assert _rel(got, ref) < TOLP, l
+    NO = A * C
+    pwp = _q(_rand(NO, Fc, seed=39, scale=2.0 * Fc ** -0.5))
+    bias = _rand(NO, seed=40, scale=0.5) - 2.0
+    N = A * P
+    cls_all = torch.full((B, N, C), float('nan'), dtype=torch.float32, device=DEV)
+    energy = torch.empty(B, N, dtype=torch.float32, device=DEV)
+    maxl = torch.empty(B, N, dtype=torch.float32, device=DEV)
+    _hip.sepconv(PAIR | 4, B, hw, li, 0, [], 1.0, 0, taps, _enc(pwp).to(DEV), None, bias.reshape(1, NO).to(DEV),
+                 [0] * 5, 0, Fc, NO, [cls_all.data_ptr() + offs[l] * NO * es for l in range(5)], [P * NO] * 5,
+                 ood=dict(classes=C, energy=energy, maxlogit=maxl, stride=N, level_off=[o * A for o in offs[:5]]), A=A)
+    torch.cuda.synchronize()
+    refs = [_sep_ref([fq[l]], [0], [], 1.0, 0, 0, dw, pwp.reshape(NO, Fc, 1, 1), bias, None, torch.zeros(NO), 0) for l in range(5)]
+    ref_all = torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, C) for r in refs], 1)
+    assert _rel(cls_all, ref_all) < TOLP
+    e_ref = -torch.logsumexp(ref_all, dim=2)
+    m_ref = ref_all.max(dim=2).values
+    assert float((energy.cpu().double() - e_ref).abs().max()) < 1e-4 * max(1.0, float(e_ref.abs().max()))
+    assert float((maxl.cpu().double() - m_ref).abs().max()) < 1e-4 * max(1.0, float(m_ref.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# fused MBConv front half (expand 1x1 + BN + SiLU -> depthwise + BN + SiLU + SE pool partials)
+# ------------------------------------------------------------------------------------------------------------------
+def _mbconv_ref(x, gate, w1, s1, t1, wd, s2, t2, k, s):
+    xd = x.double()
+    if gate is not None:
+        xd = xd * gate.double()[:, :, None, None]
+    e = F.conv2d(xd, w1.double()[:, :, None, None]) * s1.double()[None, :, None, None] + t1.double()[None, :, None, None]
+    e = e * torch.sigmoid(e)
+    y = om.conv2d_pad(e, wd.double(), None, s, 'same', groups=wd.shape[0]) * s2.double()[None, :, None, None] + t2.double()[None, :, None, None]
+    return y * torch.sigmoid(y)
+
+
+@pytest.mark.parametrize('Cin,mid,H,W,k,s,gated', [
+    # rolling-window form (inputs up to 64 channels): every d0 / 640 early-stage shape class, odd sizes, both strides
+    (16, 96, 40, 36, 3, 2, False), (24, 144, 22, 30, 3, 1, False), (24, 144, 33, 21, 5, 2, False), (40, 240, 20, 20, 5, 1, False),
+    (40, 240, 41, 40, 3, 2, False), (32, 96, 40, 36, 3, 2, True), (32, 96, 64, 64, 3, 2, True), (16, 48, 21, 50, 5, 1, True),
+    # shared-X form (wider inputs): every d0 late-stage shape, two strips, several bands, stride 2
+    (80, 480, 40, 40, 3, 1, False), (80, 480, 40, 40, 5, 1, False), (112, 672, 40, 40, 5, 1, False), (112, 672, 40, 40, 5, 2, False),
+    (192, 1152, 20, 20, 5, 1, False), (192, 1152, 20, 20, 3, 1, False), (112, 672, 37, 41, 5, 1, False), (80, 480, 33, 40, 3, 2, False),
+    (192, 1152, 13, 19, 5, 2, False), (112, 672, 23, 17, 5, 1, False)])
+def test_mbconv_expand_dw_pair(Cin, mid, H, W, k, s, gated):
+    import _hip
+    from ood_object_detection_amd import _lib
+    lib = _lib.load()
+    B = 3
+    xq, xe = _nhwc_q(_rand(B, Cin, H, W, seed=50))
+    gate = torch.sigmoid(_rand(B, Cin, seed=75)) if gated else None
+    w1 = _q(_rand(mid, Cin, seed=51, scale=1.5 * Cin ** -0.5))
+    s1, t1 = torch.rand(mid) + 0.5, _rand(mid, seed=52, scale=0.2)
+    wd = _rand(mid, 1, k, k, seed=53, scale=1.0 / k)
+    s2, t2 = torch.rand(mid) + 0.5, _rand(mid, seed=54, scale=0.2)
+    ref = _mbconv_ref(xq, gate, w1, s1, t1, wd, s2, t2, k, s)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    y = torch.full((B, Ho, Wo, mid), float('nan'), dtype=torch.float32, device=DEV)
+    fn = lib.effdet_mbconv_gated_tiles_per_image if gated else lib.effdet_mbconv_tiles_per_image
+    nt = fn(PAIR, H, W, Cin, mid, k, s)
+    assert nt > 0, nt
+    part = torch.full((B, nt, mid), float('nan'), dtype=torch.float32, device=DEV)
+    dv = [t.contiguous().to(DEV) for t in (_enc(w1), s1, t1, wd.permute(2, 3, 0, 1).reshape(k * k, mid), s2, t2)]
+    if gated:
+        gd = gate.to(DEV)
+        rc = lib.effdet_mbconv_expand_dw_gated(_hip.stream(DEV), PAIR, xe.data_ptr(), gd.data_ptr(), y.data_ptr(), *[t.data_ptr() for t in dv],
+                                               part.data_ptr(), B, H, W, Cin, mid, k, s)
+    else:
+        rc = lib.effdet_mbconv_expand_dw(_hip.stream(DEV), PAIR, xe.data_ptr(), y.data_ptr(), *[t.data_ptr() for t in dv],
+                                         part.data_ptr(), B, H, W, Cin, mid, k, s)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert lib.effdet_device_error(0) == 0
+    got = _dec(y).permute(0, 3, 1, 2)
+    err = _rel(got, ref)
+    assert err < TOLP, err
+    pooled = part.sum(1).cpu().double() / (Ho * Wo)
+    pref = ref.mean((2, 3))
+    assert float((pooled - pref).abs().max()) < 2e-5 * max(1.0, float(pref.abs().max()))
+
+
+def test_stem_dw_and_maxpool_pair():
+    """conv_stem 3x3 / s2 + bn1 + SiLU -> blocks.0.0 depthwise 3x3 + BN + SiLU (+ SE pool partials) from a float32 and from a raw
+    uint8 image (the loader's normalisation inside the load), and the BiFPN's 3x3 / s2 max pool, in the two-term dtype"""
+    import _hip
+    from ood_object_detection_amd import _lib
+    lib = _lib.load()
+    B, H, W, C = 2, 96, 128, 32
+    ws = _rand(C, 3, 3, 3, seed=60, scale=0.3)
+    s1, t1 = torch.rand(C) + 0.5, _rand(C, seed=61, scale=0.2)
+    wd = _rand(C, 1, 3, 3, seed=62, scale=0.3)
+    s2, t2 = torch.rand(C) + 0.5, _rand(C, seed=63, scale=0.2)
+    wk = torch.zeros(C, 32)
+    wk[:, :27] = ws.permute(0, 2, 3, 1).reshape(C, 27)
+    dv = [t.contiguous().to(DEV) for t in (wk, s1, t1, wd.permute(2, 3, 0, 1).reshape(9, C), s2, t2)]
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    for kind in ('f32', 'u8'):
+        if kind == 'f32':
+            x = _rand(B, 3, H, W, seed=64)
+            xin = x
+        else:
+            g = torch.Generator().manual_seed(65)
+            xu = torch.randint(0, 256, (B, 3, H, W), generator=g, dtype=torch.uint8)
+            m = torch.tensor([255.0 * v for v in mean], dtype=torch.float32).view(1, 3, 1, 1)
+            sd = torch.tensor([255.0 * v for v in std], dtype=torch.float32).view(1, 3, 1, 1)
+            x = (xu.float() - m) / sd                          # float32 like the loader (effdet/data/loader.py:127-128)
+            xin = xu
+        e = om.conv2d_pad(x.double(), ws.double(), None, 2, 'same') * s1.double()[None, :, None, None] + t1.double()[None, :, None, None]
+        e = e * torch.sigmoid(e)
+        ref = om.conv2d_pad(e, wd.double(), None, 1, 'same', groups=C) * s2.double()[None, :, None, None] + t2.double()[None, :, None, None]
+        ref = ref * torch.sigmoid(ref)
+        Ho, Wo = ref.shape[2], ref.shape[3]
+        nt = lib.effdet_stem_dw_parts(PAIR, H, W, C)
+        assert nt > 0
+        y = torch.full((B, Ho, Wo, C), float('nan'), dtype=torch.float32, device=DEV)
+        part = torch.full((B, nt, C), float('nan'), dtype=torch.float32, device=DEV)
+        xd = xin.contiguous().to(DEV)
+        if kind == 'f32':
+            rc = lib.effdet_stem_dw_fused(_hip.stream(DEV), 0, PAIR, xd.data_ptr(), *[t.data_ptr() for t in dv], y.data_ptr(), part.data_ptr(), B, H, W, C)
+        else:
+            cm = (ctypes.c_float * 3)(*[255.0 * v for v in mean])
+            cs = (ctypes.c_float * 3)(*[255.0 * v for v in std])
+            rc = lib.effdet_stem_dw_fused_u8(_hip.stream(DEV), PAIR, xd.data_ptr(), cm, cs, *[t.data_ptr() for t in dv], y.data_ptr(), part.data_ptr(), B, H, W, C)
+        assert rc == 0
+        torch.cuda.synchronize()
+        err = _rel(_dec(y).permute(0, 3, 1, 2), ref)
+        assert err < TOLP, (kind, err)
+        pooled = part.sum(1).cpu().double() / (Ho * Wo)
+        assert float((pooled - ref.mean((2, 3))).abs().max()) < 2e-5
+    # max pool of a two-term map: exact (a maximum of stored values)
+    xq, xe = _nhwc_q(_rand(B, 64, 21, 20, seed=66))
+    refp = om.maxpool_pad(xq, 3, 2, 'same')
+    out = torch.empty(B, refp.shape[2], refp.shape[3], 64, dtype=torch.float32, device=DEV)
+    assert lib.effdet_maxpool_same(_hip.stream(DEV), PAIR, xe.data_ptr(), 0, out.data_ptr(), 0, B, 21, 20, 64) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(_dec(out).permute(0, 3, 1, 2), refp)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# whole network: compute_mode = 'accurate' against the float32 CPU oracle at north_star's tolerance
+# ------------------------------------------------------------------------------------------------------------------
+def _decode(rel, a):
+    ya, xa, ha, wa = (a[:, 0] + a[:, 2]) / 2, (a[:, 1] + a[:, 3]) / 2, a[:, 2] - a[:, 0], a[:, 3] - a[:, 1]
+    w, h = torch.exp(rel[:, 3]) * wa, torch.exp(rel[:, 2]) * ha
+    yc, xc = rel[:, 0] * ha + ya, rel[:, 1] * wa + xa
+    return torch.stack([xc - w / 2, yc - h / 2, xc + w / 2, yc + h / 2], 1)
+
+
+def accurate_vs_oracle(size, B, C, seed, soft_nms=False):
+    """-> dict of L-inf errors of the accurate HIP path against the CPU oracle (float32 PyTorch) on the BN-calibrated seeded d0"""
+    from _models import seeded_model
+    from _seeded import seeded_array
+    from ood_object_detection_amd.effdet.bench import DetBenchPredict
+    model, cfg, nodes, sd = seeded_model('tf_efficientdet_d0', size, C, seed=seed, cls_bias=-2.0, soft_nms=soft_nms)
+    x = torch.from_numpy(seeded_array(seed + 1, 'input', (B, 3, size, size)))
+    with torch.no_grad():
+        cls_r, box_r = om.efficientdet_forward(sd, cfg, x, nodes)
+        e_ref, m_ref = om.ood_scores(cls_r, C)
+    model = model.to(DEV).float()
+    model.compute_mode = 'accurate'
+    bench = DetBenchPredict(model, streams=1).to(DEV)
+    with torch.no_grad():
+        det = bench(x.to(DEV))
+    torch.cuda.synchronize()
+    eng = model._engine
+    assert eng.dt == 2 and eng.cls_all.dtype == torch.float32
+    cls_g = [t.float().cpu() for t in eng.head_views(eng.cls_all, C)]
+    box_g = [t.float().cpu() for t in eng.head_views(eng.box_all, 4)]
+    out = {'class_logits_linf': max(float((a - r).abs().max()) for a, r in zip(cls_g, cls_r)),
+           'box_outputs_linf': max(float((a - r).abs().max()) for a, r in zip(box_g, box_r)),
+           'ood_energy_linf': float((model.ood_energy.cpu() - e_ref).abs().max()),
+           'ood_max_logit_linf': float((model.ood_max_logit.cpu() - m_ref).abs().max()),
+           'class_logits_absmax': max(float(r.abs().max()) for r in cls_r)}
+    # detections the accurate path kept: score / box of the SAME (anchor, class) from the oracle's head outputs
+    cls_ref_all = torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, C) for r in cls_r], 1)
+    box_ref_all = torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4) for r in box_r], 1)
+    anchors = bench.anchors.boxes.float().cpu()
+    anc = bench.last_ood['anchor_index'].cpu()
+    det = det.float().cpu()
+    ss = sb = 0.0
+    n_det = 0
+    for i in range(B):
+        n = int(bench.last_count[i])
+        n_det += n
+        if n == 0:
+            continue
+        a_idx, c_idx = anc[i, :n], det[i, :n, 5].long() - 1
+        ss = max(ss, float((torch.sigmoid(cls_ref_all[i, a_idx, c_idx]) - det[i, :n, 4]).abs().max())) if not soft_nms else ss
+        sb = max(sb, float((_decode(box_ref_all[i, a_idx], anchors[a_idx]) - det[i, :n, :4]).abs().max()))
+    out.update(same_candidate_scores_linf=ss, same_candidate_boxes_linf_px=sb, detections=n_det)
+    return out, model, bench, x
+
+
+def test_accurate_mode_meets_1e3_against_the_oracle():
+    """north_star: detections (boxes, classes, scores) and OOD scores match the reference PyTorch CPU path within 1e-3 abs.  The
+    accurate mode on the BN-calibrated seeded d0 (logits O(1), scores spread over (0, 1)): class logits, box regressions, OOD
+    energy / max-logit and the scores of the kept detections within 1e-3 of the ORACLE; decoded boxes within 2e-2 px (an anchor of
+    ~600 px scales the regression error; the float32 HIP path measures ~1e-3 px there)."""
+    r, model, bench, x = accurate_vs_oracle(512, 2, 90, 11)
+    print('accurate vs oracle (512 px):', r)
+    assert r['class_logits_linf'] <= 1e-3 and r['box_outputs_linf'] <= 1e-3, r
+    assert r['ood_energy_linf'] <= 1e-3 and r['ood_max_logit_linf'] <= 1e-3, r
+    assert r['detections'] > 0 and r['same_candidate_scores_linf'] <= 1e-3 and r['same_candidate_boxes_linf_px'] <= 2e-2, r
+    # batch invariance: image 0 alone gives the same bits
+    eng = model._engine
+    c0, b0, e0 = eng.cls_all[0].clone(), eng.box_all[0].clone(), model.ood_energy[0].clone()
+    with torch.no_grad():
+        bench(x[:1].to(DEV))
+    eng1 = model._engine
+    assert torch.equal(eng1.cls_all[0], c0) and torch.equal(eng1.box_all[0], b0) and torch.equal(model.ood_energy[0], e0)
+    # modes that return intermediate tensors decode them: backbone features and pyramid levels against the oracle
+    with torch.no_grad():
+        feats, activs = model(x.to(DEV), mode='fpn')
+        sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+        cfg = model.config
+        fr = om.backbone_forward(sd, cfg.backbone_name, x, pad_type=cfg.pad_type)
+    for a, b in zip(feats, fr):
+        assert float((a.cpu() - b).abs().max()) <= 1e-3 * max(1.0, float(b.abs().max()))
+    # ... and accept them back: mode='fpn_and_head' on the decoded features reproduces the full forward
+    with torch.no_grad():
+        cls_full = [t.clone() for t in model(x.to(DEV))[0]]
+        cls2, box2 = model([f.contiguous() for f in feats], mode='fpn_and_head')
+    assert max(float((a - b).abs().max()) for a, b in zip(cls2, cls_full)) <= 1e-4
+
+
+def test_accurate_mode_rejects_what_it_cannot_run():
+    from _models import seeded_model
+    model, cfg, nodes, sd = seeded_model('tf_efficientdet_d0', 128, 20, seed=3)
+    model = model.to(DEV).to(torch.bfloat16)
+    model.compute_mode = 'accurate'
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(1, 3, 128, 128, device=DEV, dtype=torch.bfloat16))
+    model = model.float()
+    model.compute_mode = 'fast'
+    with pytest.raises(ValueError):
+        model(torch.zeros(1, 3, 128, 128, device=DEV))
