@@ -51,8 +51,11 @@ template <int V> struct IntC { static constexpr int value = V; };
 
 // NO = output tiles (16 px) per strip row: a compile-time count, so that every output row issues the same number of loads
 // and stores and the compiler can count them in its waits
-// T: bf16_t, or bf16p_t (dtype 2, two-term bf16: X, W1, the expanded ring and Y carry hi + lo, every MFMA becomes three; NKC then
-// counts 128-byte chunks - still 32 channels each - and a ring pixel is 64 bytes = two 8-channel groups [8 hi][8 lo])
+// T: bf16_t, or bf16p_t (dtype 2, two-term bf16: X, W1 and Y carry hi + lo and the expand GEMM takes three MFMAs per chunk; NKC
+// then counts 128-byte chunks - still 32 channels each.  The expanded ring holds FLOAT32 there (64 bytes per 16-channel pixel) and
+// the depthwise taps run on the vector ALU in float32: with two-term operands the diagonal-MFMA form costs 3 x 16 cycles per tap
+// pair and 16 px x 16 ch tile (240 / 624 cycles for 3 x 3 / 5 x 5) against 72 / 200 cycles of packed float32 FMAs, and the
+// expanded values need no splitting at all)
 template <int KS, int S, int NKC, int MT, int NO, typename T>
 __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : (NKC <= 2 ? 4 : 3))) void mbconv_roll_kernel(RollArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -102,6 +105,13 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : (NKC <= 2 ? 4 : 3))) v
     }
     const f32x4 sh1 = *reinterpret_cast<const f32x4*>(p.t1 + c0 + 4 * kg);
     const f32x4 t2v = *reinterpret_cast<const f32x4*>(p.t2 + c0 + 4 * kg);
+    // two-term mode: the lane's 4 channels of every tap, BN2's scale folded in (float32 vector-ALU depthwise)
+    f32x4 wv[PAIR ? NTAP : 1];
+    if constexpr (PAIR) {
+        const f32x4 s2q = *reinterpret_cast<const f32x4*>(p.s2 + c0 + 4 * kg);
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) wv[t] = *reinterpret_cast<const f32x4*>(p.taps + (long long)t * mid + c0 + 4 * kg) * s2q;
+    }
     // BN1's scale of the row's channel is folded into the bf16 weights (the shift is the accumulator's initial value), and so
     // is the SE gate of the producing block along K where that block's project conv was composed into W1
 #pragma unroll
@@ -174,7 +184,8 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : (NKC <= 2 ? 4 : 3))) v
     for (int u = 0; u < OTN; ++u) {
         const int oxl = 16 * u + frow;
         const bool ok = oxl < tw;
-        dl[u] = ring + (ok ? oxl * S * PXB : 0) + (kg & 1) * (PXB / 2);   // invalid lanes read pixel 0 (finite), dropped at the store
+        // invalid lanes read pixel 0 (finite), dropped at the store.  (two-term: the lane's 4 float32 channels of the pixel)
+        dl[u] = ring + (ok ? oxl * S * PXB : 0) + (PAIR ? kg * 16 : (kg & 1) * (PXB / 2));
         if constexpr (KS == 5) dlh[u] = dl[u] + hi * PXB;
         // two-term: byte offset of the hi half of the lane's 4 channels inside their 8-channel group (lo: + 16)
         yoff[u] = ok ? (PAIR ? (ox0 + oxl) * mid * 4 + ((c0 + 4 * kg) >> 3) * 32 + ((c0 + 4 * kg) & 7) * 2 : ((ox0 + oxl) * mid + c0 + 4 * kg) * 2) : OOB;
@@ -215,7 +226,8 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : (NKC <= 2 ? 4 : 3))) v
 #pragma unroll
             for (int kc = 0; kc < NKC; ++kc) mma_chunk(wf[kc], src[t][kc], acc);
             const f32x4 v = silu4_fast(acc) * (cmask[t] * rmask);
-            row_store4<T>(ring_e + slot_bytes + 16 * PXB * t, 4 * kg, v);
+            if constexpr (PAIR) *reinterpret_cast<f32x4*>(ring_e + slot_bytes + 16 * PXB * t + kg * 16) = v;      // float32 ring
+            else row_store4<T>(ring_e + slot_bytes + 16 * PXB * t, 4 * kg, v);
         }
     };
 
@@ -260,7 +272,36 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : (NKC <= 2 ? 4 : 3))) v
         // them out of the row loop and spills; an opaque copy of the lane's tap selector keeps them (1 + NO adds per pair) here
         int hsel = hi;
         asm volatile("" : "+v"(hsel));
-        if constexpr (KS == 5) {
+        if constexpr (PAIR) {
+            // float32 depthwise on the vector ALU: per tap one 16-byte ring read (4 channels of the lane's pixel) and two packed FMAs
+            // per output tile; ring offsets are immediates (PH is a template constant), one window row of taps per batch
+            f32x4 acc[OTN];
+#pragma unroll
+            for (int u = 0; u < OTN; ++u) acc[u] = t2v;
+#pragma unroll
+            for (int dy = 0; dy < KS; ++dy) {
+                f32x4 e[KS][OTN];
+#pragma unroll
+                for (int dx = 0; dx < KS; ++dx)
+#pragma unroll
+                    for (int u = 0; u < OTN; ++u)
+                        e[dx][u] = *reinterpret_cast<const f32x4*>(dl[u] + ((PH + dy) % KS) * rowbytes + dx * PXB);
+#pragma unroll
+                for (int dx = 0; dx < KS; ++dx)
+#pragma unroll
+                    for (int u = 0; u < OTN; ++u) acc[u] = e[dx][u] * wv[dy * KS + dx] + acc[u];
+                __builtin_amdgcn_sched_barrier(0);              // rows stay rows: hoisting every read of the window would spill
+            }
+#pragma unroll
+            for (int u = 0; u < OTN; ++u) {
+                const f32x4 ov = silu4_fast(acc[u]);
+                const int yo = yoff[u];
+                const float vm = yo == OOB ? 0.f : 1.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pl[r] += ov[r] * vm;
+                store_out(ov, yo, yrow);
+            }
+        } else if constexpr (KS == 5) {
             // 5 x 5 (round 3, as in mbconv_wide.hip): every tap pair is expanded ONCE per row and applied to all NO tiles (the row used
             // to be walked in groups of two tiles, each re-expanding the 13 diagonal operands); the B operands of a batch of G pairs x
             // NO tiles are requested before the batch's first MFMA and the operands are expanded while they travel; pairs whose two
@@ -396,6 +437,7 @@ RollGeometry pick_roll(int H, int W, int Cin, int mid, int k, int stride, bool p
         if (iwa > iwa_max) continue;
         // the prefetched rows (stride x IWa/16 tiles x K-chunks fragments) must fit the register budget without spills
         const int mt = iwa / 16;
+        if (pair && k == 5 && g.nkc > 1 && mt >= 3) continue;     // (two-term, 25 resident tap vectors + two-term X fragments: spills at 256 registers)
         if (stride == 1) {
             if (mt == 4 && g.nkc > 1 && k == 5) continue;
         } else {

@@ -78,10 +78,11 @@ constexpr int WIDE_HDR = 64 + 1024;                // LDS header: arrival counte
 
 // KS taps per side, S stride, NKC = 64-byte K chunks of Cin, MT input tiles (16 px) per strip row, NO output tiles per strip
 // row, NPL = 16-byte X pieces a lane stages per row.  Register budget: 128 (up to 16 waves per CU)
-// T: bf16_t, or bf16p_t (dtype 2, two-term bf16: X, W1, both rings and Y carry hi + lo, every MFMA becomes three; NKC then counts
-// 128-byte chunks - still 32 channels each; register budget 256, up to 8 waves per CU)
+// T: bf16_t, or bf16p_t (dtype 2, two-term bf16: X, W1, the X ring and Y carry hi + lo and the expand GEMM takes three MFMAs per
+// chunk; NKC then counts 128-byte chunks - still 32 channels each; register budget 256: workgroups of at most 8 waves, 8 waves per
+// CU.  The expanded ring holds FLOAT32 there and the depthwise taps run on the vector ALU, see mbconv_roll.hip)
 template <int KS, int S, int NKC, int MT, int NO, int NPL, typename T>
-__global__ __launch_bounds__(1024, (IsPair<T>::value ? 2 : 4)) void mbconv_wide_kernel(WideArgs p) {
+__global__ __launch_bounds__((IsPair<T>::value ? 512 : 1024), (IsPair<T>::value ? 2 : 4)) void mbconv_wide_kernel(WideArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr bool PAIR = IsPair<T>::value;
     constexpr int PB = OpGeom<T>::PIECE, CHB = OpGeom<T>::CHUNK;     // bytes of a lane's operand piece / of a 32-channel K-chunk
@@ -127,6 +128,13 @@ __global__ __launch_bounds__(1024, (IsPair<T>::value ? 2 : 4)) void mbconv_wide_
     }
     const f32x4 sh1 = *reinterpret_cast<const f32x4*>(p.t1 + c0 + 4 * kg);
     const f32x4 t2v = *reinterpret_cast<const f32x4*>(p.t2 + c0 + 4 * kg);
+    // two-term mode: the lane's 4 channels of every tap, BN2's scale folded in (float32 vector-ALU depthwise)
+    f32x4 wv[PAIR ? NTAP : 1];
+    if constexpr (PAIR) {
+        const f32x4 s2q = *reinterpret_cast<const f32x4*>(p.s2 + c0 + 4 * kg);
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) wv[t] = *reinterpret_cast<const f32x4*>(p.taps + (long long)t * mid + c0 + 4 * kg) * s2q;
+    }
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
         const bool kv = kc * CHB + kg * PB < cbytes;
@@ -189,8 +197,13 @@ __global__ __launch_bounds__(1024, (IsPair<T>::value ? 2 : 4)) void mbconv_wide_
     }
     const int xlane = frow * p.xpitch + kg * PB;                  // B operand of the expand: pixel frow of a tile, piece kg of a chunk
     const int xtile = 16 * p.xpitch;
+    // The last K-chunk's lanes beyond Cin meet zero weights, but what they read must be FINITE (0 * NaN = NaN): beyond the last
+    // pixel of the last X slot lies the first expanded ring, whose float32 words (two-term mode) read as bf16 pairs can be NaN
+    // patterns.  Those lanes re-read the pixel's first piece instead.
+    const int xlast = ((NKC - 1) * CHB + kg * PB < cbytes) ? (NKC - 1) * CHB : -kg * PB;
     char* const ring_e = ring + frow * PXB;                       // expand store: pixel frow of a tile (channels 4*kg.. by row_store4)
-    const char* const dl = ring + frow * S * PXB + (kg & 1) * (PXB / 2);  // depthwise B operand of tile 0; tile u: + u * 16 * S * PXB
+    // depthwise B operand of tile 0; tile u: + u * 16 * S * PXB  (two-term: the lane's 4 float32 channels of the pixel)
+    const char* const dl = ring + frow * S * PXB + (PAIR ? kg * 16 : (kg & 1) * (PXB / 2));
     const char* const dlh = dl + hi * PXB;                        // ... for a pair of taps in one window row (second tap = next pixel)
     // output offsets: all lanes of the tiles before the last are inside the strip
     // (two-term: byte offset of the hi half of the lane's 4 channels inside their 8-channel group; lo: + 16)
@@ -254,14 +267,17 @@ __global__ __launch_bounds__(1024, (IsPair<T>::value ? 2 : 4)) void mbconv_wide_
         const int iy = iy_top + rel;
         if ((WIDE_ABLATE & 4) != 0 || iy < 0 || iy >= p.H) {       // TF-SAME pads the EXPANDED map: rows outside the image are zeros
 #pragma unroll
-            for (int t = 0; t < MT; ++t) row_store4<T>(ring_e + slot_bytes + 16 * PXB * t, 4 * kg, f32x4{0.f, 0.f, 0.f, 0.f});
+            for (int t = 0; t < MT; ++t) {
+                if constexpr (PAIR) *reinterpret_cast<f32x4*>(ring_e + slot_bytes + 16 * PXB * t + kg * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+                else row_store4<T>(ring_e + slot_bytes + 16 * PXB * t, 4 * kg, f32x4{0.f, 0.f, 0.f, 0.f});
+            }
             return;
         }
         const char* xb = xring + (rel & (NSX - 1)) * p.xslot_bytes + xlane;
         // the B operands of tile t + 1 are requested right after the MFMAs of tile t, so their LDS latency hides behind tile t's SiLU
         Frag<T> xf[NKC];
 #pragma unroll
-        for (int kc = 0; kc < NKC; ++kc) xf[kc] = ld_frag<T>(xb + kc * CHB);
+        for (int kc = 0; kc < NKC; ++kc) xf[kc] = ld_frag<T>(xb + (kc + 1 < NKC ? kc * CHB : xlast));
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             f32x4 acc = sh1;
@@ -270,7 +286,7 @@ __global__ __launch_bounds__(1024, (IsPair<T>::value ? 2 : 4)) void mbconv_wide_
             if (t + 1 < MT) {
                 xb += xtile;
 #pragma unroll
-                for (int kc = 0; kc < NKC; ++kc) xf[kc] = ld_frag<T>(xb + kc * CHB);
+                for (int kc = 0; kc < NKC; ++kc) xf[kc] = ld_frag<T>(xb + (kc + 1 < NKC ? kc * CHB : xlast));
             }
             __builtin_amdgcn_sched_barrier(0);
             // the inside-the-image mask as a bitwise AND with one register per tile (a packed multiply wants the mask duplicated into
@@ -279,9 +295,10 @@ __global__ __launch_bounds__(1024, (IsPair<T>::value ? 2 : 4)) void mbconv_wide_
             const f32x4 a_ = act4_w(acc);
             const unsigned cm = cmask[t];
             const float e0 = a_[0], e1 = a_[1], e2 = a_[2], e3 = a_[3];
-            row_store4<T>(ring_e + slot_bytes + 16 * PXB * t, 4 * kg,
-                          f32x4{__builtin_bit_cast(float, __builtin_bit_cast(unsigned, e0) & cm), __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e1) & cm),
-                                __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e2) & cm), __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e3) & cm)});
+            const f32x4 ev = {__builtin_bit_cast(float, __builtin_bit_cast(unsigned, e0) & cm), __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e1) & cm),
+                              __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e2) & cm), __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e3) & cm)};
+            if constexpr (PAIR) *reinterpret_cast<f32x4*>(ring_e + slot_bytes + 16 * PXB * t + kg * 16) = ev;      // float32 ring
+            else row_store4<T>(ring_e + slot_bytes + 16 * PXB * t, 4 * kg, ev);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -327,12 +344,29 @@ __global__ __launch_bounds__(1024, (IsPair<T>::value ? 2 : 4)) void mbconv_wide_
         f32x4 acc[NO];
 #pragma unroll
         for (int u = 0; u < NO; ++u) acc[u] = t2v;
+        if constexpr (PAIR) {
+            // float32 depthwise on the vector ALU (see mbconv_roll.hip): one 16-byte ring read and two packed FMAs per tap and tile
+#pragma unroll
+            for (int dy = 0; dy < ((WIDE_ABLATE & 2) ? 0 : KS); ++dy) {
+                f32x4 e[KS][NO];
+#pragma unroll
+                for (int dx = 0; dx < KS; ++dx)
+#pragma unroll
+                    for (int u = 0; u < NO; ++u)
+                        e[dx][u] = *reinterpret_cast<const f32x4*>(dl + ((PH + dy) % KS) * rowbytes + dx * PXB + u * (16 * S * PXB));
+#pragma unroll
+                for (int dx = 0; dx < KS; ++dx)
+#pragma unroll
+                    for (int u = 0; u < NO; ++u) acc[u] = e[dx][u] * wv[dy * KS + dx] + acc[u];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
 #ifndef WIDE_G
 #define WIDE_G 12
 #endif
         constexpr int G = WIDE_G / NO < NPAIR ? WIDE_G / NO : NPAIR;     // (two-term: the same count of twice as large fragments, at twice the register budget)
 #pragma unroll
-        for (int p0 = 0; p0 < ((WIDE_ABLATE & 2) ? 0 : NPAIR); p0 += G) {
+        for (int p0 = 0; p0 < ((WIDE_ABLATE & 2) || PAIR ? 0 : NPAIR); p0 += G) {
             Frag<T> bq[G][NO];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
