@@ -57,7 +57,7 @@ template <int V> struct IntC { static constexpr int value = V; };
 // pair and 16 px x 16 ch tile (240 / 624 cycles for 3 x 3 / 5 x 5) against 72 / 200 cycles of packed float32 FMAs, and the
 // expanded values need no splitting at all)
 template <int KS, int S, int NKC, int MT, int NO, typename T>
-__global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : (NKC <= 2 ? 4 : 3))) void mbconv_roll_kernel(RollArgs p) {
+__global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT <= 3 ? 3 : 2) : (NKC <= 2 ? 4 : 3))) void mbconv_roll_kernel(RollArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr bool PAIR = IsPair<T>::value;
     constexpr int PB = OpGeom<T>::PIECE, CHB = OpGeom<T>::CHUNK;     // bytes of a lane's operand piece / of a 32-channel K-chunk
@@ -428,7 +428,9 @@ RollGeometry pick_roll(int H, int W, int Cin, int mid, int k, int stride, bool p
     if (g.nkc > 2 || mid % 16 || Cin % 8) return g;
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
     const int npair = (k * k + 1) / 2;
-    const int iwa_max = k == 5 ? 48 : 64;                     // waves x KS rows x IWa x 32 B must fit the CU's LDS
+    // waves x KS rows x IWa x 32 B must fit the CU's LDS.  (two-term: 64 B per ring pixel and twice the registers per prefetched X
+    // fragment - strips of at most 48 input pixels keep the 3 x 3 kernels at three waves per SIMD)
+    const int iwa_max = (k == 5 || pair) ? 48 : 64;
     long long best = -1;
     for (int ns = 1; ns <= (Wo + 7) / 8; ++ns) {
         const int two = (Wo + ns - 1) / ns;

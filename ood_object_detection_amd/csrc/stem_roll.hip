@@ -28,6 +28,7 @@ struct SrArgs {
     void* Y; float* pool_partial;
     int B, H, W, C, Ho, Wo, pad_t, pad_l;
     int TWo, nstrips, band_rows, nbands, wpg, per_image;
+    int jsplit;                                   // channel-tile groups per (band, strip): 1 = a wave owns all C / 16 tiles; C / 16 = one tile per wave
 };
 
 typedef float f32x2r __attribute__((ext_vector_type(2)));
@@ -66,7 +67,10 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : 4)) void stem_roll_ker
     const int xcd = blockIdx.x & 7, rr_ = blockIdx.x >> 3;
     const int b = (rr_ / p.per_image) * 8 + xcd;
     if (b >= p.B) return;
-    const int q = (rr_ % p.per_image) * p.wpg + wave;              // (band, strip) of this wave
+    // (band, strip[, channel-tile group]) of this wave
+    int q = (rr_ % p.per_image) * p.wpg + wave;
+    const int jb = q % p.jsplit;                                    // first channel tile of this wave
+    q /= p.jsplit;
     const int strip = q % p.nstrips, band = q / p.nstrips;
     if (band >= p.nbands) return;                                   // waves are autonomous: no barrier follows
     const int C = p.C;
@@ -79,13 +83,14 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : 4)) void stem_roll_ker
     // K slots are (kx, c4) = 12 real values + 4 zeros; the lane (row m = frow, pieces of 8 K) holds K = 8*kg .. 8*kg + 7.
     Frag<T> wf[NJ][2];
     f32x4 sh1[NJ], t2v[NJ];
-    unsigned abits[NJ][5], abitl[PAIR ? NJ : 1][5];
+    unsigned abits[NJ][5];
+    f32x4 wv[PAIR ? NJ : 1][PAIR ? 9 : 1];          // two-term mode: float32 taps (BN2 scale folded in) of the lane's 4 channels, see mbconv_roll.hip
     const int hi = kg >> 1;
     const bool dactive = (kg & 1) == (frow >> 3);
     const int dq = (frow & 7) >> 1;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int ch = 16 * j + frow;
+        const int ch = 16 * (j + jb) + frow;
         const float rs1 = p.s1[ch], rs2 = p.s2[ch];
         typedef typename std::conditional<PAIR, float, bf16_t>::type WT;
         const WT* wrow = reinterpret_cast<const WT*>(p.Wk) + (long long)ch * 32;
@@ -107,16 +112,19 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : 4)) void stem_roll_ker
                 }
             }
         }
-        sh1[j] = *reinterpret_cast<const f32x4*>(p.t1 + 16 * j + 4 * kg);
-        t2v[j] = *reinterpret_cast<const f32x4*>(p.t2 + 16 * j + 4 * kg);
+        if constexpr (PAIR) {
+            const f32x4 s2q = *reinterpret_cast<const f32x4*>(p.s2 + 16 * (j + jb) + 4 * kg);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wv[j][t] = *reinterpret_cast<const f32x4*>(p.taps + (long long)t * C + 16 * (j + jb) + 4 * kg) * s2q;
+        }
+        sh1[j] = *reinterpret_cast<const f32x4*>(p.t1 + 16 * (j + jb) + 4 * kg);
+        t2v[j] = *reinterpret_cast<const f32x4*>(p.t2 + 16 * (j + jb) + 4 * kg);
 #pragma unroll
         for (int pr = 0; pr < 5; ++pr) {
             const int t = 2 * pr + hi;
             const bool on = dactive && t < 9;
             const float wv = on ? p.taps[(long long)(t < 9 ? t : 0) * C + ch] * rs2 : 0.f;
-            const bf16_t wvh = (bf16_t)wv;
-            abits[j][pr] = (unsigned)__builtin_bit_cast(unsigned short, wvh) << (16 * (frow & 1));
-            if constexpr (PAIR) abitl[j][pr] = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)(wv - (float)wvh)) << (16 * (frow & 1));
+            abits[j][pr] = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)wv) << (16 * (frow & 1));
         }
     }
     const int oy_b = band * p.band_rows, oy_e = min(p.Ho, oy_b + p.band_rows);
@@ -126,12 +134,6 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : 4)) void stem_roll_ker
     // lane constants.  Staging: lane l handles input pixels l and l + 64 (the 65th) of a row.
     constexpr int OOB = 0x7FFFFFF0;
     const int esz = IN == 0 ? 4 : (IN == 1 ? 2 : 1);
-    int ivoff[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int c = lane + 64 * h, ix = ix0 + c;
-        ivoff[h] = (c < 65 && ix >= 0 && ix < p.W) ? ix * esz : OOB;
-    }
     float cmask[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : 4)) void stem_roll_ker
     for (int u = 0; u < 2; ++u) {
         const int oxl = 16 * u + frow;
         const bool ok = oxl < tw;
-        dl[u] = rings + (ok ? oxl * PXB : 0) + (kg & 1) * (PXB / 2);
+        dl[u] = rings + (ok ? oxl * PXB : 0) + (PAIR ? kg * 16 : (kg & 1) * (PXB / 2));      // (two-term: a float32 ring, 4 channels per lane)
         // (two-term: byte offset of the hi half of channels 4 kg .. inside their 8-channel group; channel tile j adds 64 bytes)
         yoff[u] = ok ? (PAIR ? (ox0 + oxl) * C * 4 + ((4 * kg) >> 3) * 32 + ((4 * kg) & 7) * 2 : ((ox0 + oxl) * C + 4 * kg) * 2) : OOB;
     }
@@ -157,76 +159,70 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : 4)) void stem_roll_ker
     // im2col operand address inside a staged input row: pixel 2 * (16 t + frow) + 2 * (kg & 1), i.e. 16-byte aligned
     const int xf_lane = (2 * frow + 2 * (kg & 1)) * 8;
 
-    // One input row = 3 planes x 2 lane-halves raw values, fetched one output row ahead.  bfloat16 input: lanes 0 .. 32 load a
-    // DWORD = two pixels per plane (ix0, W and pad_l are even, so a pair never straddles the image border): 6 loads per step
-    // instead of 12 two-byte ones, and one 16-byte LDS store per lane.
-    // three steps of input rows wait in registers: an HBM round trip is several output rows of work long, one row ahead is not enough
-    constexpr int PFD = IN == 1 ? 3 : 1;                              // (float32 / uint8 inputs hold twice the registers per row: one step)
-    float raw[PFD][2][3][2];
-    unsigned rawd[PFD][2][3];
-    const int dvoff = (lane < 33 && ix0 + 2 * lane >= 0 && ix0 + 2 * lane < p.W) ? (ix0 + 2 * lane) * 2 : OOB;
+    // One input row = 3 planes, fetched THREE output rows ahead (an HBM round trip is several output rows of work long): lanes 0 .. 32
+    // load TWO adjacent pixels per plane and row - a dword of bfloat16, a dwordx2 of float32 or a 16-bit pair of uint8 (ix0, W and
+    // pad_l are even, so a pair never straddles the image border) - 6 loads per step, and commit them with one 16-byte LDS store
+    // per lane (two-term mode: one per term).  Raw values wait in registers; uint8 is normalised at the commit.
+    // (round 4: float32 / uint8 inputs used to take 12 scalar loads per step, one step ahead: 0.42 / 0.40 ms against 0.26 ms of
+    // the bfloat16 input at d0 / 640 / batch 64)
+    constexpr int PFD = 3;
+    u32x2 rawq[PFD][2][3];                                            // .x (and .y for float32): the pair's raw bits
+    const bool dvok = lane < 33 && ix0 + 2 * lane >= 0 && ix0 + 2 * lane < p.W;
+    const int dvoff = dvok ? (ix0 + 2 * lane) * esz : OOB;
     auto fetch_rows = [&](int iy0, auto SLC) {                        // input rows iy0, iy0 + 1 -> register slot SL
         constexpr int SL = decltype(SLC)::value;
-        if constexpr (IN == 1) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                int iy = iy0 + r;
-                const bool rin = iy >= 0 && iy < p.H;
-                iy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);
-#pragma unroll
-                for (int ci = 0; ci < 3; ++ci) {
-                    const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(xrs, dvoff, ci * plane + iy * p.W * 2, 0);
-                    rawd[SL][r][ci] = rin ? v : 0u;
-                }
-            }
-            return;
-        }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             int iy = iy0 + r;
-            const bool rin = iy >= 0 && iy < p.H;
-            iy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);
+            iy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);             // rows outside the image: any valid row, zeroed at the commit
 #pragma unroll
-            for (int ci = 0; ci < 3; ++ci)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int so = ci * plane + iy * p.W * esz;
-                    float v;
-                    if constexpr (IN == 0) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ivoff[h], so, 0));
-                    else if constexpr (IN == 1) v = (float)__builtin_bit_cast(bf16_t, __builtin_amdgcn_raw_buffer_load_b16(xrs, ivoff[h], so, 0));
-                    else v = ((float)__builtin_amdgcn_raw_buffer_load_b8(xrs, ivoff[h], so, 0) - (ci == 0 ? p.nmean[0] : ci == 1 ? p.nmean[1] : p.nmean[2])) /
-                             (ci == 0 ? p.nstd[0] : ci == 1 ? p.nstd[1] : p.nstd[2]);
-                    // rows / columns outside the image are TF-SAME zero padding of the INPUT (uint8: zero after normalisation too)
-                    raw[SL][r][ci][h] = (rin && ivoff[h] != OOB) ? v : 0.f;
-                }
+            for (int ci = 0; ci < 3; ++ci) {
+                const int so = ci * plane + iy * p.W * esz;
+                if constexpr (IN == 0) rawq[SL][r][ci] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, dvoff, so, 0));
+                else if constexpr (IN == 1) rawq[SL][r][ci] = u32x2{__builtin_amdgcn_raw_buffer_load_b32(xrs, dvoff, so, 0), 0u};
+                else rawq[SL][r][ci] = u32x2{(unsigned)__builtin_amdgcn_raw_buffer_load_b16(xrs, dvoff, so, 0), 0u};
+            }
         }
     };
     auto commit_rows = [&](int iy0, auto SLC) {                       // raw -> interleaved bf16 pixels in ring slots (iy & 3)
         constexpr int SL = decltype(SLC)::value;
-        if constexpr (IN == 1) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                char* dst = irows + ((iy0 + r) & 3) * SR_IROW;
-                // {c0 c1} | {c2 0} of pixel 2*lane, then of pixel 2*lane + 1
-                const u32x4 v = {(rawd[SL][r][0] & 0xFFFFu) | (rawd[SL][r][1] << 16), rawd[SL][r][2] & 0xFFFFu,
-                                 (rawd[SL][r][0] >> 16) | (rawd[SL][r][1] & 0xFFFF0000u), rawd[SL][r][2] >> 16};
-                if (lane < 36) *reinterpret_cast<u32x4*>(dst + lane * 16) = v;
-            }
-            return;
-        }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             char* dst = irows + ((iy0 + r) & 3) * SR_IROW;
+            const bool rin = iy0 + r >= 0 && iy0 + r < p.H;           // rows / columns outside the image are TF-SAME zero padding of the INPUT
+            if constexpr (IN == 1) {
+                // {c0 c1} | {c2 0} of pixel 2*lane, then of pixel 2*lane + 1
+                const unsigned m = rin ? 0xFFFFFFFFu : 0u;
+                const unsigned d0 = rawq[SL][r][0][0] & m, d1 = rawq[SL][r][1][0] & m, d2 = rawq[SL][r][2][0] & m;
+                const u32x4 v = {(d0 & 0xFFFFu) | (d1 << 16), d2 & 0xFFFFu, (d0 >> 16) | (d1 & 0xFFFF0000u), d2 >> 16};
+                if (lane < 36) *reinterpret_cast<u32x4*>(dst + lane * 16) = v;
+            } else {
+                float f[2][3];                                        // [pixel of the pair][plane]; uint8: zero AFTER normalisation too
+                const bool valid = rin && dvok;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int c = lane + 64 * h;
-                if (c < SR_IPX) {
-                    typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
-                    const bf16x4_ vh = bf16x4_{(bf16_t)raw[SL][r][0][h], (bf16_t)raw[SL][r][1][h], (bf16_t)raw[SL][r][2][h], (bf16_t)0.f};
-                    *reinterpret_cast<bf16x4_*>(dst + c * 8) = vh;
-                    if constexpr (PAIR)
-                        *reinterpret_cast<bf16x4_*>(dst + ILO + c * 8) = bf16x4_{(bf16_t)(raw[SL][r][0][h] - (float)vh[0]), (bf16_t)(raw[SL][r][1][h] - (float)vh[1]),
-                                                                                 (bf16_t)(raw[SL][r][2][h] - (float)vh[2]), (bf16_t)0.f};
+                for (int ci = 0; ci < 3; ++ci) {
+                    float v0, v1;
+                    if constexpr (IN == 0) {
+                        // (elements copied to scalars first: __builtin_bit_cast applied to an ext-vector element lvalue reads element 0)
+                        const u32x2 q2 = rawq[SL][r][ci];
+                        const unsigned a0 = q2[0], a1 = q2[1];
+                        v0 = __builtin_bit_cast(float, a0);
+                        v1 = __builtin_bit_cast(float, a1);
+                    } else {
+                        const float mean = ci == 0 ? p.nmean[0] : ci == 1 ? p.nmean[1] : p.nmean[2];
+                        const float sd = ci == 0 ? p.nstd[0] : ci == 1 ? p.nstd[1] : p.nstd[2];
+                        v0 = ((float)(rawq[SL][r][ci][0] & 0xFFu) - mean) / sd;
+                        v1 = ((float)((rawq[SL][r][ci][0] >> 8) & 0xFFu) - mean) / sd;
+                    }
+                    f[0][ci] = valid ? v0 : 0.f;
+                    f[1][ci] = valid ? v1 : 0.f;
+                }
+                const bf16x8 vh = {(bf16_t)f[0][0], (bf16_t)f[0][1], (bf16_t)f[0][2], (bf16_t)0.f, (bf16_t)f[1][0], (bf16_t)f[1][1], (bf16_t)f[1][2], (bf16_t)0.f};
+                if (lane < 36) *reinterpret_cast<bf16x8*>(dst + lane * 16) = vh;
+                if constexpr (PAIR) {
+                    const bf16x8 vl = {(bf16_t)(f[0][0] - (float)vh[0]), (bf16_t)(f[0][1] - (float)vh[1]), (bf16_t)(f[0][2] - (float)vh[2]), (bf16_t)0.f,
+                                       (bf16_t)(f[1][0] - (float)vh[4]), (bf16_t)(f[1][1] - (float)vh[5]), (bf16_t)(f[1][2] - (float)vh[6]), (bf16_t)0.f};
+                    if (lane < 36) *reinterpret_cast<bf16x8*>(dst + ILO + lane * 16) = vl;
                 }
             }
         }
@@ -252,7 +248,8 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : 4)) void stem_roll_ker
                 mma_chunk(wf[j][0], x0, acc);
                 mma_chunk(wf[j][1], x1, acc);
                 const f32x4 v = silu4r(acc) * (cmask[t] * rmask);
-                row_store4<T>(ring_e + j * SR_RING + slot_bytes + 16 * PXB * t, 4 * kg, v);
+                if constexpr (PAIR) *reinterpret_cast<f32x4*>(ring_e + j * SR_RING + slot_bytes + 16 * PXB * t + kg * 16) = v;
+                else row_store4<T>(ring_e + j * SR_RING + slot_bytes + 16 * PXB * t, 4 * kg, v);
             }
         }
     };
@@ -296,26 +293,35 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : 4)) void stem_roll_ker
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             f32x4 acc[2] = {t2v[j], t2v[j]};
+            if constexpr (PAIR) {
+                // float32 depthwise on the vector ALU (mbconv_roll.hip): one 16-byte ring read + two packed FMAs per tap and tile
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    f32x4 e[3][2];
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+                            e[dx][u] = *reinterpret_cast<const f32x4*>(dl[u] + j * SR_RING + ((PH + dy) % 3) * SR_ROWB + dx * PXB);
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) acc[u] = e[dx][u] * wv[j][dy * 3 + dx] + acc[u];
+                }
+            } else {
 #pragma unroll
             for (int pr = 0; pr < 5; ++pr) {
                 unsigned bits = abits[j][pr];
                 asm volatile("" : "+v"(bits));        // expand the diagonal operand at use: NJ x 5 hoisted fragments would spill
                 const u32x4 fr = {dq == 0 ? bits : 0u, dq == 1 ? bits : 0u, dq == 2 ? bits : 0u, dq == 3 ? bits : 0u};
-                Frag<T> af;
-                if constexpr (PAIR) {
-                    unsigned bl = abitl[j][pr];
-                    asm volatile("" : "+v"(bl));
-                    const u32x4 fl = {dq == 0 ? bl : 0u, dq == 1 ? bl : 0u, dq == 2 ? bl : 0u, dq == 3 ? bl : 0u};
-                    af.h = __builtin_bit_cast(bf16x8, fr);
-                    af.l = __builtin_bit_cast(bf16x8, fl);
-                } else {
-                    af.v = __builtin_bit_cast(bf16x8, fr);
-                }
+                Frag<bf16_t> af;
+                af.v = __builtin_bit_cast(bf16x8, fr);
                 const int ta = 2 * pr, tb = 2 * pr + 1 < 9 ? 2 * pr + 1 : 0;
                 const int offa = ((PH + ta / 3) % 3) * SR_ROWB + (ta % 3) * PXB, offb = ((PH + tb / 3) % 3) * SR_ROWB + (tb % 3) * PXB;
                 const int off = (hsel ? offb : offa) + j * SR_RING;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) mma_chunk(af, ld_frag<T>(dl[u] + off), acc[u]);
+                for (int u = 0; u < 2; ++u) mma_chunk(af, ld_frag<bf16_t>(dl[u] + off), acc[u]);
+            }
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -326,12 +332,12 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : 4)) void stem_roll_ker
                 if constexpr (PAIR) {                   // (an out-of-range offset + 16 is out of range too: the store is dropped)
                     u32x2 oh, ol;
                     pair_split4(ov, oh, ol);
-                    const int yo = yoff[u] == OOB ? OOB : yoff[u] + 64 * j;
+                    const int yo = yoff[u] == OOB ? OOB : yoff[u] + 64 * (j + jb);
                     __builtin_amdgcn_raw_buffer_store_b64(oh, yrs, yo, yrow, 0);
                     __builtin_amdgcn_raw_buffer_store_b64(ol, yrs, yo + 16, yrow, 0);
                 } else {
                     const bf16x4 ob = {(bf16_t)ov[0], (bf16_t)ov[1], (bf16_t)ov[2], (bf16_t)ov[3]};
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), yrs, yoff[u] == OOB ? OOB : yoff[u] + 32 * j, yrow, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), yrs, yoff[u] == OOB ? OOB : yoff[u] + 32 * (j + jb), yrow, 0);
                 }
             }
         }
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : 4)) void stem_roll_ker
                 pl[j][r] = v;
             }
             if (frow == 0) {
-                float* dst = p.pool_partial + ((long long)b * (p.nstrips * p.nbands) + band * p.nstrips + strip) * C + 16 * j + 4 * kg;
+                float* dst = p.pool_partial + ((long long)b * (p.nstrips * p.nbands) + band * p.nstrips + strip) * C + 16 * (j + jb) + 4 * kg;
                 *reinterpret_cast<f32x4*>(dst) = f32x4{pl[j][0], pl[j][1], pl[j][2], pl[j][3]};
             }
         }
@@ -377,8 +383,11 @@ SrGeometry pick_stem_roll(int H, int W, int C, bool pair = false) {
     g.band_rows = (Ho + g.nbands - 1) / g.nbands;
     g.nbands = (Ho + g.band_rows - 1) / g.band_rows;
     g.wpg = 4;
-    g.per_image = (g.nstrips * g.nbands + g.wpg - 1) / g.wpg;
-    g.lds = (size_t)g.wpg * ((pair ? 2 : 1) * 4 * SR_IROW + (C / 16) * 3 * 32 * (pair ? 64 : 32));
+    // (one channel tile per wave - jsplit = C / 16 - was measured for the two-term mode, whose rings allow only two waves per SIMD
+    // with all tiles in one wave: three waves per SIMD but every tile wave staging the input rows again ran 0.82 ms against 0.72)
+    const int jsplit = 1;
+    g.per_image = (g.nstrips * g.nbands * jsplit + g.wpg - 1) / g.wpg;
+    g.lds = (size_t)g.wpg * ((pair ? 2 : 1) * 4 * SR_IROW + (C / 16 / jsplit) * 3 * 32 * (pair ? 64 : 32));
     g.use = true;
     return g;
 }
@@ -403,6 +412,7 @@ int effdet_stem_roll_launch(hipStream_t st, int in_dtype, const void* X, const f
     a.B = B; a.H = H; a.W = W; a.C = C; a.Ho = same_out(H, 2); a.Wo = same_out(W, 2);
     a.pad_t = same_pad_before(H, 3, 2); a.pad_l = same_pad_before(W, 3, 2);
     a.TWo = g.TWo; a.nstrips = g.nstrips; a.band_rows = g.band_rows; a.nbands = g.nbands; a.wpg = g.wpg; a.per_image = g.per_image;
+    a.jsplit = 1;
     void (*kern)(SrArgs) = nullptr;
     const int nj = C / 16;
 #define SR_PICK(IN_, T_) (nj == 2 ? stem_roll_kernel<IN_, 2, T_> : nullptr)

@@ -1,0 +1,23 @@
+import sys, torch
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import bench as B
+from ood_object_detection_amd.effdet.bench import DetBenchPredict
+dev = 'cuda:0'
+def t(fn, reps=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+for mode in ('bf16', 'accurate'):
+    m = B.build_model('tf_efficientdet_d0', 640, 90).to(dev)
+    if mode == 'bf16': m = m.to(torch.bfloat16)
+    else: m.compute_mode = 'accurate'
+    eng = m.prepare(64, (640, 640))
+    for xin in ('bf16', 'f32', 'u8'):
+        if mode == 'accurate' and xin == 'bf16': continue
+        x = torch.randn(64, 3, 640, 640, device=dev)
+        x = x.to(torch.bfloat16) if xin == 'bf16' else (x if xin == 'f32' else (x * 50 + 128).clamp(0, 255).to(torch.uint8))
+        x = x.contiguous()
+        print(mode, xin, 'stem ms %.4f' % t(lambda: eng._stem_call(x)))

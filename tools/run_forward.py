@@ -1,14 +1,18 @@
-"""Minimal forward loop for profiling: python3 tools/run_forward.py [steps]"""
+"""Minimal forward loop for profiling: python3 tools/run_forward.py [steps] [bf16|f32|accurate]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import bench as B
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-model = B.build_model('tf_efficientdet_d0', 640, 90).to('cuda:0').to(torch.bfloat16)
+mode = sys.argv[2] if len(sys.argv) > 2 else 'bf16'
+dt = torch.bfloat16 if mode == 'bf16' else torch.float32
+model = B.build_model('tf_efficientdet_d0', 640, 90).to('cuda:0').to(dt)
+if mode == 'accurate':
+    model.compute_mode = 'accurate'
 from ood_object_detection_amd.effdet.bench import DetBenchPredict
-bench = DetBenchPredict(model).to('cuda:0')
-x = torch.randn(64, 3, 640, 640, device='cuda:0').to(torch.bfloat16)
+bench = DetBenchPredict(model, streams=1).to('cuda:0')
+x = torch.randn(64, 3, 640, 640, device='cuda:0').to(dt)
 with torch.no_grad():
     for _ in range(steps):
         bench(x)
