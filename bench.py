@@ -688,6 +688,10 @@ def main():
         'roofline': roofline, 'cpu_baseline': cpu,
     }
     out['config']['images_in_flight'] = nfl * B
+    # the limiter of image-sharded inference is the host-side feed, so the rate is quoted with the inputs already in HBM
+    # (every rank generates its batch on its own GPU before the timed region); the PCIe-inclusive rate is a separate measurement
+    out['config']['inputs'] = ('device-resident (generated on each rank\'s GPU before the timed region); host-to-device copies are not in '
+                               'the timed region - PCIe-inclusive rate: tools/pcie_rate.py (profiles/r01_q_pcie_inclusive_rate.json, DESIGN 5)')
     out['ranks'] = {'world_size': world, 'answered_all_reduce': ranks_seen, 'backend': ('rccl' if backend == 'nccl' else backend) if world > 1 else None,
                     'per_rank_images_per_sec': per_rank}
     out.update(extra)

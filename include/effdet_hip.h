@@ -39,6 +39,14 @@ extern "C" {
 #define EFFDET_F32 0
 #define EFFDET_BF16 1
 #define EFFDET_BF16X2 2          /* two-term bfloat16 values ("accurate" mode), see Conventions */
+/* Padding convention of strided convolutions / pools (timm `padding=`, effdet config.pad_type; reference call sites
+ * effdet/efficientdet.py:46,66,70,165): default TF-"SAME" (the tf_ model family); OR this flag into the `dtype` argument of an
+ * inference entry point that pads (effdet_stem_*, effdet_mbconv_expand_dw[_gated], effdet_dwconv_bn_act, effdet_maxpool_same,
+ * effdet_sepconv_fused) - or into the first selector argument of a training entry point that pads (`k` of effdet_train_dwconv_*,
+ * `op` of effdet_train_spatial, `method` of effdet_train_fpn_combine / _wgrad, `idx` of effdet_train_fpn_input_bwd, `B` of
+ * effdet_train_im2col_stem) - for pad_type='' (efficientdet_d0 / d1 on efficientnet_b0 / b1: static symmetric padding
+ * ((s-1)+(k-1))/2).  Output sizes are the same; the window of a stride-2 layer on an even map starts one pixel earlier. */
+#define EFFDET_PAD_SYMMETRIC (1 << 24)
 
 /* ABI version of this header (bumped on any signature change). */
 int effdet_abi_version(void);

@@ -29,6 +29,10 @@ SCALING = {  # name -> (channel multiplier, depth multiplier)
     'tf_efficientnet_b0': (1.0, 1.0), 'tf_efficientnet_b1': (1.0, 1.1), 'tf_efficientnet_b2': (1.1, 1.2),
     'tf_efficientnet_b3': (1.2, 1.4), 'tf_efficientnet_b4': (1.4, 1.8), 'tf_efficientnet_b5': (1.6, 2.2),
 }
+# timm's non-`tf_` variants (efficientnet_b0 ... b5: the backbones of efficientdet_d0 ... d5, the models pretrain.py:81-112 and
+# infer.py:119-149 build by default) share the architecture; they differ in the padding convention (pad_type '' = static symmetric
+# padding instead of TF-"SAME") and in BatchNorm's eps / momentum (PyTorch defaults 1e-5 / 0.1 instead of TensorFlow's 1e-3 / 0.01)
+SCALING.update({k[3:]: v for k, v in list(SCALING.items())})
 FEATURE_STAGES = (2, 4, 6)      # feature_info indices (2, 3, 4) -> strides 8, 16, 32
 BN_EPS_TF = 1e-3
 
@@ -60,8 +64,11 @@ def efficientnet_arch(name):
     return stem, stages
 
 
+_BN_KW = dict(eps=BN_EPS_TF, momentum=0.01)          # of the network being constructed (EfficientNetFeatures.__init__ sets it)
+
+
 def _bn(c):
-    return nn.BatchNorm2d(c, eps=BN_EPS_TF, momentum=0.01)
+    return nn.BatchNorm2d(c, **_BN_KW)
 
 
 class _SE(nn.Module):
@@ -109,6 +116,9 @@ class EfficientNetFeatures(nn.Module):
         self.name = name
         stem, stages = efficientnet_arch(name)
         self.arch = (stem, stages)
+        self.pad_type = 'same' if name.startswith('tf_') else ''
+        _BN_KW.clear()
+        _BN_KW.update(dict(eps=BN_EPS_TF, momentum=0.01) if name.startswith('tf_') else dict(eps=1e-5, momentum=0.1))
         # Stochastic depth (timm's `drop_path_rate` in config.backbone_args, 0.2 for every tf_efficientdet config and the value
         # pretrain.py:49,94 passes): block i of n drops its residual branch per SAMPLE with probability rate * i / n while the
         # backbone module is in training mode; applied by the training engine (train_engine.py), never at inference.
@@ -159,6 +169,10 @@ def create_backbone(name, features_only=True, out_indices=(2, 3, 4), pretrained=
     if not features_only or tuple(out_indices) != (2, 3, 4):
         raise ValueError('only features_only=True, out_indices=(2, 3, 4) is on the hot path')
     if pretrained:
-        raise RuntimeError('pretrained backbone weights need a network fetch, which is unavailable; '
-                           'load a local state-dict instead (reference: effdet/helpers.py:14-22)')
+        # timm would download ImageNet weights here.  Nothing can be fetched in this environment, and the scripts that construct
+        # EfficientDet(h) with the default pretrained_backbone=True load a complete checkpoint right afterwards (pretrain.py:137-141,
+        # infer.py:174-185, strict load): say so loudly and go on with timm's random initialisation.
+        import warnings
+        warnings.warn('pretrained backbone weights for %r cannot be fetched offline: the backbone is randomly initialised - load a '
+                      'checkpoint with load_state_dict (reference: effdet/helpers.py:14-22)' % (name,), RuntimeWarning, stacklevel=3)
     return EfficientNetFeatures(name, **kwargs)

@@ -263,21 +263,21 @@ template <typename T> DEV void row_store4(void* row, int ch, const f32x4 v) {
 __attribute__((visibility("hidden"))) int effdet_mbconv_roll_parts(int H, int W, int Cin, int mid, int k, int stride, int pair = 0);
 __attribute__((visibility("hidden"))) int effdet_mbconv_roll_launch(hipStream_t st, const void* X, const float* in_gate, void* Y, const void* W1, const float* s1, const float* t1,
                               const float* taps, const float* s2, const float* t2, float* pool_partial,
-                              int B, int H, int W, int Cin, int mid, int k, int stride, int pair = 0);
+                              int B, int H, int W, int Cin, int mid, int k, int stride, int pair = 0, int sym = 0);
 
 // mbconv_wide.hip (internal): rolling-window form for inputs wider than 64 channels (X rows shared by a workgroup through an
 // LDS ring), bf16 only; parts = SE pool partial rows per image when the form applies to the geometry, 0 otherwise
 __attribute__((visibility("hidden"))) int effdet_mbconv_wide_parts(int H, int W, int Cin, int mid, int k, int stride, int pair = 0);
 __attribute__((visibility("hidden"))) int effdet_mbconv_wide_launch(hipStream_t st, const void* X, void* Y, const void* W1, const float* s1, const float* t1,
                               const float* taps, const float* s2, const float* t2, float* pool_partial,
-                              int B, int H, int W, int Cin, int mid, int k, int stride, int pair = 0);
+                              int B, int H, int W, int Cin, int mid, int k, int stride, int pair = 0, int sym = 0);
 
 // stem_roll.hip (internal): rolling-window form of the fused stem + stage-0 depthwise, bf16 only; parts = SE pool partial rows
 // per image when the form applies, 0 otherwise
-__attribute__((visibility("hidden"))) int effdet_stem_roll_parts(int H, int W, int C, int pair = 0);
+__attribute__((visibility("hidden"))) int effdet_stem_roll_parts(int H, int W, int C, int pair = 0, int sym = 0);
 __attribute__((visibility("hidden"))) int effdet_stem_roll_launch(hipStream_t st, int in_dtype, const void* X, const float* mean, const float* stdv,
                             const void* Wk, const float* s1, const float* t1, const float* taps, const float* s2, const float* t2,
-                            void* Y, float* pool_partial, int B, int H, int W, int C, int pair = 0);
+                            void* Y, float* pool_partial, int B, int H, int W, int C, int pair = 0, int sym = 0);
 
 // train_net.hip (internal): out[g][l] (+)= alpha * sum_s in[g][s][l], summed in a fixed order
 __attribute__((visibility("hidden"))) int effdet_launch_reduce_mid(hipStream_t st, const float* in, int G, int S, long long L, float* out,
@@ -294,6 +294,14 @@ static inline int same_pad_before(int size, int k, int s) {
     return total / 2;
 }
 static inline int same_out(int size, int s) { return (size + s - 1) / s; }
+// timm's two padding conventions (create_conv2d / create_pool2d `padding=`; effdet config.pad_type): 'same' = TF-SAME above; '' =
+// static symmetric padding ((s - 1) + (k - 1)) / 2 on every side.  For the odd kernels and strides 1 | 2 of this network both give
+// ceil(size / s) outputs; they differ in where the window starts when stride 2 meets an even size (one pixel earlier for '').
+// Callers select '' by OR-ing EFFDET_PAD_SYMMETRIC into the entry point's dtype (or first selector) argument.
+static inline int pad_before(int size, int k, int s, int symmetric) {
+    return symmetric ? ((s - 1) + (k - 1)) / 2 : same_pad_before(size, k, s);
+}
+static inline int take_pad_flag(int& v) { const int f = (v & EFFDET_PAD_SYMMETRIC) ? 1 : 0; v &= ~EFFDET_PAD_SYMMETRIC; return f; }
 
 DEV float wave_reduce_sum(float v) {
 #pragma unroll

@@ -61,7 +61,10 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs p) {
                 float x;
                 if (p.in_dtype == 0) x = reinterpret_cast<const float*>(p.X)[off];
                 else if (p.in_dtype == 1) x = (float)reinterpret_cast<const bf16_t*>(p.X)[off];
-                else x = to_f<T>(from_f<T>(((float)reinterpret_cast<const unsigned char*>(p.X)[off] - p.nmean[ci]) / p.nstd[ci]));
+                else {
+                    x = ((float)reinterpret_cast<const unsigned char*>(p.X)[off] - p.nmean[ci]) / p.nstd[ci];
+                    if constexpr (!IsPair<T>::value) x = to_f<T>(from_f<T>(x));       // (two-term mode: the float32 value is the input)
+                }
                 const float* w = wl + ((ky * 3 + kx) * 3 + ci) * C + cg * 8;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] = fmaf(x, w[e], acc[e]);
@@ -125,8 +128,8 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs p) {
         for (int e = 0; e < 8; ++e) {
             float v = acc.v[e] * sc.v[e] + sh.v[e];
             if (p.act == 1) v = silu_t<T>(v);
-            // the SE average is taken over what the next layer will read: the T-rounded value
-            o.v[e] = to_f<T>(from_f<T>(v));
+            // the SE average is taken over what the next layer will read: the T-rounded value (two-term: 16 bits - below the tolerance)
+            if constexpr (IsPair<T>::value) o.v[e] = v; else o.v[e] = to_f<T>(from_f<T>(v));
             pool.v[e] += o.v[e];
         }
         store8<T>(Y + (long long)pix * p.C + c0, o);
@@ -258,10 +261,12 @@ __global__ __launch_bounds__(256) void maxpool_kernel(PoolArgs p) {
 
 static int stem_conv_common(void* stream, int in_dtype, int out_dtype, const void* X, const float* mean, const float* stdv,
                             const float* Wt, const float* scale, const float* shift, void* Y, int B, int H, int W, int Cout) {
+    const int sym = take_pad_flag(out_dtype);
     if (!X || !Wt || !scale || !shift || !Y || B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout % 8) return EFFDET_EINVAL;
-    if (in_dtype < 0 || in_dtype > 2 || (out_dtype & ~1) || (in_dtype == 2 && (!mean || !stdv))) return EFFDET_EINVAL;
+    if (in_dtype < 0 || in_dtype > 2 || out_dtype < 0 || out_dtype > 2 || (in_dtype == 2 && (!mean || !stdv))) return EFFDET_EINVAL;
+    if (out_dtype == 2 && (in_dtype == 1 || reinterpret_cast<uintptr_t>(Y) % 16)) return EFFDET_EINVAL;   // two-term: float32 / uint8 images
     StemArgs a{X, in_dtype, {0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}, Wt, scale, shift, Y, B, H, W, Cout, same_out(H, 2), same_out(W, 2),
-               same_pad_before(H, 3, 2), same_pad_before(W, 3, 2)};
+               pad_before(H, 3, 2, sym), pad_before(W, 3, 2, sym)};
     if (in_dtype == 2) for (int i = 0; i < 3; ++i) { a.nmean[i] = mean[i]; a.nstd[i] = stdv[i]; }
     const long long total = (long long)B * a.Ho * a.Wo * (Cout / 8);
     const long long blocks = (total + 255) / 256;
@@ -269,7 +274,8 @@ static int stem_conv_common(void* stream, int in_dtype, int out_dtype, const voi
     const size_t sh = (size_t)29 * Cout * sizeof(float);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (out_dtype == 0) hipLaunchKernelGGL(stem_kernel<float>, dim3((unsigned)blocks), dim3(256), sh, st, a);
-    else hipLaunchKernelGGL(stem_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), sh, st, a);
+    else if (out_dtype == 1) hipLaunchKernelGGL(stem_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), sh, st, a);
+    else hipLaunchKernelGGL(stem_kernel<bf16p_t>, dim3((unsigned)blocks), dim3(256), sh, st, a);
     return effdet_check_launch();
 }
 
@@ -361,14 +367,16 @@ extern "C" int effdet_dwconv_blocks_per_image(int Ho, int Wo, int C) {
 static int launch_dwconv(void* stream, int dtype, const void* X, void* Y, const float* Wt,
                          const float* scale, const float* shift, int act, float* pool_partial,
                          int B, int H, int W, int C, int k, int stride) {
+    const int sym = take_pad_flag(dtype);
     if (!X || !Y || !Wt || !scale || !shift || B <= 0 || H <= 0 || W <= 0) return EFFDET_EINVAL;
     if (C <= 0 || C % 8 || (k != 3 && k != 5) || (stride != 1 && stride != 2)) return EFFDET_EINVAL;
-    if ((dtype & ~1) || (act & ~1)) return EFFDET_EINVAL;
+    if (dtype < 0 || dtype > 2 || (act & ~1)) return EFFDET_EINVAL;
+    if (dtype == 2 && (reinterpret_cast<uintptr_t>(X) % 16 || reinterpret_cast<uintptr_t>(Y) % 16)) return EFFDET_EINVAL;
     DwArgs a;
     a.X = X; a.Y = Y; a.Wt = Wt; a.scale = scale; a.shift = shift; a.pool_partial = pool_partial;
     a.B = B; a.H = H; a.W = W; a.C = C; a.k = k; a.stride = stride; a.act = act;
     a.Ho = same_out(H, stride); a.Wo = same_out(W, stride);
-    a.pad_t = same_pad_before(H, k, stride); a.pad_l = same_pad_before(W, k, stride);
+    a.pad_t = pad_before(H, k, stride, sym); a.pad_l = pad_before(W, k, stride, sym);
     const int nz = dw_slices(C);
     a.CG = C / 8 / nz; a.PT = 256 / a.CG;
     const int npix = a.Ho * a.Wo;
@@ -382,9 +390,12 @@ static int launch_dwconv(void* stream, int dtype, const void* X, void* Y, const 
     if (dtype == 0) {
         if (k == 3) hipLaunchKernelGGL((dwconv_kernel<float, 3>), grid, block, sh, st, a);
         else hipLaunchKernelGGL((dwconv_kernel<float, 5>), grid, block, sh, st, a);
-    } else {
+    } else if (dtype == 1) {
         if (k == 3) hipLaunchKernelGGL((dwconv_kernel<bf16_t, 3>), grid, block, sh, st, a);
         else hipLaunchKernelGGL((dwconv_kernel<bf16_t, 5>), grid, block, sh, st, a);
+    } else {                                     // two-term bf16: the unfused fallback of the accurate mode (wide / odd geometries)
+        if (k == 3) hipLaunchKernelGGL((dwconv_kernel<bf16p_t, 3>), grid, block, sh, st, a);
+        else hipLaunchKernelGGL((dwconv_kernel<bf16p_t, 5>), grid, block, sh, st, a);
     }
     return effdet_check_launch();
 }
@@ -429,10 +440,11 @@ extern "C" int effdet_train_se_gate(void* stream, const float* partial, int nblk
 extern "C" int effdet_maxpool_same(void* stream, int dtype, const void* X, long long x_image_stride,
                                    void* Y, long long y_image_stride, int B, int H, int W, int C) {
     EFFDET_ENTER();
+    const int sym = take_pad_flag(dtype);
     if (!X || !Y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || dtype < 0 || dtype > 2) return EFFDET_EINVAL;
     if (dtype == 2 && (reinterpret_cast<uintptr_t>(X) % 16 || reinterpret_cast<uintptr_t>(Y) % 16 || x_image_stride % 4 || y_image_stride % 4)) return EFFDET_EINVAL;
     PoolArgs a{X, Y, x_image_stride, y_image_stride, B, H, W, C, same_out(H, 2), same_out(W, 2),
-               same_pad_before(H, 3, 2), same_pad_before(W, 3, 2)};
+               pad_before(H, 3, 2, sym), pad_before(W, 3, 2, sym)};
     if (a.x_image_stride <= 0) a.x_image_stride = (long long)H * W * C;
     if (a.y_image_stride <= 0) a.y_image_stride = (long long)a.Ho * a.Wo * C;
     const long long total = (long long)B * a.Ho * a.Wo * (C / 8);

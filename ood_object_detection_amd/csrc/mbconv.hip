@@ -39,6 +39,7 @@ struct MbArgs {
     FastDiv fd_ppr, fd_iw, fd_tx;               // / (16-byte pieces per input row), / IW, / tiles_x
     int tw_shift;                               // TW = 1 << tw_shift
     int dbg;                                    // phase-ablation mask; only read in the -DEFFDET_ABLATE build
+    int sym;                                    // padding convention (host side: forwarded to the rolling-window launchers)
 };
 
 constexpr int MC = 64;                          // expanded channels per pass
@@ -816,11 +817,11 @@ int launch_mb(hipStream_t st, MbArgs& a) {
         // bf16: the rolling-window form (mbconv_roll.hip) wherever its geometry applies
         if (effdet_mbconv_roll_parts(a.H, a.W, a.Cin, a.mid, a.k, a.stride) > 0)
             return effdet_mbconv_roll_launch(st, a.X, a.in_gate, a.Y, a.W1, a.s1, a.t1, a.taps, a.s2, a.t2, a.pool_partial,
-                                             a.B, a.H, a.W, a.Cin, a.mid, a.k, a.stride);
+                                             a.B, a.H, a.W, a.Cin, a.mid, a.k, a.stride, 0, a.sym);
         // wider inputs: the rolling-window form with the X rows shared through LDS (mbconv_wide.hip)
         if (!a.in_gate && effdet_mbconv_wide_parts(a.H, a.W, a.Cin, a.mid, a.k, a.stride) > 0)
             return effdet_mbconv_wide_launch(st, a.X, a.Y, a.W1, a.s1, a.t1, a.taps, a.s2, a.t2, a.pool_partial,
-                                             a.B, a.H, a.W, a.Cin, a.mid, a.k, a.stride);
+                                             a.B, a.H, a.W, a.Cin, a.mid, a.k, a.stride, 0, a.sym);
     }
     const DeepGeometry dg = pick_deep<T>(a.H, a.W, a.Cin, a.mid, a.k, a.stride);
     if (dg.use && !a.in_gate) return launch_deep<T>(st, a, dg);                    // gated inputs always take the spatial form
@@ -848,6 +849,7 @@ int launch_mb(hipStream_t st, MbArgs& a) {
 }  // namespace
 
 extern "C" int effdet_mbconv_tiles_per_image(int dtype, int H, int W, int Cin, int mid, int k, int stride) {
+    (void)take_pad_flag(dtype);                          // (no geometry depends on the padding convention)
     if (H <= 0 || W <= 0 || Cin <= 0 || mid <= 0 || (k != 3 && k != 5) || (stride != 1 && stride != 2) || dtype < 0 || dtype > 2) return EFFDET_EINVAL;
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
     if (dtype == 2) {                                   // two-term bf16: the two rolling-window forms only
@@ -870,6 +872,7 @@ extern "C" int effdet_mbconv_tiles_per_image(int dtype, int H, int W, int Cin, i
 }
 
 extern "C" int effdet_mbconv_gated_tiles_per_image(int dtype, int H, int W, int Cin, int mid, int k, int stride) {
+    (void)take_pad_flag(dtype);
     if (H <= 0 || W <= 0 || Cin <= 0 || mid <= 0 || (k != 3 && k != 5) || (stride != 1 && stride != 2) || dtype < 0 || dtype > 2) return EFFDET_EINVAL;
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
     if (dtype == 2) {
@@ -890,6 +893,7 @@ static int mbconv_common(void* stream, int dtype, const void* X, const float* in
                          const float* s2, const float* t2, float* pool_partial,
                          int B, int H, int W, int Cin, int mid, int k, int stride) {
     if (!X || !Y || !W1 || !s1 || !t1 || !taps || !s2 || !t2 || B <= 0 || H <= 0 || W <= 0) return EFFDET_EINVAL;
+    const int sym = take_pad_flag(dtype);
     if (Cin <= 0 || Cin % 8 || mid <= 0 || mid % 8 || (k != 3 && k != 5) || (stride != 1 && stride != 2) || dtype < 0 || dtype > 2) return EFFDET_EINVAL;
     if (dtype == 2) {
         // two-term bf16 (the "accurate" mode): the rolling-window forms with every operand in two terms; geometries outside them
@@ -897,16 +901,16 @@ static int mbconv_common(void* stream, int dtype, const void* X, const float* in
         if (reinterpret_cast<uintptr_t>(X) % 16 || reinterpret_cast<uintptr_t>(Y) % 16 || reinterpret_cast<uintptr_t>(W1) % 16) return EFFDET_EINVAL;
         hipStream_t st2 = reinterpret_cast<hipStream_t>(stream);
         if (effdet_mbconv_roll_parts(H, W, Cin, mid, k, stride, 1) > 0)
-            return effdet_mbconv_roll_launch(st2, X, in_gate, Y, W1, s1, t1, taps, s2, t2, pool_partial, B, H, W, Cin, mid, k, stride, 1);
+            return effdet_mbconv_roll_launch(st2, X, in_gate, Y, W1, s1, t1, taps, s2, t2, pool_partial, B, H, W, Cin, mid, k, stride, 1, sym);
         if (!in_gate && effdet_mbconv_wide_parts(H, W, Cin, mid, k, stride, 1) > 0)
-            return effdet_mbconv_wide_launch(st2, X, Y, W1, s1, t1, taps, s2, t2, pool_partial, B, H, W, Cin, mid, k, stride, 1);
+            return effdet_mbconv_wide_launch(st2, X, Y, W1, s1, t1, taps, s2, t2, pool_partial, B, H, W, Cin, mid, k, stride, 1, sym);
         return EFFDET_EINVAL;
     }
     MbArgs a;
     a.X = X; a.in_gate = in_gate; a.Y = Y; a.W1 = W1; a.s1 = s1; a.t1 = t1; a.taps = taps; a.s2 = s2; a.t2 = t2; a.pool_partial = pool_partial;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.mid = mid; a.k = k; a.stride = stride;
     a.Ho = same_out(H, stride); a.Wo = same_out(W, stride);
-    a.pad_t = same_pad_before(H, k, stride); a.pad_l = same_pad_before(W, k, stride);
+    a.pad_t = pad_before(H, k, stride, sym); a.pad_l = pad_before(W, k, stride, sym); a.sym = sym;
 #ifdef EFFDET_ABLATE
     a.dbg = getenv("EFFDET_DEBUG_SKIP") ? atoi(getenv("EFFDET_DEBUG_SKIP")) : 0;
 #else

@@ -522,11 +522,11 @@ int effdet_mbconv_roll_parts(int H, int W, int Cin, int mid, int k, int stride, 
 
 int effdet_mbconv_roll_launch(hipStream_t st, const void* X, const float* in_gate, void* Y, const void* W1, const float* s1, const float* t1,
                               const float* taps, const float* s2, const float* t2, float* pool_partial,
-                              int B, int H, int W, int Cin, int mid, int k, int stride, int pair) {
+                              int B, int H, int W, int Cin, int mid, int k, int stride, int pair, int sym) {
     const RollGeometry g = pick_roll(H, W, Cin, mid, k, stride, pair != 0);
     if (!g.use) return EFFDET_EINVAL;
     RollArgs r{X, Y, W1, in_gate, s1, t1, taps, s2, t2, pool_partial, B, H, W, Cin, mid, same_out(H, stride), same_out(W, stride),
-               same_pad_before(H, k, stride), same_pad_before(W, k, stride), g.TWo, g.nstrips, g.band_rows, g.nbands, g.IWs,
+               pad_before(H, k, stride, sym), pad_before(W, k, stride, sym), g.TWo, g.nstrips, g.band_rows, g.nbands, g.IWs,
                g.wpg, g.ngroups, g.ring_bytes, g.nstrips * g.nbands * g.ngroups};
     if (pair) {
         if (k == 3) return stride == 1 ? launch_roll_ks<3, 1, bf16p_t>(st, r, g) : launch_roll_ks<3, 2, bf16p_t>(st, r, g);

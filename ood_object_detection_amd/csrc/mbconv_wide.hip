@@ -628,7 +628,7 @@ int effdet_mbconv_wide_parts(int H, int W, int Cin, int mid, int k, int stride, 
 
 int effdet_mbconv_wide_launch(hipStream_t st, const void* X, void* Y, const void* W1, const float* s1, const float* t1,
                               const float* taps, const float* s2, const float* t2, float* pool_partial,
-                              int B, int H, int W, int Cin, int mid, int k, int stride, int pair) {
+                              int B, int H, int W, int Cin, int mid, int k, int stride, int pair, int sym) {
     const WideGeometry g = pick_wide(H, W, Cin, mid, k, stride, pair != 0);
     if (!wide_supported(g, k, stride)) return EFFDET_EINVAL;
 #ifdef WIDE_TUNE
@@ -642,7 +642,7 @@ int effdet_mbconv_wide_launch(hipStream_t st, const void* X, void* Y, const void
     WideArgs r{};
     r.X = X; r.Y = Y; r.W1 = W1; r.s1 = s1; r.t1 = t1; r.taps = taps; r.s2 = s2; r.t2 = t2; r.pool_partial = pool_partial;
     r.B = B; r.H = H; r.W = W; r.Cin = Cin; r.mid = mid; r.Ho = same_out(H, stride); r.Wo = same_out(W, stride);
-    r.pad_t = same_pad_before(H, k, stride); r.pad_l = same_pad_before(W, k, stride);
+    r.pad_t = pad_before(H, k, stride, sym); r.pad_l = pad_before(W, k, stride, sym);
     r.TWo = g.TWo; r.nstrips = g.nstrips; r.band_rows = g.band_rows; r.nbands = g.nbands; r.IWs = g.IWs; r.nw = g.nw; r.ngroups = g.ngroups;
     r.ring_bytes = g.ring_bytes; r.per_image = g.nstrips * g.nbands * g.ngroups;
     r.xpitch = g.xpitch; r.xslot_bytes = g.xslot_bytes; r.ppr = Cin * (pair ? 4 : 2) / 16; r.pieces_row = g.IWs * r.ppr;

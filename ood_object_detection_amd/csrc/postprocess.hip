@@ -286,13 +286,86 @@ __global__ __launch_bounds__(256) void topk_collect_kernel(Src src, const TopkSt
                    [](unsigned long long key, unsigned int) { return key; });
 }
 
-// Stage 1 compaction: indices of the anchors whose row maximum reaches the selected prefix (any order)
+// Stage 1 in ONE launch (round 4; it was hist + find + hist + find + collect = 5 launches of 5 - 12 us each): a workgroup of 1024
+// threads per image walks the image's row maxima (0.3 - 0.8 MB, L2-resident: the class head has just written them) three times -
+// two 11-bit radix passes with the histogram in LDS, then the compaction of the anchors that reach the selected prefix - and
+// resets the image's stage-2 state, so no memset launch is needed either.  Same arithmetic and the same selected SET as the
+// multi-launch form (the order inside `asel` is arbitrary in both).
 template <typename Src>
-__global__ __launch_bounds__(256) void anchor_collect_kernel(Src src, TopkState* state, int* asel) {
-    const int b = blockIdx.y;
+__global__ __launch_bounds__(1024) void anchor_select_kernel(Src src, int k, TopkState* state1, TopkState* state2, int* asel) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ unsigned int h[HIST_BINS];
+    __shared__ unsigned int part[1024];
+    __shared__ unsigned int sel[3];
+    __shared__ unsigned int s_cnt;
     const long long L = src.count(b);
-    collect_common(src, state + b, state + b, b, asel + (long long)b * L, (unsigned int)L,
-                   [](unsigned long long, unsigned int idx) { return (int)idx; });
+    unsigned long long prefix = 0;
+    int bits_done = 0;
+    unsigned int c_hi = 0, cand_total = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int i = tid; i < HIST_BINS; i += 1024) h[i] = 0;
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        const int shift = kPassShift[pass];
+        const unsigned int mask = (1u << kPassBits[pass]) - 1u;
+        const int pshift = 64 - bits_done;
+        unsigned int last_bin = 0xFFFFFFFFu, run = 0;
+        src.for_each(b, 0, L, tid, 1024, [&](float f, unsigned int idx) {
+            const unsigned long long key = comp_key(f, idx);
+            if (pass == 0 || (key >> pshift) == prefix) {
+                const unsigned int bin = (unsigned int)(key >> shift) & mask;
+                if (bin == last_bin) { ++run; }
+                else { if (run) atomicAdd(&h[last_bin], run); last_bin = bin; run = 1; }
+            }
+        });
+        if (run) atomicAdd(&h[last_bin], run);
+        __syncthreads();
+        // thread t owns bins 2t, 2t + 1; suffix sums from the top over the 1024 per-thread totals (Hillis-Steele, 10 steps)
+        const unsigned int l0 = h[2 * tid], l1 = h[2 * tid + 1], sown = l0 + l1;
+        unsigned int incl = sown;
+        part[tid] = incl;
+        __syncthreads();
+#pragma unroll
+        for (int off = 1; off < 1024; off <<= 1) {
+            const unsigned int add = tid + off < 1024 ? part[tid + off] : 0u;
+            __syncthreads();
+            incl += add;
+            part[tid] = incl;
+            __syncthreads();
+        }
+        const unsigned int need = (unsigned int)k - c_hi;
+        unsigned int above = incl - sown;
+        if (above < need && above + sown >= need) {
+            if (above + l1 >= need) { sel[0] = 2 * tid + 1; sel[1] = above; sel[2] = l1; }
+            else { sel[0] = 2 * tid; sel[1] = above + l1; sel[2] = l0; }
+        }
+        __syncthreads();
+        const int bits = kPassBits[pass];
+        prefix = (prefix << bits) | (unsigned long long)sel[0];
+        bits_done += bits;
+        c_hi += sel[1];
+        cand_total = c_hi + sel[2];
+        __syncthreads();
+        if (cand_total <= (unsigned int)k + 1024u) break;           // (the multi-launch form's early stop)
+    }
+    // compaction: anchors whose key reaches the prefix
+    {
+        const int pshift = 64 - bits_done;
+        int* out = asel + (long long)b * L;
+        src.for_each(b, 0, L, tid, 1024, [&](float f, unsigned int idx) {
+            const unsigned long long key = comp_key(f, idx);
+            const bool take = (key >> pshift) >= prefix;
+            const unsigned int pos = wave_append(&s_cnt, take);
+            if (take && pos < (unsigned int)L) out[pos] = (int)idx;
+        });
+    }
+    __syncthreads();
+    if (tid == 0) {
+        TopkState st{};
+        st.prefix = prefix; st.bits_done = bits_done; st.done = 1; st.c_hi = c_hi; st.cand_total = cand_total; st.cand_count = s_cnt;
+        state1[b] = st;
+        state2[b] = TopkState{};                                     // stage 2 starts from a clean state (no memset launch)
+    }
 }
 
 // After the fast stage-2 compaction (every pair whose key reaches the stage-1 threshold): when the candidates
@@ -300,7 +373,7 @@ __global__ __launch_bounds__(256) void anchor_collect_kernel(Src src, TopkState*
 // the image with the full multi-pass radix select over the gathered rows - slow, but only degenerate inputs
 // get here.
 template <typename T>
-__global__ __launch_bounds__(1024) void pair_finish_kernel(PairSrc<T> src, int k, TopkState* state, unsigned long long* cand) {
+DEV void pair_finish(const PairSrc<T>& src, int k, TopkState* state, unsigned long long* cand) {
     const int b = blockIdx.x, tid = threadIdx.x;
     TopkState* sp = state + b;
     __shared__ unsigned int h[HIST_BINS];
@@ -308,6 +381,7 @@ __global__ __launch_bounds__(1024) void pair_finish_kernel(PairSrc<T> src, int k
     __shared__ unsigned int s_chi, s_total, s_cnt;
     __shared__ int s_bits, s_done;
     if (sp->cand_count <= (unsigned int)TOPK_CAP) {                 // uniform across the workgroup
+        __syncthreads();                                            // (everyone has read cand_count before it may be touched)
         if (tid == 0) { sp->cand_total = sp->cand_count; sp->done = 1; }
         return;
     }
@@ -368,11 +442,14 @@ __global__ __launch_bounds__(256) void row_max_kernel(const T* X, long long rows
     if (lane == 0) M[r] = m;
 }
 
-template <typename T>
-__global__ __launch_bounds__(1024) void topk_sort_kernel(const TopkState* state, const unsigned long long* cand,
+// FINISH: the launch follows the prefilter's pair compaction and first closes it (pair_finish: a no-op unless the candidates
+// overflow the sort buffer) - one launch instead of two
+template <typename T, bool FINISH>
+__global__ __launch_bounds__(1024) void topk_sort_kernel(TopkState* state, unsigned long long* cand,
                                                          int k, int C, const T* cls_all, const T* box_all,
                                                          long long L, long long n_anchors,
-                                                         T* out_cls, T* out_box, long long* out_idx, long long* out_cls_id) {
+                                                         T* out_cls, T* out_box, long long* out_idx, long long* out_cls_id,
+                                                         PairSrc<T> fsrc) {
     // Merge sort, descending, TOPK_CAP slots (unused ones hold key 0, below every real key): every thread sorts
     // its 16 keys in registers, then ten merge rounds double the run length.  In a round a thread owns 16
     // consecutive output slots: a merge-path binary search finds where they start in the two input runs, a
@@ -380,7 +457,12 @@ __global__ __launch_bounds__(1024) void topk_sort_kernel(const TopkState* state,
     // the barrier.  O(n log n) compare work instead of the bitonic network's O(n log^2 n).
     extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
     const int b = blockIdx.x, tid = threadIdx.x;
-    unsigned int n = state[b].cand_total;
+    if constexpr (FINISH) {
+        pair_finish<T>(fsrc, k, state, cand);
+        __threadfence_block();
+        __syncthreads();
+    }
+    unsigned int n = FINISH ? (state[b].cand_count <= (unsigned int)TOPK_CAP ? state[b].cand_count : state[b].cand_total) : state[b].cand_total;
     if (n > (unsigned int)TOPK_CAP) n = TOPK_CAP;
     constexpr int E = TOPK_CAP / 1024;                       // 16 keys per thread
     auto slot = [](int i) { return i + (i >> 4); };          // one pad slot per 16: the per-thread 128-byte rows spread over the banks
@@ -934,11 +1016,12 @@ int topk_run(hipStream_t st, const T* cls_all, const float* anchor_max, int B, l
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(q);   q += (size_t)B * TOPK_CAP * 8;
     int* asel = reinterpret_cast<int*>(q);                                 q += (size_t)B * n_anchors * 4;
     float* rowmax = reinterpret_cast<float*>(q);
-    if (hipMemsetAsync(ws, 0, (size_t)B * (2 * sizeof(TopkState) + HIST_BINS * 4), st) != hipSuccess) return EFFDET_ELAUNCH;
+    const bool prefilter = n_anchors >= 4LL * k;
+    // (the prefilter's first kernel initialises both states itself and needs no global histogram)
+    if (!prefilter && hipMemsetAsync(ws, 0, (size_t)B * (2 * sizeof(TopkState) + HIST_BINS * 4), st) != hipSuccess) return EFFDET_ELAUNCH;
     // the sort buffer needs cand_total <= TOPK_CAP; stopping the radix passes at the next power of two >= k
     // keeps the bitonic network as small as the request allows
     unsigned int cap = 1024; while (cap < (unsigned int)k) cap <<= 1;
-    const bool prefilter = n_anchors >= 4LL * k;
     if (prefilter) {
         if (!anchor_max) {
             hipLaunchKernelGGL(row_max_kernel<T>, dim3((unsigned int)(((long long)B * n_anchors + 3) / 4)), dim3(256), 0, st,
@@ -946,17 +1029,11 @@ int topk_run(hipStream_t st, const T* cls_all, const float* anchor_max, int B, l
             anchor_max = rowmax;
         }
         RowMaxSrc<sizeof(T) == 2> src1{anchor_max, n_anchors};
-        const int S1 = sparse_segments(n_anchors);
-        for (int pass = 0; pass < 2; ++pass) {
-            hipLaunchKernelGGL(topk_hist_kernel<decltype(src1)>, dim3(S1, B), dim3(256), 0, st, src1, pass, state1, hist);
-            hipLaunchKernelGGL(topk_find_kernel, dim3(B), dim3(256), 0, st, pass, 1, k, (unsigned int)k + 1024u, state1, hist);
-        }
-        hipLaunchKernelGGL(anchor_collect_kernel<decltype(src1)>, dim3(S1, B), dim3(256), 0, st, src1, state1, asel);
+        hipLaunchKernelGGL(anchor_select_kernel<decltype(src1)>, dim3(B), dim3(1024), 0, st, src1, k, state1, state2, asel);
         // stage 2, fast path: every pair of the selected anchors that reaches the stage-1 threshold
         PairSrc<T> src2{cls_all, L, asel, state1, n_anchors, C};
         const int S2 = sparse_segments(2LL * k * C);
         hipLaunchKernelGGL(topk_collect_kernel<PairSrc<T>>, dim3(S2, B), dim3(256), 0, st, src2, (const TopkState*)state1, state2, cand);
-        hipLaunchKernelGGL(pair_finish_kernel<T>, dim3(B), dim3(1024), 0, st, src2, k, state2, cand);
     } else {
         DenseSrc<T> src{cls_all, L};
         const int S = topk_segments(B, L);
@@ -969,12 +1046,18 @@ int topk_run(hipStream_t st, const T* cls_all, const float* anchor_max, int B, l
     const size_t sort_lds = (size_t)(TOPK_CAP + TOPK_CAP / 16) * 8;
     static bool attr_done = false;               // one per T
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(topk_sort_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(topk_sort_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(topk_sort_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds) != hipSuccess)
             return EFFDET_ELAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL(topk_sort_kernel<T>, dim3(B), dim3(1024), sort_lds, st, state2, cand, k, C, cls_all, box_all, L, n_anchors,
-                       out_cls, out_box, out_indices, out_classes);
+    PairSrc<T> fsrc{cls_all, L, asel, state1, n_anchors, C};
+    if (prefilter)
+        hipLaunchKernelGGL((topk_sort_kernel<T, true>), dim3(B), dim3(1024), sort_lds, st, state2, cand, k, C, cls_all, box_all, L, n_anchors,
+                           out_cls, out_box, out_indices, out_classes, fsrc);
+    else
+        hipLaunchKernelGGL((topk_sort_kernel<T, false>), dim3(B), dim3(1024), sort_lds, st, state2, cand, k, C, cls_all, box_all, L, n_anchors,
+                           out_cls, out_box, out_indices, out_classes, fsrc);
     return effdet_check_launch();
 }
 

@@ -806,6 +806,7 @@ static int sepconv_common(
     if (nlevels < 1 || nlevels > 5 || n_in < 1 || n_in > 3 || B <= 0) return EFFDET_EINVAL;
     if (!level_hw || !in_ptr || !in_image_stride || !in_hw || !in_mode || !dw_w || !pw_w || !shift || !affine_row ||
         !out_ptr || !out_image_stride) return EFFDET_EINVAL;
+    const int sym = take_pad_flag(dtype);                // padding convention of the on-the-fly 3x3 / s2 max pool (mode 2 inputs)
     // dtype 3 (= 1 | 2): bfloat16 compute, float32 outputs; dtype 6 (= 2 | 4): two-term bf16 compute, float32 outputs
     if (dtype != 0 && dtype != 1 && dtype != 2 && dtype != 3 && dtype != 6) return EFFDET_EINVAL;
     const int out_f32 = (dtype == 3 || dtype == 6) ? 1 : 0;
@@ -854,7 +855,7 @@ static int sepconv_common(
             else if (I.mode == 1) { if (I.H * 2 != L.H || I.W * 2 != L.W) return EFFDET_EINVAL; }
             else if (I.mode == 2) {
                 if (same_out(I.H, 2) != L.H || same_out(I.W, 2) != L.W) return EFFDET_EINVAL;
-                I.pad_t = same_pad_before(I.H, 3, 2); I.pad_l = same_pad_before(I.W, 3, 2);
+                I.pad_t = pad_before(I.H, 3, 2, sym); I.pad_l = pad_before(I.W, 3, 2, sym);
             } else return EFFDET_EINVAL;
         }
     }

@@ -275,13 +275,14 @@ size_t sd_lds_bytes(int C) {
 
 // SE pool partial rows per image of the kernel effdet_stem_dw_fused[_u8] will run for (dtype, H, W, C)
 extern "C" int effdet_stem_dw_parts(int dtype, int H, int W, int C) {
+    const int sym = take_pad_flag(dtype);
     if (H <= 0 || W <= 0 || C <= 0 || dtype < 0 || dtype > 2) return EFFDET_EINVAL;
     if (dtype == 2) {                                                // two-term bf16: the rolling-window form only
-        const int parts = effdet_stem_roll_parts(H, W, C, 1);
+        const int parts = effdet_stem_roll_parts(H, W, C, 1, sym);
         return parts > 0 ? parts : EFFDET_EINVAL;
     }
     if (dtype == 1) {
-        const int parts = effdet_stem_roll_parts(H, W, C);
+        const int parts = effdet_stem_roll_parts(H, W, C, 0, sym);
         if (parts > 0) return parts;
     }
     const int Ho = same_out(H, 2), Wo = same_out(W, 2);
@@ -299,23 +300,24 @@ static int stem_dw_common(void* stream, int in_dtype, int dtype, const void* X, 
                           const float* s2, const float* t2, void* Y, float* pool_partial,
                           int B, int H, int W, int C) {
     if (!X || !Wk || !s1 || !t1 || !taps || !s2 || !t2 || !Y || B <= 0 || H <= 0 || W <= 0) return EFFDET_EINVAL;
+    const int sym = take_pad_flag(dtype);
     if (C <= 0 || C % 8 || C > 64 || in_dtype < 0 || in_dtype > 2 || dtype < 0 || dtype > 2 || (in_dtype == 2 && (!mean || !stdv))) return EFFDET_EINVAL;
     if (dtype == 2) {
         // two-term bf16 (the "accurate" mode): Wk is float32 [C][32], Y two-term; float32 or uint8 images; C = 32 and an even width
-        if (effdet_stem_roll_parts(H, W, C, 1) <= 0 || reinterpret_cast<uintptr_t>(Y) % 16) return EFFDET_EINVAL;
-        return effdet_stem_roll_launch(reinterpret_cast<hipStream_t>(stream), in_dtype, X, mean, stdv, Wk, s1, t1, taps, s2, t2, Y, pool_partial, B, H, W, C, 1);
+        if (effdet_stem_roll_parts(H, W, C, 1, sym) <= 0 || reinterpret_cast<uintptr_t>(Y) % 16) return EFFDET_EINVAL;
+        return effdet_stem_roll_launch(reinterpret_cast<hipStream_t>(stream), in_dtype, X, mean, stdv, Wk, s1, t1, taps, s2, t2, Y, pool_partial, B, H, W, C, 1, sym);
     }
     SdArgs a;
     for (int i = 0; i < 3; ++i) { a.nmean[i] = in_dtype == 2 ? mean[i] : 0.f; a.nstd[i] = in_dtype == 2 ? stdv[i] : 1.f; }
     a.X = X; a.in_dtype = in_dtype; a.Wk = Wk; a.s1 = s1; a.t1 = t1; a.taps = taps; a.s2 = s2; a.t2 = t2;
     a.Y = Y; a.pool_partial = pool_partial; a.B = B; a.H = H; a.W = W; a.C = C;
     a.Ho = same_out(H, 2); a.Wo = same_out(W, 2);
-    a.pad_t = same_pad_before(H, 3, 2); a.pad_l = same_pad_before(W, 3, 2);
+    a.pad_t = pad_before(H, 3, 2, sym); a.pad_l = pad_before(W, 3, 2, sym);
     a.tiles_x = (a.Wo + SD_TW - 1) / SD_TW; a.tiles_y = (a.Ho + SD_TH - 1) / SD_TH;
     a.vec_in = in_dtype == 1 && dtype == 1 && W % 2 == 0 && a.pad_l % 2 == 0 && reinterpret_cast<uintptr_t>(X) % 4 == 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == 1 && effdet_stem_roll_parts(H, W, C) > 0)          // bf16: the rolling-window form (stem_roll.hip) where it applies
-        return effdet_stem_roll_launch(st, in_dtype, X, mean, stdv, Wk, s1, t1, taps, s2, t2, Y, pool_partial, B, H, W, C);
+    if (dtype == 1 && effdet_stem_roll_parts(H, W, C, 0, sym) > 0)          // bf16: the rolling-window form (stem_roll.hip) where it applies
+        return effdet_stem_roll_launch(st, in_dtype, X, mean, stdv, Wk, s1, t1, taps, s2, t2, Y, pool_partial, B, H, W, C, 0, sym);
     dim3 grid(a.tiles_x * a.tiles_y, B), block(256);
     const size_t lds = dtype == 0 ? sd_lds_bytes<float>(C) : sd_lds_bytes<bf16_t>(C);
     void (*kern)(SdArgs) = nullptr;

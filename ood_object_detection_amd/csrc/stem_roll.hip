@@ -370,11 +370,11 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : 4)) void stem_roll_ker
 struct SrGeometry { bool use; int TWo, nstrips, band_rows, nbands, wpg, per_image; size_t lds; };
 
 // map sizes only (never the batch): an image's result is the same at every batch size
-SrGeometry pick_stem_roll(int H, int W, int C, bool pair = false) {
+SrGeometry pick_stem_roll(int H, int W, int C, bool pair = false, int sym = 0) {
     SrGeometry g{};
     g.use = false;
     if (C != 32) return g;                                            // 2 channel tiles (b0 .. b2 stems); wider stems spill at 128 registers
-    if (same_pad_before(W, 3, 2) % 2) return g;                       // the 16-byte operand reads need an even left pad
+    if (pad_before(W, 3, 2, sym) % 2) return g;                       // the 16-byte operand reads need an even left pad (never with pad_type='')
     const int Ho = same_out(H, 2), Wo = same_out(W, 2);
     if (Wo < 16 || Ho < 8) return g;
     g.nstrips = (Wo + SR_TW - 1) / SR_TW;
@@ -394,15 +394,15 @@ SrGeometry pick_stem_roll(int H, int W, int C, bool pair = false) {
 
 }  // namespace
 
-int effdet_stem_roll_parts(int H, int W, int C, int pair) {
-    const SrGeometry g = pick_stem_roll(H, W, C, pair != 0);
+int effdet_stem_roll_parts(int H, int W, int C, int pair, int sym) {
+    const SrGeometry g = pick_stem_roll(H, W, C, pair != 0, sym);
     return g.use ? g.nstrips * g.nbands : 0;
 }
 
 int effdet_stem_roll_launch(hipStream_t st, int in_dtype, const void* X, const float* mean, const float* stdv, const void* Wk,
                             const float* s1, const float* t1, const float* taps, const float* s2, const float* t2,
-                            void* Y, float* pool_partial, int B, int H, int W, int C, int pair) {
-    const SrGeometry g = pick_stem_roll(H, W, C, pair != 0);
+                            void* Y, float* pool_partial, int B, int H, int W, int C, int pair, int sym) {
+    const SrGeometry g = pick_stem_roll(H, W, C, pair != 0, sym);
     if (!g.use) return EFFDET_EINVAL;
     if (pair && in_dtype == 1) return EFFDET_EINVAL;                 // two-term mode takes float32 or raw uint8 images
     SrArgs a;
@@ -410,7 +410,7 @@ int effdet_stem_roll_launch(hipStream_t st, int in_dtype, const void* X, const f
     for (int i = 0; i < 3; ++i) { a.nmean[i] = in_dtype == 2 ? mean[i] : 0.f; a.nstd[i] = in_dtype == 2 ? stdv[i] : 1.f; }
     a.s1 = s1; a.t1 = t1; a.taps = taps; a.s2 = s2; a.t2 = t2; a.Y = Y; a.pool_partial = pool_partial;
     a.B = B; a.H = H; a.W = W; a.C = C; a.Ho = same_out(H, 2); a.Wo = same_out(W, 2);
-    a.pad_t = same_pad_before(H, 3, 2); a.pad_l = same_pad_before(W, 3, 2);
+    a.pad_t = pad_before(H, 3, 2, sym); a.pad_l = pad_before(W, 3, 2, sym);
     a.TWo = g.TWo; a.nstrips = g.nstrips; a.band_rows = g.band_rows; a.nbands = g.nbands; a.wpg = g.wpg; a.per_image = g.per_image;
     a.jsplit = 1;
     void (*kern)(SrArgs) = nullptr;

@@ -218,13 +218,13 @@ __global__ __launch_bounds__(256) void fpn_input_bwd_kernel(FpnBwdArgs p) {
     *reinterpret_cast<f32x4*>(p.out + i * 4) = g;
 }
 
-inline int fpn_fill_in(FpnIn& in, const float* p, int h, int w, int H, int W) {
+inline int fpn_fill_in(FpnIn& in, const float* p, int h, int w, int H, int W, int sym) {
     in.p = p; in.h = h; in.w = w; in.pad_t = 0; in.pad_l = 0;
     if (!p || h <= 0 || w <= 0) return EFFDET_EINVAL;
     if (h == H && w == W) in.delta = 0;
     else if (2 * h == H && 2 * w == W) in.delta = 1;
     else if (same_out(h, 2) == H && same_out(w, 2) == W) {
-        in.delta = -1; in.pad_t = same_pad_before(h, 3, 2); in.pad_l = same_pad_before(w, 3, 2);
+        in.delta = -1; in.pad_t = pad_before(h, 3, 2, sym); in.pad_l = pad_before(w, 3, 2, sym);
     } else return EFFDET_EINVAL;
     return 0;
 }
@@ -255,11 +255,12 @@ extern "C" int effdet_train_fpn_weights(void* stream, const float* edge_weights,
 extern "C" int effdet_train_fpn_combine(void* stream, int n, const void* const* srcs, const int* hs, const int* ws, int method,
                                         const float* wdev, float* fused, float* act, int B, int H, int W, int C) {
     EFFDET_ENTER();
+    const int sym = take_pad_flag(method);
     if (n < 2 || n > 3 || !srcs || !hs || !ws || !wdev || !fused || !act || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 ||
         method < 0 || method > 2) return EFFDET_EINVAL;
     FpnArgs p{};
     for (int i = 0; i < 3; ++i)
-        if (fpn_fill_in(p.in[i], static_cast<const float*>(srcs[i < n ? i : 0]), hs[i < n ? i : 0], ws[i < n ? i : 0], H, W)) return EFFDET_EINVAL;
+        if (fpn_fill_in(p.in[i], static_cast<const float*>(srcs[i < n ? i : 0]), hs[i < n ? i : 0], ws[i < n ? i : 0], H, W, sym)) return EFFDET_EINVAL;
     p.n = n; p.method = method == 0 ? 0 : 1; p.wdev = wdev; p.out = fused; p.out2 = act; p.B = B; p.H = H; p.W = W; p.C = C;
     const long long blocks = ((long long)B * H * W * (C / 4) + 255) / 256;
     if (blocks > 0x7fffffffLL) return EFFDET_EINVAL;
@@ -279,11 +280,12 @@ extern "C" int effdet_train_fpn_wgrad(void* stream, int n, const void* const* sr
                                       float* dots, float* grad, int B, int H, int W, int C, float* workspace,
                                       long long workspace_floats) {
     EFFDET_ENTER();
+    const int sym = take_pad_flag(method);
     if (n < 2 || n > 3 || !srcs || !hs || !ws || !wdev || !dact || !fused || !dots || !workspace || B <= 0 || H <= 0 || W <= 0 ||
         C <= 0 || C % 4 || method < 0 || method > 2 || (method < 2 && (!grad || !edge_weights))) return EFFDET_EINVAL;
     FpnArgs p{};
     for (int i = 0; i < 3; ++i)
-        if (fpn_fill_in(p.in[i], static_cast<const float*>(srcs[i < n ? i : 0]), hs[i < n ? i : 0], ws[i < n ? i : 0], H, W)) return EFFDET_EINVAL;
+        if (fpn_fill_in(p.in[i], static_cast<const float*>(srcs[i < n ? i : 0]), hs[i < n ? i : 0], ws[i < n ? i : 0], H, W, sym)) return EFFDET_EINVAL;
     long long rps;
     const int S = fpn_slices((long long)B * H * W, C, &rps);
     if (workspace_floats < (long long)S * n * C) return EFFDET_EINVAL;
@@ -304,9 +306,10 @@ extern "C" int effdet_train_fpn_wgrad(void* stream, int n, const void* const* sr
 extern "C" int effdet_train_fpn_input_bwd(void* stream, int idx, const float* src, int h, int w, const float* wdev, const float* dact,
                                           const float* fused, const float* acc, float* out, int B, int H, int W, int C) {
     EFFDET_ENTER();
+    const int sym = take_pad_flag(idx);
     FpnBwdArgs p{};
     if (idx < 0 || idx > 2 || !wdev || !dact || !fused || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 ||
-        fpn_fill_in(p.in, src, h, w, H, W)) return EFFDET_EINVAL;
+        fpn_fill_in(p.in, src, h, w, H, W, sym)) return EFFDET_EINVAL;
     p.idx = idx; p.wdev = wdev; p.dact = dact; p.fused = fused; p.acc = acc; p.out = out; p.B = B; p.H = H; p.W = W; p.C = C;
     const long long blocks = ((long long)B * h * w * (C / 4) + 255) / 256;
     if (blocks > 0x7fffffffLL) return EFFDET_EINVAL;

@@ -1711,19 +1711,22 @@ extern "C" int effdet_train_reduce_mid(void* stream, const float* in, int G, int
     return launch_reduce_mid(reinterpret_cast<hipStream_t>(stream), in, G, S, L, out, accumulate);
 }
 
-static int dw_fill(DwBwdArgs& a, int B, int H, int W, int C, int k, int stride) {
+// (k may carry EFFDET_PAD_SYMMETRIC: stripped here, so the callers' kernel dispatch sees the plain size)
+static int dw_fill(DwBwdArgs& a, int B, int H, int W, int C, int& k, int stride) {
+    const int sym = take_pad_flag(k);
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || (k != 3 && k != 5) || (stride != 1 && stride != 2)) return EFFDET_EINVAL;
     a.B = B; a.H = H; a.W = W; a.C = C; a.k = k; a.stride = stride;
     a.Ho = same_out(H, stride); a.Wo = same_out(W, stride);
-    a.pad_t = same_pad_before(H, k, stride); a.pad_l = same_pad_before(W, k, stride);
+    a.pad_t = pad_before(H, k, stride, sym); a.pad_l = pad_before(W, k, stride, sym);
     return 0;
 }
 
-static int dwf_fill(DwFwdArgs& a, int B, int H, int W, int C, int k, int stride) {
+static int dwf_fill(DwFwdArgs& a, int B, int H, int W, int C, int& k, int stride) {
+    const int sym = take_pad_flag(k);
     if (B <= 0 || B > 65535 || H <= 0 || W <= 0 || C <= 0 || C % 4 || (k != 3 && k != 5) || (stride != 1 && stride != 2)) return EFFDET_EINVAL;
     a.B = B; a.H = H; a.W = W; a.C = C;
     a.Ho = same_out(H, stride); a.Wo = same_out(W, stride);
-    a.pad_t = same_pad_before(H, k, stride); a.pad_l = same_pad_before(W, k, stride);
+    a.pad_t = pad_before(H, k, stride, sym); a.pad_l = pad_before(W, k, stride, sym);
     a.strips_x = (a.Wo + DWF_PX - 1) / DWF_PX;
     a.nstrips = a.strips_x * a.Ho;
     a.blocks_per_image = (a.nstrips + 16 * DWF_SPL - 1) / (16 * DWF_SPL);
@@ -1945,8 +1948,9 @@ extern "C" int effdet_train_bn_bwd_sums(void* stream, const float* dy, const flo
 extern "C" int effdet_train_spatial(void* stream, int op, const float* in, const float* aux, float* out,
                                     int B, int H, int W, int C) {
     EFFDET_ENTER();
+    const int sym = take_pad_flag(op);
     if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || op < 0 || op > 2 || (op == 2 && !aux)) return EFFDET_EINVAL;
-    SpArgs p{op, in, aux, out, B, H, W, C, same_out(H, 2), same_out(W, 2), same_pad_before(H, 3, 2), same_pad_before(W, 3, 2)};
+    SpArgs p{op, in, aux, out, B, H, W, C, same_out(H, 2), same_out(W, 2), pad_before(H, 3, 2, sym), pad_before(W, 3, 2, sym)};
     const long long total = (long long)B * H * W * (C / 4) * (op == 0 ? 4 : 1);
     const long long blocks = (total + 255) / 256;
     if (blocks > 0x7fffffffLL) return EFFDET_EINVAL;
@@ -1956,8 +1960,9 @@ extern "C" int effdet_train_spatial(void* stream, int op, const float* in, const
 
 extern "C" int effdet_train_im2col_stem(void* stream, const float* X, float* col, int B, int H, int W) {
     EFFDET_ENTER();
+    const int sym = take_pad_flag(B);
     if (!X || !col || B <= 0 || H <= 0 || W <= 0) return EFFDET_EINVAL;
-    Im2colArgs p{X, col, B, H, W, same_out(H, 2), same_out(W, 2), same_pad_before(H, 3, 2), same_pad_before(W, 3, 2)};
+    Im2colArgs p{X, col, B, H, W, same_out(H, 2), same_out(W, 2), pad_before(H, 3, 2, sym), pad_before(W, 3, 2, sym)};
     const long long total = (long long)B * p.Ho * p.Wo * 32;
     const long long blocks = (total + 255) / 256;
     if (blocks > 0x7fffffffLL) return EFFDET_EINVAL;

@@ -86,6 +86,31 @@ def default_detection_model_configs():
 _URL = 'https://github.com/rwightman/efficientdet-pytorch/releases/download/v0.1/'
 
 efficientdet_model_param_dict = dict(
+    # PyTorch-trained variants on timm's non-tf EfficientNets (model_config.py:90-158): symmetric padding, no redundant biases
+    efficientdet_d0=dict(
+        name='efficientdet_d0', backbone_name='efficientnet_b0', image_size=(512, 512),
+        fpn_channels=64, fpn_cell_repeats=3, box_class_repeats=3, pad_type='', redundant_bias=False,
+        backbone_args=dict(drop_path_rate=0.), url=_URL + 'efficientdet_d0-f3276ba8.pth'),
+    efficientdet_d1=dict(
+        name='efficientdet_d1', backbone_name='efficientnet_b1', image_size=(640, 640),
+        fpn_channels=88, fpn_cell_repeats=4, box_class_repeats=3, pad_type='', redundant_bias=False,
+        backbone_args=dict(drop_path_rate=0.2), url=_URL + 'efficientdet_d1-bb7e98fe.pth'),
+    efficientdet_d2=dict(
+        name='efficientdet_d2', backbone_name='efficientnet_b2', image_size=(768, 768),
+        fpn_channels=112, fpn_cell_repeats=5, box_class_repeats=3, pad_type='', redundant_bias=False,
+        backbone_args=dict(drop_path_rate=0.2), url=''),
+    efficientdet_d3=dict(
+        name='efficientdet_d3', backbone_name='efficientnet_b3', image_size=(896, 896),
+        fpn_channels=160, fpn_cell_repeats=6, box_class_repeats=4, pad_type='', redundant_bias=False,
+        backbone_args=dict(drop_path_rate=0.2), url=''),
+    efficientdet_d4=dict(
+        name='efficientdet_d4', backbone_name='efficientnet_b4', image_size=(1024, 1024),
+        fpn_channels=224, fpn_cell_repeats=7, box_class_repeats=4,
+        backbone_args=dict(drop_path_rate=0.2)),
+    efficientdet_d5=dict(
+        name='efficientdet_d5', backbone_name='efficientnet_b5', image_size=(1280, 1280),
+        fpn_channels=288, fpn_cell_repeats=7, box_class_repeats=4,
+        backbone_args=dict(drop_path_rate=0.2), url=''),
     tf_efficientdet_d0=dict(
         name='tf_efficientdet_d0', backbone_name='tf_efficientnet_b0', image_size=(512, 512),
         fpn_channels=64, fpn_cell_repeats=3, box_class_repeats=3,

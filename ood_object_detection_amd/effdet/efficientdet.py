@@ -53,8 +53,8 @@ class _Holder(nn.Module):
 
 
 def _check(config):
-    if config.pad_type != 'same':
-        raise NotImplementedError("only pad_type='same' (the tf_ model family) is built; got %r" % (config.pad_type,))
+    if config.pad_type not in ('same', ''):
+        raise NotImplementedError("pad_type must be 'same' (TF-SAME, the tf_ model family) or '' (static symmetric); got %r" % (config.pad_type,))
     if (config.act_type or 'swish') not in ('swish', 'silu') or (getattr(config, 'head_act_type', None) or 'swish') not in ('swish', 'silu'):
         raise NotImplementedError('only the swish/SiLU activation is built')
     if config.norm_layer is not None:

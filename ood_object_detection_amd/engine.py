@@ -25,6 +25,7 @@ from . import pairfmt
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 _PAIR = 2                    # dtype code of the two-term bf16 ("accurate") mode
+_PAD_SYMMETRIC = 1 << 24     # EFFDET_PAD_SYMMETRIC: OR-ed into the dtype argument of the entry points that pad
 
 
 def _same_out(n, s):
@@ -51,6 +52,10 @@ class Engine(object):
         if self.mode not in ('native', 'accurate'):
             raise ValueError("compute_mode must be 'native' or 'accurate' (got %r)" % (self.mode,))
         self.pair = self.mode == 'accurate'
+        # padding convention (timm `padding=`): TF-"SAME" for the tf_ family, static symmetric for pad_type = '' (efficientdet_d0 / d1
+        # on efficientnet_b0 / b1, the scripts' default models); the backbone follows its own name, BiFPN / heads config.pad_type
+        self.bb_pad = _PAD_SYMMETRIC if getattr(model.backbone, 'pad_type', 'same') == '' else 0
+        self.fpn_pad = _PAD_SYMMETRIC if cfg.pad_type == '' else 0
         if self.pair:
             if p0.dtype != torch.float32:
                 raise RuntimeError("compute_mode='accurate' splits float32 master weights into two bf16 terms: it needs a float32 model")
@@ -156,6 +161,7 @@ class Engine(object):
     # --------------------------------------------------------------------------------- backbone
     def _build_backbone(self, bb, H, W):
         lib, B, dt = self.lib, self.B, self.dt
+        dtp = dt | self.bb_pad                   # dtype argument of the entry points that pad (stem, depthwise): + the padding convention
         stem_c, stages = bb.arch
         plan = []
         Hs, Ws = _same_out(H, 2), _same_out(W, 2)
@@ -167,15 +173,14 @@ class Engine(object):
                 ho, wo = _same_out(h, b['s']), _same_out(w, b['s'])
                 mid_max = max(mid_max, B * ho * wo * b['mid'])
                 if b['type'] == 'ir':
-                    nblk = lib.effdet_mbconv_tiles_per_image(dt, h, w, b['cin'], b['mid'], b['k'], b['s'])
+                    nblk = lib.effdet_mbconv_tiles_per_image(dtp, h, w, b['cin'], b['mid'], b['k'], b['s'])
                     if nblk <= 0:        # no fused geometry (very wide fp32 inputs): expand GEMM + depthwise kernels
-                        if self.pair:
-                            raise NotImplementedError("compute_mode='accurate': block (cin %d, mid %d, %dx%d map, k %d, stride %d) is outside the "
-                                                      "two-term MBConv kernels' range" % (b['cin'], b['mid'], h, w, b['k'], b['s']))
+                        # (accurate mode: the two-term MBConv kernels cover inputs up to 192 channels - every block of d0; wider
+                        #  blocks take this unfused path too, with the expanded tensor in HBM)
                         nblk = lib.effdet_dwconv_blocks_per_image(ho, wo, b['mid'])
                         exp_max = max(exp_max, B * h * w * b['mid'])
                 else:
-                    nblk = max(lib.effdet_dwconv_blocks_per_image(ho, wo, b['mid']), lib.effdet_stem_dw_parts(dt, H, W, stem_c))
+                    nblk = max(lib.effdet_dwconv_blocks_per_image(ho, wo, b['mid']), lib.effdet_stem_dw_parts(dtp, H, W, stem_c))
                 if nblk <= 0:
                     raise NotImplementedError('block geometry (mid=%d) is outside the built range' % b['mid'])
                 part_max = max(part_max, B * nblk * b['mid'])
@@ -189,12 +194,12 @@ class Engine(object):
         b00, b10 = stages[0][0], (stages[1][0] if len(stages) > 1 else None)
         self._compose01 = bool(len(stages[0]) == 1 and b10 is not None and b00['type'] == 'ds' and not b00['residual']
                                and b10['type'] == 'ir' and not b10['residual'] and b00['mid'] % 8 == 0 and
-                               lib.effdet_mbconv_gated_tiles_per_image(dt, Hs, Ws, b00['mid'], b10['mid'], b10['k'], b10['s']) > 0)
+                               lib.effdet_mbconv_gated_tiles_per_image(dtp, Hs, Ws, b00['mid'], b10['mid'], b10['k'], b10['s']) > 0)
         dbuf2 = None
         if self._compose01:
             h1, w1_ = _same_out(Hs, b10['s']), _same_out(Ws, b10['s'])
             dbuf2 = self._new(B * h1 * w1_ * b10['mid'])
-            part_max = max(part_max, B * lib.effdet_mbconv_gated_tiles_per_image(dt, Hs, Ws, b00['mid'], b10['mid'], b10['k'], b10['s']) * b10['mid'])
+            part_max = max(part_max, B * lib.effdet_mbconv_gated_tiles_per_image(dtp, Hs, Ws, b00['mid'], b10['mid'], b10['k'], b10['s']) * b10['mid'])
         ebuf = self._new(exp_max) if exp_max else None
         partial = self._new(part_max, dtype=torch.float32)
         composed = None          # (W_proj folded, t3) of block 0.0 while block 1.0 is being planned
@@ -206,8 +211,8 @@ class Engine(object):
         s, t = self._f32(s), self._f32(t)
         b00 = stages[0][0]
         self._fuse_stem = (b00['type'] == 'ds' and b00['k'] == 3 and b00['s'] == 1 and stem_c <= 64)
-        if self.pair and not (self._fuse_stem and lib.effdet_stem_dw_parts(dt, H, W, stem_c) > 0):
-            raise NotImplementedError("compute_mode='accurate' needs the fused stem's rolling-window form (32 stem channels, even image width)")
+        if self._fuse_stem and self.pair and lib.effdet_stem_dw_parts(dtp, H, W, stem_c) <= 0:
+            self._fuse_stem = False              # accurate mode outside the fused stem's form (32 channels, even left pad): stem conv + depthwise
         if self._fuse_stem:
             # conv_stem + bn1 + SiLU + blocks.0.0.conv_dw + bn1 + SiLU in one launch (stem map stays in LDS)
             wk = torch.zeros(stem_c, 32, dtype=torch.float32, device=self.device)
@@ -256,9 +261,9 @@ class Engine(object):
                         t1 = t1.to(self.device) + s1.to(self.device) * (we @ t3c)
                         w1 = self._w(wcomb)
                         s1, t1 = self._f32(s1), self._f32(t1)
-                        nblk = lib.effdet_mbconv_gated_tiles_per_image(dt, h, w, cmid, b['mid'], b['k'], b['s'])
+                        nblk = lib.effdet_mbconv_gated_tiles_per_image(dtp, h, w, cmid, b['mid'], b['k'], b['s'])
                         plan.append((lib.effdet_mbconv_expand_dw_gated,
-                                     (dt, dbuf.data_ptr(), gate.data_ptr(), dbuf2.data_ptr(), w1.data_ptr(), s1.data_ptr(), t1.data_ptr(),
+                                     (dtp, dbuf.data_ptr(), gate.data_ptr(), dbuf2.data_ptr(), w1.data_ptr(), s1.data_ptr(), t1.data_ptr(),
                                       taps.data_ptr(), s2.data_ptr(), t2.data_ptr(), partial.data_ptr(),
                                       B, h, w, cmid, b['mid'], b['k'], b['s']), what + '.conv_pw(+blocks.0.0.conv_pw)+conv_dw',
                                      dict(kind='mbconv', bytes=B * (h * w * cmid + ho * wo * b['mid']) * es + b['mid'] * cmid * es,
@@ -269,13 +274,13 @@ class Engine(object):
                     else:
                       w1 = self._w(m.conv_pw.weight.reshape(b['mid'], b['cin']))
                       s1, t1 = self._f32(s1), self._f32(t1)
-                      nblk = lib.effdet_mbconv_tiles_per_image(dt, h, w, b['cin'], b['mid'], b['k'], b['s'])
+                      nblk = lib.effdet_mbconv_tiles_per_image(dtp, h, w, b['cin'], b['mid'], b['k'], b['s'])
                       mid_buf = dbuf
                     if mid_buf is dbuf2:
                         pass
                     elif nblk > 0:
                         plan.append((lib.effdet_mbconv_expand_dw,
-                                     (dt, cur.data_ptr(), dbuf.data_ptr(), w1.data_ptr(), s1.data_ptr(), t1.data_ptr(),
+                                     (dtp, cur.data_ptr(), dbuf.data_ptr(), w1.data_ptr(), s1.data_ptr(), t1.data_ptr(),
                                       taps.data_ptr(), s2.data_ptr(), t2.data_ptr(), partial.data_ptr(),
                                       B, h, w, b['cin'], b['mid'], b['k'], b['s']), what + '.conv_pw+conv_dw',
                                      dict(kind='mbconv', bytes=B * (h * w * b['cin'] + ho * wo * b['mid']) * es + b['mid'] * b['cin'] * es,
@@ -287,7 +292,7 @@ class Engine(object):
                                       t1.data_ptr(), 1, None, None, 0, ebuf.data_ptr(), 0, 0), what + '.conv_pw',
                                      self._gemm_meta(B * h * w, b['cin'], b['mid'])))
                         plan.append((lib.effdet_dwconv_bn_act,
-                                     (dt, ebuf.data_ptr(), dbuf.data_ptr(), taps.data_ptr(), s2.data_ptr(), t2.data_ptr(), 1,
+                                     (dtp, ebuf.data_ptr(), dbuf.data_ptr(), taps.data_ptr(), s2.data_ptr(), t2.data_ptr(), 1,
                                       partial.data_ptr(), B, h, w, b['mid'], b['k'], b['s']), what + '.conv_dw',
                                      dict(kind='dwconv', bytes=B * (h * w + ho * wo) * b['mid'] * es,
                                           flops=2 * b['k'] * b['k'] * B * ho * wo * b['mid'])))
@@ -302,7 +307,7 @@ class Engine(object):
                     s2, t2 = self._f32(s2), self._f32(t2)
                     nblk = lib.effdet_dwconv_blocks_per_image(ho, wo, b['mid'])
                     plan.append((lib.effdet_dwconv_bn_act,
-                                 (dt, cur.data_ptr(), dbuf.data_ptr(), taps.data_ptr(), s2.data_ptr(), t2.data_ptr(), 1,
+                                 (dtp, cur.data_ptr(), dbuf.data_ptr(), taps.data_ptr(), s2.data_ptr(), t2.data_ptr(), 1,
                                   partial.data_ptr(), B, h, w, b['mid'], b['k'], b['s']), what + '.conv_dw',
                                  dict(kind='dwconv', bytes=B * (h * w + ho * wo) * b['mid'] * es,
                                       flops=2 * b['k'] * b['k'] * B * ho * wo * b['mid'])))
@@ -357,24 +362,24 @@ class Engine(object):
             std = (ctypes.c_float * 3)(*[255.0 * v for v in self.input_std])
             if self._fuse_stem:
                 wk, s, t, taps0, s2, t2, dbuf, partial, H, W, c = self._stem
-                _lib.check(self.lib.effdet_stem_dw_fused_u8(st, self.dt, x.data_ptr(), mean, std, wk.data_ptr(), s.data_ptr(),
+                _lib.check(self.lib.effdet_stem_dw_fused_u8(st, self.dt | self.bb_pad, x.data_ptr(), mean, std, wk.data_ptr(), s.data_ptr(),
                                                             t.data_ptr(), taps0.data_ptr(), s2.data_ptr(), t2.data_ptr(),
                                                             dbuf.data_ptr(), partial.data_ptr(), self.B, H, W, c),
                            'backbone.conv_stem+blocks.0.0.conv_dw (uint8)')
             else:
                 wt, s, t, out, H, W, c = self._stem
-                _lib.check(self.lib.effdet_stem_conv_u8(st, self.dt, x.data_ptr(), mean, std, wt.data_ptr(), s.data_ptr(),
+                _lib.check(self.lib.effdet_stem_conv_u8(st, self.dt | self.bb_pad, x.data_ptr(), mean, std, wt.data_ptr(), s.data_ptr(),
                                                         t.data_ptr(), out.data_ptr(), self.B, H, W, c), 'backbone.conv_stem (uint8)')
             return
         if self._fuse_stem:
             wk, s, t, taps0, s2, t2, dbuf, partial, H, W, c = self._stem
-            _lib.check(self.lib.effdet_stem_dw_fused(st, _DT[x.dtype], self.dt, x.data_ptr(), wk.data_ptr(), s.data_ptr(),
+            _lib.check(self.lib.effdet_stem_dw_fused(st, _DT[x.dtype], self.dt | self.bb_pad, x.data_ptr(), wk.data_ptr(), s.data_ptr(),
                                                      t.data_ptr(), taps0.data_ptr(), s2.data_ptr(), t2.data_ptr(),
                                                      dbuf.data_ptr(), partial.data_ptr(), self.B, H, W, c),
                        'backbone.conv_stem+blocks.0.0.conv_dw')
         else:
             wt, s, t, out, H, W, c = self._stem
-            _lib.check(self.lib.effdet_stem_conv(st, _DT[x.dtype], self.dt, x.data_ptr(), wt.data_ptr(), s.data_ptr(),
+            _lib.check(self.lib.effdet_stem_conv(st, _DT[x.dtype], self.dt | self.bb_pad, x.data_ptr(), wt.data_ptr(), s.data_ptr(),
                                                  t.data_ptr(), out.data_ptr(), self.B, H, W, c), 'backbone.conv_stem')
 
     # ------------------------------------------------------------------------------------- BiFPN
@@ -424,7 +429,7 @@ class Engine(object):
                                 'fpn.resample.%d.conv' % level))
                 src = tmp
             out = dense(level)
-            plan.append((lib.effdet_maxpool_same, (dt, src.data_ptr(), 0, out.data_ptr(), 0, B, ph, pw_, F),
+            plan.append((lib.effdet_maxpool_same, (dt | self.fpn_pad, src.data_ptr(), 0, out.data_ptr(), 0, B, ph, pw_, F),
                          'fpn.resample.%d.downsample' % level,
                          dict(kind='maxpool', bytes=B * (ph * pw_ + hw[level][0] * hw[level][1]) * F * self.pyr_es, flops=0)))
             level_src[level] = out
@@ -543,7 +548,7 @@ class Engine(object):
             self._keep.append(c_ooff)
             ood_args = (ood['classes'], self.A, ood['energy'].data_ptr(), ood['maxlogit'].data_ptr(), ood['stride'], c_ooff)
         self._keep += [c_hw, c_ptr, c_str, c_ihw, c_mode, c_fw, c_aff, c_out, c_ostr]
-        args = (self.dt | (2 if (out_f32 and self.dt == 1) else 0) | (4 if (out_f32 and self.dt == _PAIR) else 0), self.B, nl, c_hw, n_in, c_ptr, c_str, c_ihw, c_mode, fuse_mode, c_fw, ctypes.c_float(den), pre_act,
+        args = (self.dt | (2 if (out_f32 and self.dt == 1) else 0) | (4 if (out_f32 and self.dt == _PAIR) else 0) | self.fpn_pad, self.B, nl, c_hw, n_in, c_ptr, c_str, c_ihw, c_mode, fuse_mode, c_fw, ctypes.c_float(den), pre_act,
                 taps.data_ptr(), wq.data_ptr(), scale.data_ptr() if scale is not None else None, shift.data_ptr(),
                 c_aff, post_act, F, N, c_out, c_ostr) + ood_args
         es = self.pyr_es

@@ -178,6 +178,9 @@ class _Ops(object):
         self.dev = device
         self._ws = None
         self._retired = []
+        # EFFDET_PAD_SYMMETRIC (1 << 24) or 0: the padding convention of the stage that is running (timm pad_type '' vs 'same'),
+        # OR-ed into the selector argument of every entry point that pads; set by TrainEngine._in_stage
+        self.pad = 0
 
     def st(self):
         return torch.cuda.current_stream(self.dev).cuda_stream
@@ -238,7 +241,7 @@ class _Ops(object):
         B, H, W, C = x.shape
         y = self.new(B, _same_out(H, s), _same_out(W, s), C)
         _lib.check(self.lib.effdet_train_dwconv_fwd(self.st(), x.data_ptr(), y.data_ptr(), None, taps.data_ptr(), scale.data_ptr(),
-                                                    shift.data_ptr(), None, B, H, W, C, k, s), 'effdet_train_dwconv_fwd')
+                                                    shift.data_ptr(), None, B, H, W, C, k | self.pad, s), 'effdet_train_dwconv_fwd')
         return y
 
     def dw_fwd_train(self, x, taps, scale, shift, k, s):
@@ -246,10 +249,10 @@ class _Ops(object):
         B, H, W, C = x.shape
         Ho, Wo = _same_out(H, s), _same_out(W, s)
         z, a = self.new(B, Ho, Wo, C), self.new(B, Ho, Wo, C)
-        nblk = self.lib.effdet_train_dwconv_fwd_parts(H, W, C, k, s)
+        nblk = self.lib.effdet_train_dwconv_fwd_parts(H, W, C, k | self.pad, s)
         part = self.new(B, nblk, C)
         _lib.check(self.lib.effdet_train_dwconv_fwd(self.st(), x.data_ptr(), z.data_ptr(), a.data_ptr(), taps.data_ptr(),
-                                                    scale.data_ptr(), shift.data_ptr(), part.data_ptr(), B, H, W, C, k, s),
+                                                    scale.data_ptr(), shift.data_ptr(), part.data_ptr(), B, H, W, C, k | self.pad, s),
                    'effdet_train_dwconv_fwd')
         return z, a, part, nblk
 
@@ -278,14 +281,14 @@ class _Ops(object):
         dx = self.new(B, H, W, C)
         if z is not None:
             _lib.check(self.lib.effdet_train_dwconv_bwd_dx_silu(self.st(), dy.data_ptr(), taps.data_ptr(), z.data_ptr(), dx.data_ptr(),
-                                                                B, H, W, C, k, s), 'effdet_train_dwconv_bwd_dx_silu')
+                                                                B, H, W, C, k | self.pad, s), 'effdet_train_dwconv_bwd_dx_silu')
         else:
-            _lib.check(self.lib.effdet_train_dwconv_bwd_dx(self.st(), dy.data_ptr(), taps.data_ptr(), dx.data_ptr(), B, H, W, C, k, s),
+            _lib.check(self.lib.effdet_train_dwconv_bwd_dx(self.st(), dy.data_ptr(), taps.data_ptr(), dx.data_ptr(), B, H, W, C, k | self.pad, s),
                        'effdet_train_dwconv_bwd_dx')
-        n = self.lib.effdet_train_dwconv_bwd_dw_workspace_floats(B, H, W, C, k, s)
+        n = self.lib.effdet_train_dwconv_bwd_dw_workspace_floats(B, H, W, C, k | self.pad, s)
         ws = self.ws(n)
         out = self.new(k * k + 1, C) if out is None else out.view(k * k + 1, C)
-        _lib.check(self.lib.effdet_train_dwconv_bwd_dw(self.st(), dy.data_ptr(), x.data_ptr(), out.data_ptr(), B, H, W, C, k, s,
+        _lib.check(self.lib.effdet_train_dwconv_bwd_dw(self.st(), dy.data_ptr(), x.data_ptr(), out.data_ptr(), B, H, W, C, k | self.pad, s,
                                                        ws.data_ptr(), ws.numel(), int(cmajor)), 'effdet_train_dwconv_bwd_dw')
         if cmajor:                                   # tap gradients in the parameter's [C, k*k] layout
             return dx, out.view(-1)[:k * k * C].view(C, k * k), out[k * k]
@@ -336,14 +339,14 @@ class _Ops(object):
         else:
             out = self.new(B, H, W, C)
             h, w = H, W
-        _lib.check(self.lib.effdet_train_spatial(self.st(), op, x.data_ptr(), None if aux is None else aux.data_ptr(),
+        _lib.check(self.lib.effdet_train_spatial(self.st(), op | self.pad, x.data_ptr(), None if aux is None else aux.data_ptr(),
                                                  out.data_ptr(), B, h, w, C), 'effdet_train_spatial(%d)' % op)
         return out
 
     def maxpool(self, x):
         B, H, W, C = x.shape
         y = self.new(B, _same_out(H, 2), _same_out(W, 2), C)
-        _lib.check(self.lib.effdet_maxpool_same(self.st(), 0, x.data_ptr(), 0, y.data_ptr(), 0, B, H, W, C), 'effdet_maxpool_same')
+        _lib.check(self.lib.effdet_maxpool_same(self.st(), 0 | self.pad, x.data_ptr(), 0, y.data_ptr(), 0, B, H, W, C), 'effdet_maxpool_same')
         return y
 
     # ---- whole-pyramid operators (csrc/train_levels.hip) ------------------------------------------
@@ -448,7 +451,7 @@ class _Ops(object):
         B, C = ins[0].shape[0], ins[0].shape[-1]
         fused, act = self.new(B, H, W, C), self.new(B, H, W, C)
         sp, hs, ws_ = self._fpn_srcs(ins)
-        _lib.check(self.lib.effdet_train_fpn_combine(self.st(), len(ins), sp, hs, ws_, method, wdev.data_ptr(), fused.data_ptr(),
+        _lib.check(self.lib.effdet_train_fpn_combine(self.st(), len(ins), sp, hs, ws_, method | self.pad, wdev.data_ptr(), fused.data_ptr(),
                                                      act.data_ptr(), B, H, W, C), 'effdet_train_fpn_combine')
         return fused, act
 
@@ -458,7 +461,7 @@ class _Ops(object):
         ws = self.ws(self.lib.effdet_train_fpn_dots_workspace_floats(B, H, W, C))
         out = self.new(n * C + n)
         sp, hs, ws_ = self._fpn_srcs(ins)
-        _lib.check(self.lib.effdet_train_fpn_wgrad(self.st(), n, sp, hs, ws_, method, wdev.data_ptr(), ewp.data_ptr(), dact.data_ptr(),
+        _lib.check(self.lib.effdet_train_fpn_wgrad(self.st(), n, sp, hs, ws_, method | self.pad, wdev.data_ptr(), ewp.data_ptr(), dact.data_ptr(),
                                                    fused.data_ptr(), out.data_ptr(), out[n * C:].data_ptr(), B, H, W, C,
                                                    ws.data_ptr(), ws.numel()), 'effdet_train_fpn_wgrad')
         return out[n * C:]
@@ -466,7 +469,7 @@ class _Ops(object):
     def fpn_input_bwd(self, idx, src, wdev, dact, fused, acc=None):
         B, H, W, C = fused.shape
         out = torch.empty_like(src)
-        _lib.check(self.lib.effdet_train_fpn_input_bwd(self.st(), idx, src.data_ptr(), src.shape[1], src.shape[2], wdev.data_ptr(),
+        _lib.check(self.lib.effdet_train_fpn_input_bwd(self.st(), idx | self.pad, src.data_ptr(), src.shape[1], src.shape[2], wdev.data_ptr(),
                                                        dact.data_ptr(), fused.data_ptr(), None if acc is None else acc.data_ptr(),
                                                        out.data_ptr(), B, H, W, C), 'effdet_train_fpn_input_bwd')
         return out
@@ -499,6 +502,9 @@ class TrainEngine(object):
         self.F = cfg.fpn_channels
         self.L = cfg.num_levels
         self.A = model.num_anchors
+        # padding conventions (EFFDET_PAD_SYMMETRIC for timm's pad_type ''): the backbone's follows its name, BiFPN / heads config.pad_type
+        self.bb_pad = (1 << 24) if getattr(model.backbone, 'pad_type', 'same') == '' else 0
+        self.fpn_pad = (1 << 24) if cfg.pad_type == '' else 0
         self._ones = {}
         self._tables = {'bb': _StageTables(self.ops), 'fh': _StageTables(self.ops)}
         self._stage = None                          # the stage whose forward / backward is running (None: called from outside, e.g. meta_grad)
@@ -746,10 +752,12 @@ class TrainEngine(object):
     # conv + BN parameter gradients) goes through that stage's tables: one launch per kind (see _StageTables).
     def _in_stage(self, stage, fn, *args, **kw):
         self._stage = stage if self.use_tables else None
+        self.ops.pad = self.bb_pad if stage == 'bb' else self.fpn_pad
         try:
             return fn(*args, **kw)
         finally:
             self._stage = None
+            self.ops.pad = 0
 
     def bb_forward(self, x):
         """x: [B,3,H,W] float32 (normalised) or uint8 (raw; loader normalisation applied).  -> (feats NHWC list, saved)"""
@@ -804,7 +812,7 @@ class TrainEngine(object):
         stem_c, stages = bb.arch
         Ho, Wo = _same_out(H, 2), _same_out(W, 2)
         col = ops.new(B, Ho, Wo, 32)
-        _lib.check(self.lib.effdet_train_im2col_stem(ops.st(), x.data_ptr(), col.data_ptr(), B, H, W), 'effdet_train_im2col_stem')
+        _lib.check(self.lib.effdet_train_im2col_stem(ops.st(), x.data_ptr(), col.data_ptr(), B | ops.pad, H, W), 'effdet_train_im2col_stem')
         saved = dict(blocks=[])
         # stochastic depth (timm drop_path: x / keep_prob * floor(keep_prob + U[0,1)) per sample, then + shortcut), active while the
         # backbone MODULE is in training mode - pretrain.py:168-176 only puts its BatchNorm layers in eval mode

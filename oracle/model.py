@@ -55,9 +55,16 @@ def _make_divisible(v, divisor=8):
     return new_v
 
 
+def backbone_conventions(backbone_name):
+    """-> (pad_type, BatchNorm eps) of a timm EfficientNet variant: the `tf_` family uses TF-"SAME" padding and eps 1e-3, the
+    PyTorch-trained variants (efficientnet_b0 ...) static symmetric padding ('') and nn.BatchNorm2d's default eps 1e-5 (timm's
+    efficientnet.py; absent dependency, restated - see DESIGN.md)"""
+    return ('same', 1e-3) if backbone_name.startswith('tf_') else ('', 1e-5)
+
+
 def efficientnet_spec(backbone_name):
     """Returns (stem_chs, stages) with stages = list of lists of block dicts."""
-    cm, dm = _SCALING[backbone_name]
+    cm, dm = _SCALING[backbone_name if backbone_name.startswith('tf_') else 'tf_' + backbone_name]
     stem = _make_divisible(32 * cm)
     stages = []
     in_chs = stem
@@ -143,11 +150,14 @@ def silu(x):
 # ----------------------------------------------------------------------------------------------
 # backbone
 # ----------------------------------------------------------------------------------------------
-def backbone_forward(sd, backbone_name, x, prefix='backbone.', eps=1e-3, pad_type='same', drop_scales=None):
+def backbone_forward(sd, backbone_name, x, prefix='backbone.', eps=None, pad_type=None, drop_scales=None):
     """drop_scales (training restatement): {flat block index: [B] tensor} = timm's drop_path factor floor(keep + U) / keep of the
     residual branch of that block (timm `drop_path`, layers/drop.py - absent dependency, restated from the published code:
     `x.div(keep_prob) * random_tensor` then `x += shortcut`; per-block rate drop_path_rate * idx / n_blocks)"""
     stem, stages = efficientnet_spec(backbone_name)
+    conv_pad, conv_eps = backbone_conventions(backbone_name)
+    pad_type = conv_pad if pad_type is None else pad_type           # (the backbone follows ITS name, not the detector's config.pad_type)
+    eps = conv_eps if eps is None else eps
     flat_idx = 0
     g = lambda k: sd[prefix + k]
     x = conv2d_pad(x, g('conv_stem.weight'), None, 2, pad_type)
@@ -293,9 +303,9 @@ def efficientdet_forward(sd, cfg, x, fpn_nodes, mode='full_net', drop_scales=Non
     sd = {k: v.float() for k, v in sd.items() if torch.is_tensor(v)}
     info = backbone_feature_info(cfg.backbone_name)
     if mode == 'bb':
-        return backbone_forward(sd, cfg.backbone_name, x, pad_type=cfg.pad_type, drop_scales=drop_scales)
+        return backbone_forward(sd, cfg.backbone_name, x, drop_scales=drop_scales)
     if mode in ('full_net', 'fpn', 'supp_bb'):
-        feats = backbone_forward(sd, cfg.backbone_name, x, pad_type=cfg.pad_type, drop_scales=drop_scales)
+        feats = backbone_forward(sd, cfg.backbone_name, x, drop_scales=drop_scales)
         activs = bifpn_forward(sd, cfg, feats, fpn_nodes, info)
         if mode == 'fpn':
             return feats, activs

@@ -79,6 +79,52 @@ def test_state_dict_layout_matches_reference(golden, tag, name):
     assert list(mine.keys()) == list(ref.keys())       # same order too
 
 
+@pytest.mark.parametrize('tag,name', [('d0', 'efficientdet_d0'), ('d1', 'efficientdet_d1')])
+def test_state_dict_layout_matches_reference_pad0(golden, tag, name):
+    """the PyTorch-trained family (pad_type '', redundant_bias False: no conv_pw / resample-conv biases in front of a BN): keys,
+    shapes and order equal the reference module tree's, so rwightman's efficientdet_d0 / d1 checkpoints load strictly"""
+    from ood_object_detection_amd.effdet.config import get_efficientdet_config
+    from ood_object_detection_amd.effdet.efficientdet import EfficientDet
+    g = golden('bifpn_head_pad0')
+    size, ncls, _ = [int(v) for v in g[tag + '_meta']]
+    cfg = get_efficientdet_config(name)
+    cfg.image_size = (size, size)
+    cfg.num_classes = ncls
+    m = EfficientDet(cfg, pretrained_backbone=False)
+    sd = m.state_dict()
+    mine = {k: list(v.shape) for k, v in sd.items() if not k.endswith('num_batches_tracked')}
+    ref = {str(k): json.loads(str(s)) for k, s in zip(g[tag + '_keys'], g[tag + '_shapes'])}
+    assert mine == ref
+    assert list(mine.keys()) == list(ref.keys())
+    assert m.backbone.pad_type == '' and m.backbone.bn1.eps == 1e-5 and m.backbone.bn1.momentum == 0.1      # timm's non-tf defaults
+    assert m.fpn.cell[0].fnode[0].after_combine.conv.bn.eps == 1e-3                                       # config.norm_kwargs
+
+
+def test_scripts_default_models_construct():
+    """pretrain.py:81-112 and infer.py:119-149 build `default_detection_model_configs()` updated with these dicts and call
+    EfficientDet(h): `--model d0` (the default) and `--model d1` are efficientdet_d0 / d1 on efficientnet_b0 / b1 with
+    pad_type '' and redundant_bias False; `--model d3` is tf_efficientdet_d3."""
+    import torch
+    from ood_object_detection_amd.effdet.config import default_detection_model_configs
+    from ood_object_detection_amd.effdet.efficientdet import EfficientDet
+    dicts = [dict(name='efficientdet_d0', backbone_name='efficientnet_b0', image_size=(640, 640), fpn_channels=64, fpn_cell_repeats=3,
+                  box_class_repeats=3, pad_type='', redundant_bias=False, backbone_args=dict(drop_path_rate=0.2)),
+             dict(name='efficientdet_d1', backbone_name='efficientnet_b1', image_size=(640, 640), fpn_channels=88, fpn_cell_repeats=4,
+                  box_class_repeats=3, pad_type='', redundant_bias=False, backbone_args=dict(drop_path_rate=0.2)),
+             dict(name='tf_efficientdet_d3', backbone_name='tf_efficientnet_b3', image_size=(640, 640), fpn_channels=160,
+                  fpn_cell_repeats=6, box_class_repeats=4, backbone_args=dict(drop_path_rate=0.2))]
+    for d in dicts:
+        h = default_detection_model_configs()
+        h.update(d)
+        h.num_levels = h.max_level - h.min_level + 1
+        m = EfficientDet(h)
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        m.load_state_dict(sd, strict=True)
+        has_bias = any(k.endswith('conv_rep.0.conv_pw.bias') for k in sd)
+        assert has_bias == (d.get('redundant_bias', True))
+        assert m.backbone.pad_type == ('same' if d['backbone_name'].startswith('tf_') else '')
+
+
 def test_reset_head_and_param_count():
     from ood_object_detection_amd.effdet.factory import create_model
     m = create_model('tf_efficientdet_d0', num_classes=90)

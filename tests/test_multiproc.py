@@ -90,22 +90,24 @@ def _run_bench_parent(extra_args, env_extra=None, script='bench.py'):
     return subprocess.run([sys.executable, os.path.join(root, script)] + extra_args, env=env, capture_output=True, text=True, timeout=300)
 
 
+@pytest.mark.parametrize('n', [2, 8])
 @pytest.mark.parametrize('script', ['bench.py', os.path.join('tools', 'pretrain_bench.py')])
-def test_bench_gpus_n_launches_n_ranks_itself(script):
-    """`python bench.py --gpus 2` with no launcher around it: the parent starts two rank processes (RANK / LOCAL_RANK / WORLD_SIZE /
-    MASTER_* set) BEFORE touching the GPU - here a GPU-free worker over gloo - waits, and exits with the worst child code"""
+def test_bench_gpus_n_launches_n_ranks_itself(script, n):
+    """`python bench.py --gpus N` with no launcher around it: the parent starts N rank processes (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set) BEFORE touching the GPU - here GPU-free workers over gloo, two and eight of them (the driver's largest node) -
+    waits, and exits with the worst child code"""
     import json
-    r = _run_bench_parent(['--gpus', '2', '--steps', '1', '--warmup', '0'], script=script)
+    r = _run_bench_parent(['--gpus', str(n), '--steps', '1', '--warmup', '0'], script=script)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
-    assert line['n_gpus'] == 2 and line['ranks']['answered_all_reduce'] == 2 and line['ranks']['world_size'] == 2
-    assert line['ranks']['per_rank_images_per_sec'] == [100.0, 101.0]
-    # a rank that dies takes the job down with its exit code (the other rank would wait for it in the rendezvous for ever)
-    r = _run_bench_parent(['--gpus', '2'], env_extra={'EFFDET_FAKE_FAIL_RANK': '1'}, script=script)
+    assert line['n_gpus'] == n and line['ranks']['answered_all_reduce'] == n and line['ranks']['world_size'] == n
+    assert line['ranks']['per_rank_images_per_sec'] == [100.0 + i for i in range(n)]
+    # a rank that dies takes the job down with its exit code (the other ranks would wait for it in the rendezvous for ever)
+    r = _run_bench_parent(['--gpus', str(n)], env_extra={'EFFDET_FAKE_FAIL_RANK': str(n - 1)}, script=script)
     assert r.returncode == 7
     # started by a launcher with the wrong number of ranks: refuse
-    r = _run_bench_parent(['--gpus', '2'], env_extra={'WORLD_SIZE': '3', 'RANK': '0', 'LOCAL_RANK': '0'}, script=script)
-    assert r.returncode != 0 and 'WORLD_SIZE=3' in (r.stderr + r.stdout)
+    r = _run_bench_parent(['--gpus', str(n)], env_extra={'WORLD_SIZE': str(n + 1), 'RANK': '0', 'LOCAL_RANK': '0'}, script=script)
+    assert r.returncode != 0 and 'WORLD_SIZE=%d' % (n + 1) in (r.stderr + r.stdout)
 
 
 def test_resolve_world():

@@ -516,6 +516,49 @@ def test_pretrain_step_gradients_match_oracle_autograd(batch_stats):
         _close(model.state_dict()[k], sd_after[k], 1e-4, 'running_mean update')
 
 
+def test_gradient_values_at_config5_size_640px():
+    """BASELINE config 5's own size: gradient VALUES (not only finiteness) against CPU autograd through the oracle at 640 px for
+    two images - a sample of tensors from every stage (stem, the first and last block of each backbone stage, BiFPN cells 0 and 2,
+    both head towers and predict layers), 2e-3 of each tensor's largest entry as at 256 px."""
+    from ood_object_detection_amd.effdet.loss import DetectionLoss
+    size, B, C = 640, 2, 90
+    model, cfg, nodes, sd, x = _train_setup(size, B, C, seed=43)
+    cls_t, box_t, npos = _targets(cfg, size, B, C, 9)
+    npos = npos[:B]
+    (ref_total, _, _), ref_g, _, _, _ = _oracle_step(sd, cfg, nodes, x, cls_t, box_t, npos, C, True)
+    model = model.to(DEV).float().train()
+    model.backbone.apply(lambda m: m.eval() if isinstance(m, torch.nn.BatchNorm2d) else None)
+    cfg.alpha, cfg.box_loss_weight = 0.15, 50.0
+    cls_o, box_o = model(x.to(DEV))
+    total, _, _ = DetectionLoss(cfg)(cls_o, box_o, [t.to(DEV) for t in cls_t], [t.to(DEV) for t in box_t], npos.to(DEV))
+    assert abs(total.item() - float(ref_total)) <= 1e-4 * abs(float(ref_total))
+    total.backward()
+    torch.cuda.synchronize()
+    gmax = max(float(r.abs().max()) for r in ref_g.values() if r is not None)
+    sample = ['backbone.conv_stem.weight', 'backbone.bn1.weight']
+    for si, nb in enumerate((1, 2, 2, 3, 3, 4, 1)):
+        for bi in sorted({0, nb - 1}):
+            pre = 'backbone.blocks.%d.%d.' % (si, bi)
+            sample += [pre + ('conv_pw.weight'), pre + 'conv_dw.weight', pre + 'se.conv_reduce.weight', pre + ('conv_pwl.weight' if si else 'bn2.bias')]
+    for c in (0, 2):
+        for n in (0, 3, 7):
+            sample += ['fpn.cell.%d.fnode.%d.after_combine.conv.conv_pw.weight' % (c, n), 'fpn.cell.%d.fnode.%d.after_combine.conv.conv_dw.weight' % (c, n),
+                       'fpn.cell.%d.fnode.%d.after_combine.conv.bn.weight' % (c, n)]
+    for h in ('class_net', 'box_net'):
+        sample += ['%s.conv_rep.0.conv_pw.weight' % h, '%s.conv_rep.2.conv_dw.weight' % h, '%s.bn_rep.1.2.bn.weight' % h,
+                   '%s.predict.conv_pw.weight' % h, '%s.predict.conv_pw.bias' % h, '%s.predict.conv_dw.weight' % h]
+    params = dict(model.named_parameters())
+    worst = []
+    for name in sample:
+        assert name in params and ref_g.get(name) is not None, name
+        r, g = ref_g[name], params[name].grad
+        assert g is not None, name
+        worst.append((float((g.cpu() - r).abs().max()) / max(float(r.abs().max()), 1e-5 * gmax), name))
+    worst.sort(reverse=True)
+    assert len(worst) >= 60 and worst[0][0] <= 2e-3, worst[:6]
+    model.autograd = None
+
+
 def test_stochastic_depth_fixed_masks_match_oracle():
     """pretrain.py:49,94 trains with drop_path_rate = 0.2 (timm drop_path per residual block and sample, rate * i / n): with
     FIXED keep masks the training forward and every parameter gradient match autograd through the oracle; with random masks

@@ -20,6 +20,7 @@ Fixtures written
     config.npz                model_config.get_efficientdet_config + fpn_config.bifpn_config dumps
     bifpn_head.npz            EfficientDet(config) forward (reference BiFpn/HeadNet code on stub
                               conv layers and the oracle backbone): key/shape list + outputs
+    bifpn_head_pad0.npz       the same for efficientdet_d0 / d1 (pad_type '', redundant_bias False)
     aux_losses.npz            loss.cosine_loss / smooth_l1_loss / l2_loss / SupportLoss values (+ one gradient each)
     meta_nets.npz             the reference's own MetaHead / AnchorNet / ProjectionNet classes
                               (efficientdet.py:569-830) on seeded weights and inputs: forwards, fast_weights,
@@ -262,6 +263,43 @@ def gen_bifpn_head():
     save('bifpn_head', **out)
 
 
+def gen_bifpn_head_pad0():
+    """The PyTorch-trained model family (efficientdet_d0 / d1 on efficientnet_b0 / b1, the scripts' default models,
+    pretrain.py:81-112, infer.py:119-149): pad_type = '' (static symmetric padding - the variant the timm-layer stub reproduces
+    EXACTLY: nn.Conv2d / nn.MaxPool2d with padding=((s-1)+(k-1))//2) and redundant_bias = False (bias-less separable convs).
+    EfficientDet(config).forward through the reference's BiFpn / HeadNet / FpnCombine code on seeded weights."""
+    from absl import flags
+    from effdet.config import get_efficientdet_config
+    from effdet.efficientdet import EfficientDet
+    out = {}
+    for tag, name, size, ncls, seed in (('d0', 'efficientdet_d0', 128, 3, 31), ('d1', 'efficientdet_d1', 128, 2, 32)):
+        flags.FLAGS.pretrain_classes = ncls
+        cfg = get_efficientdet_config(name)
+        assert cfg.pad_type == '' and not cfg.redundant_bias
+        cfg.image_size = (size, size)
+        model = EfficientDet(cfg, pretrained_backbone=False).eval()
+        sd = model.state_dict()
+        keys = [k for k in sd.keys() if not k.endswith('num_batches_tracked')]
+        new = {k: seeded_tensor(seed, k, sd[k].shape) for k in keys}
+        for k in sd.keys():
+            if k.endswith('num_batches_tracked'):
+                new[k] = sd[k]
+        model.load_state_dict(new, strict=True)
+        x = torch.from_numpy(seeded_array(seed, 'input', (2, 3, size, size)))
+        with torch.no_grad():
+            cls_o, box_o = model(x)
+            feats, activs = model(x, mode='fpn')
+        out[tag + '_keys'] = np.array(keys)
+        out[tag + '_shapes'] = np.array([json.dumps(list(sd[k].shape)) for k in keys])
+        out[tag + '_meta'] = np.array([size, ncls, seed])
+        for i in range(5):
+            out['%s_cls%d' % (tag, i)] = cls_o[i]
+            out['%s_box%d' % (tag, i)] = box_o[i]
+            out['%s_act%d' % (tag, i)] = activs[i]
+    flags.FLAGS.pretrain_classes = 400
+    save('bifpn_head_pad0', **out)
+
+
 def gen_meta_nets():
     """The reference's MetaHead / AnchorNet / ProjectionNet (effdet/efficientdet.py:569-830), instantiated on the CPU.
     Their constructors read absl FLAGS (supplied by the stub namespace below) and move a few buffers with
@@ -435,6 +473,6 @@ def gen_evaluation():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['anchors', 'post_process', 'decode', 'soft_nms', 'generate_detections', 'loss',
-                             'labeler', 'config', 'bifpn_head', 'evaluation', 'meta_nets', 'aux_losses']
+                             'labeler', 'config', 'bifpn_head', 'bifpn_head_pad0', 'evaluation', 'meta_nets', 'aux_losses']
     for w in which:
         globals()['gen_' + w]()

@@ -81,9 +81,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # Algorithmic HBM bytes of one step, counted (not modelled): every activation-sized tensor the training engine produces during
+    # ONE eager step (forward activations kept for the backward, gradients, workspaces: train_engine._Ops.new) is written once and
+    # read at least once -> 2 x their bytes; + the input batch, + parameters / Adam state (4 flat float32 buffers read, 3 written).
+    from ood_object_detection_amd import train_engine as _te
+    counted = {'bytes': 0, 'tensors': 0, 'on': False}
+    _new = _te._Ops.new
+
+    def counting_new(self, *shape):
+        t = _new(self, *shape)
+        if counted['on']:
+            counted['bytes'] += t.numel() * 4
+            counted['tensors'] += 1
+        return t
+    _te._Ops.new = counting_new
     losses = []
-    for _ in range(max(args.warmup, 4 if args.graph else 0)):
+    for i in range(max(args.warmup, 4 if args.graph else 0)):
+        counted['on'] = i == 1                                # the second step: tables recorded, still eager
         losses.append(step(x, target)['loss'].item())
+    counted['on'] = False
+    _te._Ops.new = _new
     barrier()
     ar = 0.0
     t0 = time.perf_counter()
@@ -105,6 +122,18 @@ def main():
         dist.all_reduce(ones)
         dist.all_reduce(rates)
         ranks_seen, per_rank = int(round(float(ones.item()))), [round(float(v), 2) for v in rates.tolist()]
+    n_par = int(step.opt.flat_grad.numel())
+    step_bytes = 2 * counted['bytes'] + int(x.numel()) + 7 * 4 * n_par
+    ms = 1e3 * elapsed / args.steps
+    # forward 7.79 GFLOP / image at 640 px, C = 90 (tools/roofline_table.py); dX and dW GEMMs repeat it: ~3x per training step
+    flops = 3 * 7.79e9 * (args.image / 640.0) ** 2 * B if args.model == 'tf_efficientdet_d0' else None
+    roofline = {'bound': 'hbm', 'achieved': round(step_bytes / (ms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                'frac': round(step_bytes / (ms * 1e-3) / 1e9 / 8000.0, 4), 'traffic': None,
+                'kernel': 'whole step (every launch of the captured iteration)',
+                'algorithmic_bytes_per_step': int(step_bytes), 'activation_tensors_counted': counted['tensors'],
+                'bytes_rule': '2 x bytes of every tensor train_engine._Ops.new produced in one eager step + input + 7 x 4 B x parameters',
+                'hbm_floor_ms': round(step_bytes / 8e12 * 1e3, 3),
+                'fp32_mfma_floor_ms': None if flops is None else round(flops / 157.3e12 * 1e3, 3)}
     if rank == 0:
         print(json.dumps({
             'metric': 'pretrain steps/sec, %s %dpx float32 (forward + loss + backward + grad all-reduce + clip + Adam)' % (args.model, args.image),
@@ -117,6 +146,7 @@ def main():
                 'parallelism': 'dp%d, one flat-gradient all-reduce per step' % world,
                 'launch': 'hipgraph' if args.graph else 'eager'},
             'ranks': {'world_size': world, 'answered_all_reduce': ranks_seen, 'per_rank_images_per_sec': per_rank},
+            'roofline': roofline,
             'loss_first_last': [round(losses[0], 4), round(losses[-1], 4)],
             'peak_mem_GB': round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)}), flush=True)
     if dist is not None:
