@@ -234,6 +234,18 @@ int effdet_decode_threshold_gather(void* stream, int dtype, const void* cls_topk
 int effdet_nms_hard(void* stream, const float* boxes, const float* scores, const int* classes, const int* src,
                     const int* count, const float* maxcoord, int B, int k, double iou_threshold, int max_det,
                     const float* img_scale, float* det, int* det_count, int* keep_src);
+
+/* effdet_decode_threshold[_gather] followed by effdet_nms_hard in ONE launch (the hard-NMS path of generate_detections,
+ * effdet/anchors.py:132-166): n_anchors > 0 reads the box regressions from the head's [B, n_anchors, 4] output through `indices`
+ * (0: `box` is the gathered [B, k, 4] tensor); img_scale_clip / img_size as in effdet_decode_threshold (clipping, both or neither),
+ * img_scale_out as effdet_nms_hard's img_scale (output scaling).  The compacted intermediate arrays are still written. */
+int effdet_detections_hard(void* stream, int dtype, const void* cls_topk, const void* box, long long n_anchors,
+                           const float* anchors, const long long* indices, const long long* classes,
+                           const float* img_scale_clip, const float* img_size, int B, int k,
+                           float* boxes, float* scores, int* classes_out, int* src, int* count, float* maxcoord,
+                           double iou_threshold, int max_det, const float* img_scale_out,
+                           float* det, int* det_count, int* keep_src);
+
 int effdet_nms_soft(void* stream, const float* boxes, const float* scores, const int* classes, const int* src,
                     const int* count, const float* maxcoord, int B, int k, int method_gaussian, float sigma,
                     float iou_threshold, float score_threshold, int max_det,

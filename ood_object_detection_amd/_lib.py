@@ -79,6 +79,9 @@ SIGNATURES = {
                                         c_void_p, c_void_p]),
     'effdet_nms_hard': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                 c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'effdet_detections_hard': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int, c_void_p,
+                                       c_void_p, c_void_p, c_void_p]),
     'effdet_nms_soft': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                 c_int, c_float, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'effdet_nms_soft_large': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,

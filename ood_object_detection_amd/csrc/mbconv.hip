@@ -814,6 +814,11 @@ int launch_deep(hipStream_t st, const MbArgs& a, const DeepGeometry& g) {
 template <typename T>
 int launch_mb(hipStream_t st, MbArgs& a) {
     if constexpr (sizeof(T) == 2) {
+#ifdef MB_PREFER_WIDE    /* experiment (variant builds only) */
+        if (!a.in_gate && effdet_mbconv_wide_parts(a.H, a.W, a.Cin, a.mid, a.k, a.stride) > 0)
+            return effdet_mbconv_wide_launch(st, a.X, a.Y, a.W1, a.s1, a.t1, a.taps, a.s2, a.t2, a.pool_partial,
+                                             a.B, a.H, a.W, a.Cin, a.mid, a.k, a.stride, 0, a.sym);
+#endif
         // bf16: the rolling-window form (mbconv_roll.hip) wherever its geometry applies
         if (effdet_mbconv_roll_parts(a.H, a.W, a.Cin, a.mid, a.k, a.stride) > 0)
             return effdet_mbconv_roll_launch(st, a.X, a.in_gate, a.Y, a.W1, a.s1, a.t1, a.taps, a.s2, a.t2, a.pool_partial,
@@ -859,6 +864,9 @@ extern "C" int effdet_mbconv_tiles_per_image(int dtype, int H, int W, int Cin, i
         return parts > 0 ? parts : EFFDET_EINVAL;
     }
     if (dtype == 1) {
+#ifdef MB_PREFER_WIDE
+        { const int pw_ = effdet_mbconv_wide_parts(H, W, Cin, mid, k, stride); if (pw_ > 0) return pw_; }
+#endif
         int parts = effdet_mbconv_roll_parts(H, W, Cin, mid, k, stride);
         if (parts > 0) return parts;
         parts = effdet_mbconv_wide_parts(H, W, Cin, mid, k, stride);

@@ -48,6 +48,19 @@ DEV f32x4 silu4_fast(const f32x4 x) {
 }
 
 template <int V> struct IntC { static constexpr int value = V; };
+#ifndef ROLL_PFD2
+#define ROLL_PFD2 0
+#endif
+
+// Phase ablation for timing experiments: exists only in variant builds (`make variant TAG=.. UNIT=mbconv_roll VDEFS=-DROLL_ABLATE=n`,
+// libeffdet_hip_<TAG>.so, never loaded by the package); the product library is compiled with ROLL_ABLATE = 0.
+// 1: no depthwise arithmetic  2: no expand arithmetic  4: no Y stores  8: no X loads  16: SiLU -> identity
+#ifndef ROLL_ABLATE
+#define ROLL_ABLATE 0
+#endif
+DEV f32x4 roll_act(const f32x4 x) {
+    if constexpr ((ROLL_ABLATE & 16) != 0) return x; else return silu4_fast(x);
+}
 
 // NO = output tiles (16 px) per strip row: a compile-time count, so that every output row issues the same number of loads
 // and stores and the compiler can count them in its waits
@@ -195,8 +208,12 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
         const_cast<char*>(reinterpret_cast<const char*>(p.X)) + (long long)b * p.H * p.W * cbytes, 0, p.H * p.W * cbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char*>(p.Y) + (long long)b * p.Ho * p.Wo * mid * (int)sizeof(T), 0, p.Ho * p.Wo * mid * (int)sizeof(T), 0x00020000);
-    // One input row = MT x NKC operand fragments, loaded a whole output row ahead of their use
-    Frag<T> xq[S][MT][NKC];
+    // One input row = MT x NKC operand fragments, loaded PFD output rows ahead of their use.  PFD = 2 where the registers allow
+    // (bf16, stride 1, at most 4 fragments per row): round 4's ablation builds (profiles/r04_roll_ablation.txt) showed the wait for
+    // the X rows - L2 hits, but fetched by every channel-tile wave and queued behind the previous row's output stores in the
+    // in-order vmcnt - to be the largest single item of a row step (block 1.1: 0.288 ms, 0.176 without the X loads)
+    constexpr int PFD = ROLL_PFD2 && !PAIR && S == 1 && MT * NKC <= 4 ? 2 : 1;
+    Frag<T> xq[PFD * S][MT][NKC];
     auto load_row = [&](int rel, Frag<T> (&dst)[MT][NKC]) {
         int iy = iy_top + rel;
         iy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);             // rows outside the image: any valid row (zeroed by the row mask)
@@ -206,7 +223,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
 #pragma unroll
             for (int kc = 0; kc < NKC; ++kc) {
                 const int xo = kc + 1 < NKC ? xoff[t] + kc * CHB : xoffl[t];
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, xo, rowoff, 0);
+                const u32x4 v = (ROLL_ABLATE & 8) ? u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u} : __builtin_amdgcn_raw_buffer_load_b128(xrs, xo, rowoff, 0);
                 if constexpr (PAIR) {
                     // (an out-of-range offset + 16 stays out of range: OOB is far beyond num_records)
                     const u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(xrs, xo + 16, rowoff, 0);
@@ -224,8 +241,8 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
         for (int t = 0; t < MT; ++t) {
             f32x4 acc = sh1;
 #pragma unroll
-            for (int kc = 0; kc < NKC; ++kc) mma_chunk(wf[kc], src[t][kc], acc);
-            const f32x4 v = silu4_fast(acc) * (cmask[t] * rmask);
+            for (int kc = 0; kc < ((ROLL_ABLATE & 2) ? 0 : NKC); ++kc) mma_chunk(wf[kc], src[t][kc], acc);
+            const f32x4 v = roll_act(acc) * (cmask[t] * rmask);
             if constexpr (PAIR) *reinterpret_cast<f32x4*>(ring_e + slot_bytes + 16 * PXB * t + kg * 16) = v;      // float32 ring
             else row_store4<T>(ring_e + slot_bytes + 16 * PXB * t, 4 * kg, v);
         }
@@ -233,6 +250,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
 
     // 4 channels of one output pixel -> Y (range-checked: an out-of-range offset drops the store; OOB + 16 is out of range too)
     auto store_out = [&](const f32x4 ov, int yo, int yrow_) {
+        if constexpr ((ROLL_ABLATE & 4) != 0) { if (ov[0] == 12345.678f) __builtin_amdgcn_raw_buffer_store_b32(1u, yrs, yo, yrow_, 0); return; }
         if constexpr (PAIR) {
             u32x2 oh, ol;
             pair_split4(ov, oh, ol);
@@ -252,19 +270,22 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
         expand_row(next_rel, next_rel * rowbytes, xq[0]);
     }
 #pragma unroll
-    for (int r = 0; r < S; ++r) load_row(next_rel + r, xq[r]);
+    for (int d = 0; d < PFD; ++d)
+#pragma unroll
+        for (int r = 0; r < S; ++r) load_row(next_rel + d * S + r, xq[d * S + r]);
     int yrow = oy_b * p.Wo * mid * (int)sizeof(T);            // byte offset of the output row inside the image (scalar offset)
     const int ypitch = p.Wo * mid * (int)sizeof(T);
     int oy = oy_b;
     // One output row.  PH = ring slot of the first row of its KS-row window.
-    auto step = [&](auto PHC) {
+    auto step = [&](auto PHC, auto SLC) {
         constexpr int PH = decltype(PHC)::value;
-        // ---- expand the S new input rows of this output row (fetched one iteration ago), then fetch the next S
+        constexpr int SL = decltype(SLC)::value % PFD;          // register slot of this step's rows (fetched PFD iterations ago)
+        // ---- expand the S new input rows of this output row, then fetch the rows of the step PFD ahead into the slot just used
 #pragma unroll
-        for (int r = 0; r < S; ++r) expand_row(next_rel + r, ((PH + KS - S + r) % KS) * rowbytes, xq[r]);
+        for (int r = 0; r < S; ++r) expand_row(next_rel + r, ((PH + KS - S + r) % KS) * rowbytes, xq[SL * S + r]);
         next_rel += S;
 #pragma unroll
-        for (int r = 0; r < S; ++r) load_row(next_rel + r, xq[r]);      // past the band's end: clamped rows, never used
+        for (int r = 0; r < S; ++r) load_row(next_rel + (PFD - 1) * S + r, xq[SL * S + r]);      // past the band's end: clamped rows, never used
         __builtin_amdgcn_sched_barrier(0);
         // ---- depthwise: one output row out of the ring
         constexpr int OT = OTN < 2 ? OTN : 2;                   // output tiles in flight together
@@ -294,7 +315,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
             }
 #pragma unroll
             for (int u = 0; u < OTN; ++u) {
-                const f32x4 ov = silu4_fast(acc[u]);
+                const f32x4 ov = roll_act(acc[u]);
                 const int yo = yoff[u];
                 const float vm = yo == OOB ? 0.f : 1.f;
 #pragma unroll
@@ -333,14 +354,14 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
                     if (pr < NPAIR) {
                         const Frag<T> af = diag(pr);
 #pragma unroll
-                        for (int u = 0; u < OTN; ++u) mma_chunk(af, bq[g][u], acc[u]);
+                        for (int u = 0; u < ((ROLL_ABLATE & 1) ? 0 : OTN); ++u) mma_chunk(af, bq[g][u], acc[u]);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);              // batches stay batches: hoisting every read of the row would spill
             }
 #pragma unroll
             for (int u = 0; u < OTN; ++u) {
-                const f32x4 ov = silu4_fast(acc[u]);
+                const f32x4 ov = roll_act(acc[u]);
                 const int yo = yoff[u];
                 const float vm = yo == OOB ? 0.f : 1.f;
 #pragma unroll
@@ -362,7 +383,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
                     const int off = hsel ? offb : offa;
 #pragma unroll
                     for (int u = 0; u < OT; ++u) {
-                        if (u0 + u < OTN) mma_chunk(af, ld_frag<T>(dl[u0 + u < OTN ? u0 + u : 0] + off), acc[u]);
+                        if (u0 + u < OTN && !(ROLL_ABLATE & 1)) mma_chunk(af, ld_frag<T>(dl[u0 + u < OTN ? u0 + u : 0] + off), acc[u]);
                     }
                     // keep the scheduler from hoisting all 2 x 13 ring reads (4 registers each) to the top of the row
                     if constexpr (KS == 5) { if (pr % 4 == 3) __builtin_amdgcn_sched_barrier(0); }
@@ -370,7 +391,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
 #pragma unroll
                 for (int u = 0; u < OT; ++u) {
                     if (u0 + u < OTN) {
-                        const f32x4 ov = silu4_fast(acc[u]);
+                        const f32x4 ov = roll_act(acc[u]);
                         const int yo = yoff[u0 + u < OTN ? u0 + u : 0];
                         const float vm = yo == OOB ? 0.f : 1.f;
 #pragma unroll
@@ -386,16 +407,29 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
     };
 #pragma unroll 1
     while (oy < oy_e) {
+        // KS ring phases x PFD register slots, unrolled so that both are compile-time constants in every step
         if constexpr (KS == 3) {
-            step(IntC<0>{});
-            if (oy < oy_e) step(IntC<(S) % 3>{});
-            if (oy < oy_e) step(IntC<(2 * S) % 3>{});
+            step(IntC<0>{}, IntC<0>{});
+            if (oy < oy_e) step(IntC<(S) % 3>{}, IntC<1>{});
+            if (oy < oy_e) step(IntC<(2 * S) % 3>{}, IntC<2>{});
+            if constexpr (PFD == 2) {
+                if (oy < oy_e) step(IntC<0>{}, IntC<3>{});
+                if (oy < oy_e) step(IntC<(S) % 3>{}, IntC<4>{});
+                if (oy < oy_e) step(IntC<(2 * S) % 3>{}, IntC<5>{});
+            }
         } else {
-            step(IntC<0>{});
-            if (oy < oy_e) step(IntC<(S) % 5>{});
-            if (oy < oy_e) step(IntC<(2 * S) % 5>{});
-            if (oy < oy_e) step(IntC<(3 * S) % 5>{});
-            if (oy < oy_e) step(IntC<(4 * S) % 5>{});
+            step(IntC<0>{}, IntC<0>{});
+            if (oy < oy_e) step(IntC<(S) % 5>{}, IntC<1>{});
+            if (oy < oy_e) step(IntC<(2 * S) % 5>{}, IntC<2>{});
+            if (oy < oy_e) step(IntC<(3 * S) % 5>{}, IntC<3>{});
+            if (oy < oy_e) step(IntC<(4 * S) % 5>{}, IntC<4>{});
+            if constexpr (PFD == 2) {
+                if (oy < oy_e) step(IntC<0>{}, IntC<5>{});
+                if (oy < oy_e) step(IntC<(S) % 5>{}, IntC<6>{});
+                if (oy < oy_e) step(IntC<(2 * S) % 5>{}, IntC<7>{});
+                if (oy < oy_e) step(IntC<(3 * S) % 5>{}, IntC<8>{});
+                if (oy < oy_e) step(IntC<(4 * S) % 5>{}, IntC<9>{});
+            }
         }
     }
     if (p.pool_partial != nullptr) {

@@ -458,7 +458,11 @@ WideGeometry pick_wide(int H, int W, int Cin, int mid, int k, int stride, bool p
     const int esz = pair ? 4 : 2, pxb = 16 * esz;                  // bytes per channel / per 16-channel ring pixel
     const int cbytes = Cin * esz;
     g.nkc = (Cin + 31) / 32;                                    // K-chunks of 32 channels (64 bytes; two-term bf16: 128 bytes)
+#ifdef WIDE_NARROW       /* experiment (variant builds only): the shared-X form for inputs of 8 ... 64 channels too */
+    if (g.nkc > 6 || mid % 16 || Cin % 8) return g;
+#else
     if ((g.nkc < 3 || g.nkc > 6) || mid % 16 || Cin % 8) return g;        // narrower inputs: mbconv_roll.hip; wider: the band x slice form
+#endif
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
     // one strip per row where the row fits 64 input pixels, else equal strips
     int best_ns = 0;
@@ -595,6 +599,10 @@ int launch_wide_ks(hipStream_t st, const WideArgs& r, const WideGeometry& g) {
         }
     } else
     switch (g.nkc) {
+#ifdef WIDE_NARROW
+        case 1: kern = wide_kernel_for<KS, S, 1, T>(mt, no, g.npl); break;
+        case 2: kern = wide_kernel_for<KS, S, 2, T>(mt, no, g.npl); break;
+#endif
         case 3: kern = wide_kernel_for<KS, S, 3, T>(mt, no, g.npl); break;
         case 4: kern = wide_kernel_for<KS, S, 4, T>(mt, no, g.npl); break;
         case 5: kern = wide_kernel_for<KS, S, 5, T>(mt, no, g.npl); break;

@@ -543,7 +543,7 @@ DEV float ld_as_float(const void* p, int dtype, long long i) {
     return dtype == 0 ? reinterpret_cast<const float*>(p)[i] : (float)reinterpret_cast<const bf16_t*>(p)[i];
 }
 
-__global__ __launch_bounds__(256) void decode_threshold_kernel(DecodeArgs p) {
+DEV void decode_threshold_body(const DecodeArgs& p) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ int wcount[4];
     __shared__ float wmax[4];
@@ -604,6 +604,8 @@ __global__ __launch_bounds__(256) void decode_threshold_kernel(DecodeArgs p) {
     }
 }
 
+__global__ __launch_bounds__(256) void decode_threshold_kernel(DecodeArgs p) { decode_threshold_body(p); }
+
 // ------------------------------------------------------------------------------------------------
 struct NmsArgs {
     const float* boxes; const float* scores; const int* classes; const int* src; const int* count;
@@ -638,7 +640,7 @@ DEV bool nms_suppresses(float ix1, float iy1, float ix2, float iy2, float iarea,
 
 constexpr int NMS_MAX_DET = 512;
 
-__global__ __launch_bounds__(256) void nms_hard_kernel(NmsArgs p) {
+DEV void nms_hard_body(const NmsArgs& p) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ float kx1[NMS_MAX_DET], ky1[NMS_MAX_DET], kx2[NMS_MAX_DET], ky2[NMS_MAX_DET], kar[NMS_MAX_DET];
     __shared__ float cx1[256], cy1[256], cx2[256], cy2[256], car[256];
@@ -691,6 +693,17 @@ __global__ __launch_bounds__(256) void nms_hard_kernel(NmsArgs p) {
     }
     __syncthreads();
     if (tid == 0) p.det_count[b] = nkept_s;
+}
+
+__global__ __launch_bounds__(256) void nms_hard_kernel(NmsArgs p) { nms_hard_body(p); }
+
+// generate_detections' hard-NMS path in ONE launch (round 4): the image's workgroup decodes + thresholds its k candidates into
+// the compacted arrays and goes straight on to the greedy NMS over them (same 256 threads, same arithmetic, same arrays)
+__global__ __launch_bounds__(256) void detections_hard_kernel(DecodeArgs d, NmsArgs n) {
+    decode_threshold_body(d);
+    __threadfence();                      // the compacted candidates / count / maxcoord of THIS image are visible to its own workgroup
+    __syncthreads();
+    nms_hard_body(n);
 }
 
 // Soft-NMS: every thread keeps its candidates (index i = tid + 1024*q) in registers.
@@ -1105,6 +1118,25 @@ extern "C" int effdet_decode_threshold_gather(void* stream, int dtype, const voi
     if (B <= 0 || k <= 0 || n_anchors <= 0 || (dtype & ~3)) return EFFDET_EINVAL;
     DecodeArgs a{cls_topk, box_all, dtype & 1, (dtype & 2) ? 0 : (dtype & 1), anchors, indices, classes, img_scale, img_size, k, boxes, scores, classes_out, src, count, maxcoord, n_anchors};
     hipLaunchKernelGGL(decode_threshold_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return effdet_check_launch();
+}
+
+// decode + threshold (effdet/anchors.py:132-146) and hard NMS + top max_det (:147-166) of every image in one launch; arguments as
+// effdet_decode_threshold[_gather] (n_anchors > 0: box rows through `indices`) followed by effdet_nms_hard's
+extern "C" int effdet_detections_hard(void* stream, int dtype, const void* cls_topk, const void* box, long long n_anchors,
+                                      const float* anchors, const long long* indices, const long long* classes,
+                                      const float* img_scale_clip, const float* img_size, int B, int k,
+                                      float* boxes, float* scores, int* classes_out, int* src, int* count, float* maxcoord,
+                                      double iou_threshold, int max_det, const float* img_scale_out,
+                                      float* det, int* det_count, int* keep_src) {
+    EFFDET_ENTER();
+    if (!cls_topk || !box || !anchors || !indices || !classes || !boxes || !scores || !classes_out || !src || !count || !maxcoord ||
+        !det || !det_count || !keep_src) return EFFDET_EINVAL;
+    if (B <= 0 || k <= 0 || n_anchors < 0 || (dtype & ~3) || max_det <= 0 || max_det > NMS_MAX_DET) return EFFDET_EINVAL;
+    DecodeArgs d{cls_topk, box, dtype & 1, (dtype & 2) ? 0 : (dtype & 1), anchors, indices, classes, img_scale_clip, img_size, k, boxes, scores,
+                 classes_out, src, count, maxcoord, n_anchors};
+    NmsArgs n{boxes, scores, classes_out, src, count, maxcoord, k, iou_threshold, max_det, img_scale_out, det, det_count, keep_src, 1, 0.5f, 0.3f, 0.001f};
+    hipLaunchKernelGGL(detections_hard_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d, n);
     return effdet_check_launch();
 }
 

@@ -129,22 +129,23 @@ def batched_detections(cls_topk, box_topk, anchor_boxes, indices, classes, img_s
     tail = (anchors.data_ptr(), indices.data_ptr(), classes.data_ptr(),
             sc.data_ptr() if (sc is not None and sz is not None) else None, sz.data_ptr() if sz is not None else None, B, k,
             boxes.data_ptr(), scores.data_ptr(), cls_i.data_ptr(), src.data_ptr(), count.data_ptr(), maxc.data_ptr())
+    if box_all is not None and (bsrc.dim() != 3 or bsrc.shape[0] != B or bsrc.shape[2] != 4):
+        raise ValueError('box_all must be [B, N, 4]')
+    n_gather = bsrc.shape[1] if box_all is not None else 0
+    scp = sc.data_ptr() if sc is not None else None
+    if not soft_nms:
+        # hard NMS: decode + threshold + NMS of every image in one launch
+        _lib.check(lib.effdet_detections_hard(st, dt, cls_topk.data_ptr(), bsrc.data_ptr(), n_gather, *tail, 0.3, max_det_per_image,
+                                              scp, det.data_ptr(), det_count.data_ptr(), keep_src.data_ptr()), 'effdet_detections_hard')
+        return det, det_count, keep_src
     if box_all is not None:
-        if bsrc.dim() != 3 or bsrc.shape[0] != B or bsrc.shape[2] != 4:
-            raise ValueError('box_all must be [B, N, 4]')
-        _lib.check(lib.effdet_decode_threshold_gather(st, dt, cls_topk.data_ptr(), bsrc.data_ptr(), bsrc.shape[1], *tail),
+        _lib.check(lib.effdet_decode_threshold_gather(st, dt, cls_topk.data_ptr(), bsrc.data_ptr(), n_gather, *tail),
                    'effdet_decode_threshold_gather')
     else:
         _lib.check(lib.effdet_decode_threshold(st, dt, cls_topk.data_ptr(), bsrc.data_ptr(), *tail), 'effdet_decode_threshold')
-    scp = sc.data_ptr() if sc is not None else None
-    if soft_nms:
-        _lib.check(lib.effdet_nms_soft(st, boxes.data_ptr(), scores.data_ptr(), cls_i.data_ptr(), src.data_ptr(),
-                                       count.data_ptr(), maxc.data_ptr(), B, k, 1, 0.5, 0.3, 0.001, max_det_per_image,
-                                       scp, det.data_ptr(), det_count.data_ptr(), keep_src.data_ptr()), 'effdet_nms_soft')
-    else:
-        _lib.check(lib.effdet_nms_hard(st, boxes.data_ptr(), scores.data_ptr(), cls_i.data_ptr(), src.data_ptr(),
-                                       count.data_ptr(), maxc.data_ptr(), B, k, 0.3, max_det_per_image,
-                                       scp, det.data_ptr(), det_count.data_ptr(), keep_src.data_ptr()), 'effdet_nms_hard')
+    _lib.check(lib.effdet_nms_soft(st, boxes.data_ptr(), scores.data_ptr(), cls_i.data_ptr(), src.data_ptr(),
+                                   count.data_ptr(), maxc.data_ptr(), B, k, 1, 0.5, 0.3, 0.001, max_det_per_image,
+                                   scp, det.data_ptr(), det_count.data_ptr(), keep_src.data_ptr()), 'effdet_nms_soft')
     return det, det_count, keep_src
 
 

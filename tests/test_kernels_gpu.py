@@ -506,6 +506,54 @@ def test_generate_detections_golden(golden, soft):
             assert np.abs(det[:, 4] - ref[:, 4]).max() <= 1e-6
 
 
+@pytest.mark.parametrize('gather', [False, True])
+def test_detections_hard_one_launch_equals_decode_then_nms(gather):
+    """effdet_detections_hard (decode + threshold + hard NMS in one launch, what batched_detections runs) is bit-identical to
+    effdet_decode_threshold[_gather] followed by effdet_nms_hard, intermediate arrays included"""
+    import _hip
+    from ood_object_detection_amd import _lib
+    lib = _lib.load()
+    B, k, N = 3, 700, 4000
+    g = torch.Generator().manual_seed(9)
+    anchors = torch.rand(N, 4, generator=g) * 200
+    anchors[:, 2:] += anchors[:, :2] + 8
+    idx = torch.stack([torch.randperm(N, generator=g)[:k] for _ in range(B)]).to(torch.int64)
+    cls_id = torch.randint(0, 7, (B, k), generator=g)
+    logit = torch.randn(B, k, generator=g) * 2 - 1
+    box_all = torch.randn(B, N, 4, generator=g) * 0.3
+    box_topk = torch.gather(box_all, 1, idx[:, :, None].expand(B, k, 4)).contiguous()
+    scale, size = torch.tensor([1.0, 1.5, 0.8]), torch.tensor([[300., 280.], [256., 256.], [320., 200.]])
+    dev = lambda t: t.contiguous().to(DEV)
+    a_d, i_d, c_d, l_d, sc_d, sz_d = dev(anchors), dev(idx), dev(cls_id), dev(logit), dev(scale), dev(size)
+    bsrc = dev(box_all) if gather else dev(box_topk)
+
+    def bufs():
+        f = dict(device=DEV, dtype=torch.float32); i = dict(device=DEV, dtype=torch.int32)
+        return [torch.zeros(B, k, 4, **f), torch.zeros(B, k, **f), torch.zeros(B, k, **i), torch.zeros(B, k, **i), torch.zeros(B, **i), torch.zeros(B, **f),
+                torch.zeros(B, 100, 6, **f), torch.zeros(B, **i), torch.zeros(B, 100, **i)]
+    st = _hip.stream(DEV)
+    one, two = bufs(), bufs()
+    tail = lambda t: (a_d.data_ptr(), i_d.data_ptr(), c_d.data_ptr(), sc_d.data_ptr(), sz_d.data_ptr(), B, k) + tuple(x.data_ptr() for x in t[:6])
+    assert lib.effdet_detections_hard(st, 0, l_d.data_ptr(), bsrc.data_ptr(), N if gather else 0, *tail(one), 0.3, 100, sc_d.data_ptr(),
+                                      one[6].data_ptr(), one[7].data_ptr(), one[8].data_ptr()) == 0
+    if gather:
+        assert lib.effdet_decode_threshold_gather(st, 0, l_d.data_ptr(), bsrc.data_ptr(), N, *tail(two)) == 0
+    else:
+        assert lib.effdet_decode_threshold(st, 0, l_d.data_ptr(), bsrc.data_ptr(), *tail(two)) == 0
+    assert lib.effdet_nms_hard(st, *[x.data_ptr() for x in two[:6]], B, k, 0.3, 100, sc_d.data_ptr(), two[6].data_ptr(), two[7].data_ptr(),
+                               two[8].data_ptr()) == 0
+    torch.cuda.synchronize()
+    assert int(one[7].min()) > 0
+    cnt = one[4].cpu()
+    assert torch.equal(cnt, two[4].cpu())
+    for b in range(B):                                   # the compacted candidates (only the first count[b] rows are defined)
+        n = int(cnt[b])
+        for x, y in zip(one[:4], two[:4]):
+            assert torch.equal(x[b, :n].cpu(), y[b, :n].cpu())
+    for x, y in zip(one[5:], two[5:]):
+        assert torch.equal(x.cpu(), y.cpu())
+
+
 @pytest.mark.parametrize('tag', ['a', 'b', 'c'])
 def test_soft_nms_golden(golden, tag):
     from ood_object_detection_amd.effdet.soft_nms import soft_nms, batched_soft_nms
