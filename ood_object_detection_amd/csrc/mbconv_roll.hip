@@ -47,6 +47,18 @@ DEV f32x4 silu4_fast(const f32x4 x) {
     return f32x4{y0[0], y0[1], y1[0], y1[1]};
 }
 
+// The expand SiLU of the bf16 kernel on t = -log2(e) x (the scale sits in W1 and BN1's shift; its inverse, -ln 2, in the depthwise
+// taps): t * rcp(2^t + addc) = -log2(e) * silu(x) for addc = 1, and 0 for addc = +inf (pixels outside the image) - one packed
+// multiply and the separate mask multiplies less than silu(x) * mask (5 instead of 8.5 vector instructions per value pair)
+DEV f32x4 silu4_scaled(const f32x4 t, const float addc) {
+    const f32x2_ t0 = {t[0], t[1]}, t1 = {t[2], t[3]};
+    const f32x2_ d0 = f32x2_{__builtin_amdgcn_exp2f(t0[0]), __builtin_amdgcn_exp2f(t0[1])} + addc;
+    const f32x2_ d1 = f32x2_{__builtin_amdgcn_exp2f(t1[0]), __builtin_amdgcn_exp2f(t1[1])} + addc;
+    const f32x2_ y0 = t0 * f32x2_{__builtin_amdgcn_rcpf(d0[0]), __builtin_amdgcn_rcpf(d0[1])};
+    const f32x2_ y1 = t1 * f32x2_{__builtin_amdgcn_rcpf(d1[0]), __builtin_amdgcn_rcpf(d1[1])};
+    return f32x4{y0[0], y0[1], y1[0], y1[1]};
+}
+
 template <int V> struct IntC { static constexpr int value = V; };
 #ifndef ROLL_PFD2
 #define ROLL_PFD2 0
@@ -60,6 +72,14 @@ template <int V> struct IntC { static constexpr int value = V; };
 #endif
 DEV f32x4 roll_act(const f32x4 x) {
     if constexpr ((ROLL_ABLATE & 16) != 0) return x; else return silu4_fast(x);
+}
+
+// Pixels a lane beyond the strip's last output may read past the end of a ring row (its window starts at pixel (16 NO - 1) S at
+// most; + 1: the hi lanes of the single last tap read the pixel after the window, against zero weights - which still must not
+// meet a NaN): behind the LAST slot that is past the wave's ring, so every wave's ring carries this many zeroed pad pixels
+constexpr int roll_pad_px(int ks, int s, int mt, int no) {
+    const int over = (16 * no - 1) * s + ks + 1 - 16 * mt;
+    return over > 0 ? over : 0;
 }
 
 // NO = output tiles (16 px) per strip row: a compile-time count, so that every output row issues the same number of loads
@@ -116,7 +136,9 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
         const int t = 2 * pr + hi;
         tapv[pr] = p.taps[(long long)(t < NTAP ? t : 0) * mid + c0 + frow];
     }
-    const f32x4 sh1 = *reinterpret_cast<const f32x4*>(p.t1 + c0 + 4 * kg);
+    // bf16: the expand GEMM produces t = -log2(e) x directly (silu4_scaled), the taps carry -ln 2
+    constexpr float ESC = PAIR ? 1.f : -1.4426950408889634f, EINV = PAIR ? 1.f : -0.6931471805599453f;
+    const f32x4 sh1 = *reinterpret_cast<const f32x4*>(p.t1 + c0 + 4 * kg) * ESC;
     const f32x4 t2v = *reinterpret_cast<const f32x4*>(p.t2 + c0 + 4 * kg);
     // two-term mode: the lane's 4 channels of every tap, BN2's scale folded in (float32 vector-ALU depthwise)
     f32x4 wv[PAIR ? NTAP : 1];
@@ -139,7 +161,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
                 wf[kc].h[e] = kv ? wh : (bf16_t)0.f;
                 wf[kc].l[e] = kv ? (bf16_t)(w - (float)wh) : (bf16_t)0.f;
             } else {
-                wf[kc].v[e] = kv ? (bf16_t)((float)wf[kc].v[e] * (rs1 * ge)) : (bf16_t)0.f;
+                wf[kc].v[e] = kv ? (bf16_t)((float)wf[kc].v[e] * (rs1 * ge * ESC)) : (bf16_t)0.f;
             }
         }
     }
@@ -148,7 +170,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
 #pragma unroll
     for (int pr = 0; pr < NPAIR; ++pr) {
         const bool on = dactive && 2 * pr + hi < NTAP;
-        const float tw_ = tapv[pr] * rs2;
+        const float tw_ = tapv[pr] * (rs2 * EINV);
         const bf16_t th_ = (bf16_t)tw_;
         abits[pr] = on ? (unsigned)__builtin_bit_cast(unsigned short, th_) << (16 * (frow & 1)) : 0u;
         if constexpr (PAIR) abitl[pr] = on ? (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)(tw_ - (float)th_)) << (16 * (frow & 1)) : 0u;
@@ -186,20 +208,34 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
     for (int t = 0; t < MT; ++t) {
         const int c = 16 * t + frow, ix = ix0 + c;
         const bool inside = c < p.IWs && ix >= 0 && ix < p.W;
-        cmask[t] = inside ? 1.f : 0.f;
+        cmask[t] = PAIR ? (inside ? 1.f : 0.f) : (inside ? 1.f : __builtin_inff());     // bf16: silu4_scaled's addend
         xoff[t] = inside ? ix * cbytes + kg * PB : OOB;
         xoffl[t] = (inside && (NKC - 1) * CHB + kg * PB < cbytes) ? ix * cbytes + (NKC - 1) * CHB + kg * PB : OOB;
     }
-    const char* dl[OTN];
-    const char* dlh[KS == 5 ? OTN : 1];                          // 5 x 5: base of a tap pair inside one window row (second tap = next pixel)
+    // Depthwise ring reads: ONE lane base per kind of tap pair, every tile / tap / ring-phase offset an instruction immediate (no
+    // address arithmetic in the row loop; round 4 - it was 1 + NO vector adds per pair).  A K = 32 operand holds two taps x 16
+    // channels; lanes of the upper half (hi) read the pair's second tap.  Both taps in one window row: second tap = next pixel
+    // (`dsame`).  A pair that straddles two window rows reads (row r, last column) | (row r + 1, column 0): the byte distance is
+    // rowbytes - (KS-1) PXB while the two ring slots are consecutive (`dnw`, on the hi lanes) and (KS-1)(rowbytes + PXB) the other
+    // way round when the window wraps in the ring (`dwr`, on the lo lanes; the immediate is then the second tap's offset).
+    // Lanes beyond the strip's last output pixel are NOT redirected any more: they read finite ring contents (at most ROLL_PAD_PX
+    // pixels past the last slot: the wave's zeroed pad) and their results are dropped (store out of range, pool mask 0).
+    const char* const dl0 = ring + frow * S * PXB + (PAIR ? kg * 16 : (kg & 1) * (PXB / 2));
+    const char* const dsame = dl0 + hi * PXB;
+    const char* const dnw = dl0 + hi * (rowbytes - (KS - 1) * PXB);
+    const char* const dwr = dl0 + (1 - hi) * (KS - 1) * (rowbytes + PXB);
+    constexpr int TILEB = 16 * S * PXB;                          // ring bytes between the windows of two output tiles
+    {   // the pad behind the last ring slot: read (never used) by lanes beyond the strip - must be finite
+        constexpr int PADB = roll_pad_px(KS, S, MT, NO) * PXB;
+#pragma unroll
+        for (int o = 0; o < PADB; o += 64 * 16)
+            if (o + lane * 16 < PADB) *reinterpret_cast<u32x4*>(ring + KS * rowbytes + o + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
     int yoff[OTN];
 #pragma unroll
     for (int u = 0; u < OTN; ++u) {
         const int oxl = 16 * u + frow;
         const bool ok = oxl < tw;
-        // invalid lanes read pixel 0 (finite), dropped at the store.  (two-term: the lane's 4 float32 channels of the pixel)
-        dl[u] = ring + (ok ? oxl * S * PXB : 0) + (PAIR ? kg * 16 : (kg & 1) * (PXB / 2));
-        if constexpr (KS == 5) dlh[u] = dl[u] + hi * PXB;
         // two-term: byte offset of the hi half of the lane's 4 channels inside their 8-channel group (lo: + 16)
         yoff[u] = ok ? (PAIR ? (ox0 + oxl) * mid * 4 + ((c0 + 4 * kg) >> 3) * 32 + ((c0 + 4 * kg) & 7) * 2 : ((ox0 + oxl) * mid + c0 + 4 * kg) * 2) : OOB;
     }
@@ -236,15 +272,28 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
     };
     auto expand_row = [&](int rel, int slot_bytes, const Frag<T> (&src)[MT][NKC]) {
         const int iy = iy_top + rel;
-        const float rmask = (iy >= 0 && iy < p.H) ? 1.f : 0.f;           // rows outside the image: zeros (TF-SAME pads the expanded map)
+        const bool rowin = iy >= 0 && iy < p.H;                           // wave-uniform
+        if constexpr (PAIR) {
+            const float rmask = rowin ? 1.f : 0.f;                        // rows outside the image: zeros (the padding applies to the expanded map)
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            f32x4 acc = sh1;
+            for (int t = 0; t < MT; ++t) {
+                f32x4 acc = sh1;
 #pragma unroll
-            for (int kc = 0; kc < ((ROLL_ABLATE & 2) ? 0 : NKC); ++kc) mma_chunk(wf[kc], src[t][kc], acc);
-            const f32x4 v = roll_act(acc) * (cmask[t] * rmask);
-            if constexpr (PAIR) *reinterpret_cast<f32x4*>(ring_e + slot_bytes + 16 * PXB * t + kg * 16) = v;      // float32 ring
-            else row_store4<T>(ring_e + slot_bytes + 16 * PXB * t, 4 * kg, v);
+                for (int kc = 0; kc < NKC; ++kc) mma_chunk(wf[kc], src[t][kc], acc);
+                *reinterpret_cast<f32x4*>(ring_e + slot_bytes + 16 * PXB * t + kg * 16) = roll_act(acc) * (cmask[t] * rmask);      // float32 ring
+            }
+        } else if (rowin) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                f32x4 acc = sh1;
+#pragma unroll
+                for (int kc = 0; kc < ((ROLL_ABLATE & 2) ? 0 : NKC); ++kc) mma_chunk(wf[kc], src[t][kc], acc);
+                const f32x4 v = (ROLL_ABLATE & 16) ? (cmask[t] == 1.f ? acc : f32x4{0.f, 0.f, 0.f, 0.f}) : silu4_scaled(acc, cmask[t]);
+                row_store4<T>(ring_e + slot_bytes + 16 * PXB * t, 4 * kg, v);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) row_store4<T>(ring_e + slot_bytes + 16 * PXB * t, 4 * kg, f32x4{0.f, 0.f, 0.f, 0.f});
         }
     };
 
@@ -289,10 +338,12 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
         __builtin_amdgcn_sched_barrier(0);
         // ---- depthwise: one output row out of the ring
         constexpr int OT = OTN < 2 ? OTN : 2;                   // output tiles in flight together
-        // the per-pair read offsets are loop invariant per ring phase: left alone, the compiler hoists all KS x NPAIR x NO of
-        // them out of the row loop and spills; an opaque copy of the lane's tap selector keeps them (1 + NO adds per pair) here
-        int hsel = hi;
-        asm volatile("" : "+v"(hsel));
+        // lane base + immediate of a tap pair's ring read (ta, tb, offa, offb: constants after unrolling; a single last tap has
+        // tb = ta: its hi lanes carry zero weights and read the next pixel)
+        auto pair_addr = [&](int ta, int tb, int offa, int offb) -> const char* {
+            if (ta / KS == tb / KS) return dsame + offa;
+            return offb > offa ? dnw + offa : dwr + offb;
+        };
         if constexpr (PAIR) {
             // float32 depthwise on the vector ALU: per tap one 16-byte ring read (4 channels of the lane's pixel) and two packed FMAs
             // per output tile; ring offsets are immediates (PH is a template constant), one window row of taps per batch
@@ -306,7 +357,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
                 for (int dx = 0; dx < KS; ++dx)
 #pragma unroll
                     for (int u = 0; u < OTN; ++u)
-                        e[dx][u] = *reinterpret_cast<const f32x4*>(dl[u] + ((PH + dy) % KS) * rowbytes + dx * PXB);
+                        e[dx][u] = *reinterpret_cast<const f32x4*>(dl0 + u * TILEB + ((PH + dy) % KS) * rowbytes + dx * PXB);
 #pragma unroll
                 for (int dx = 0; dx < KS; ++dx)
 #pragma unroll
@@ -342,10 +393,8 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
                         const int ta = 2 * pr, tb = 2 * pr + 1 < NTAP ? 2 * pr + 1 : 2 * pr;        // constants after unrolling
                         const int offa = ((PH + ta / KS) % KS) * rowbytes + (ta % KS) * PXB;
                         const int offb = ((PH + tb / KS) % KS) * rowbytes + (tb % KS) * PXB;
-                        const bool same_row = ta / KS == tb / KS;
 #pragma unroll
-                        for (int u = 0; u < OTN; ++u)
-                            bq[g][u] = ld_frag<T>(same_row ? dlh[u] + offa : dl[u] + offa + hsel * (offb - offa));
+                        for (int u = 0; u < OTN; ++u) bq[g][u] = ld_frag<T>(pair_addr(ta, tb, offa, offb) + u * TILEB);
                     }
                 }
 #pragma unroll
@@ -378,12 +427,12 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
 #pragma unroll
                 for (int pr = 0; pr < NPAIR; ++pr) {
                     const Frag<T> af = diag(pr);
-                    const int ta = 2 * pr, tb = 2 * pr + 1 < NTAP ? 2 * pr + 1 : 0;        // constants after unrolling
+                    const int ta = 2 * pr, tb = 2 * pr + 1 < NTAP ? 2 * pr + 1 : 2 * pr;        // constants after unrolling
                     const int offa = ((PH + ta / KS) % KS) * rowbytes + (ta % KS) * PXB, offb = ((PH + tb / KS) % KS) * rowbytes + (tb % KS) * PXB;
-                    const int off = hsel ? offb : offa;
+                    const char* const src = pair_addr(ta, tb, offa, offb);
 #pragma unroll
                     for (int u = 0; u < OT; ++u) {
-                        if (u0 + u < OTN && !(ROLL_ABLATE & 1)) mma_chunk(af, ld_frag<T>(dl[u0 + u < OTN ? u0 + u : 0] + off), acc[u]);
+                        if (u0 + u < OTN && !(ROLL_ABLATE & 1)) mma_chunk(af, ld_frag<T>(src + (u0 + u) * TILEB), acc[u]);
                     }
                     // keep the scheduler from hoisting all 2 x 13 ring reads (4 registers each) to the top of the row
                     if constexpr (KS == 5) { if (pr % 4 == 3) __builtin_amdgcn_sched_barrier(0); }
@@ -484,7 +533,7 @@ RollGeometry pick_roll(int H, int W, int Cin, int mid, int k, int stride, bool p
         if (best < 0 || cost < best) { best = cost; g.TWo = two; g.nstrips = ns; g.IWs = iws; g.IWa = iwa; }
     }
     if (best < 0) return g;
-    g.ring_bytes = k * g.IWa * (pair ? 64 : 32);
+    g.ring_bytes = (k * g.IWa + roll_pad_px(k, stride, g.IWa / 16, (g.TWo + 15) / 16)) * (pair ? 64 : 32);      // KS slots + the zeroed pad
     // waves per workgroup: a divisor of the channel-tile count that packs the CU's 16 wave slots
     const int tiles = mid / 16;
     int bestfill = -1;
