@@ -47,18 +47,6 @@ DEV f32x4 silu4_fast(const f32x4 x) {
     return f32x4{y0[0], y0[1], y1[0], y1[1]};
 }
 
-// The expand SiLU of the bf16 kernel on t = -log2(e) x (the scale sits in W1 and BN1's shift; its inverse, -ln 2, in the depthwise
-// taps): t * rcp(2^t + addc) = -log2(e) * silu(x) for addc = 1, and 0 for addc = +inf (pixels outside the image) - one packed
-// multiply and the separate mask multiplies less than silu(x) * mask (5 instead of 8.5 vector instructions per value pair)
-DEV f32x4 silu4_scaled(const f32x4 t, const float addc) {
-    const f32x2_ t0 = {t[0], t[1]}, t1 = {t[2], t[3]};
-    const f32x2_ d0 = f32x2_{__builtin_amdgcn_exp2f(t0[0]), __builtin_amdgcn_exp2f(t0[1])} + addc;
-    const f32x2_ d1 = f32x2_{__builtin_amdgcn_exp2f(t1[0]), __builtin_amdgcn_exp2f(t1[1])} + addc;
-    const f32x2_ y0 = t0 * f32x2_{__builtin_amdgcn_rcpf(d0[0]), __builtin_amdgcn_rcpf(d0[1])};
-    const f32x2_ y1 = t1 * f32x2_{__builtin_amdgcn_rcpf(d1[0]), __builtin_amdgcn_rcpf(d1[1])};
-    return f32x4{y0[0], y0[1], y1[0], y1[1]};
-}
-
 template <int V> struct IntC { static constexpr int value = V; };
 #ifndef ROLL_PFD2
 #define ROLL_PFD2 0

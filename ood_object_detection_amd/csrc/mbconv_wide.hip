@@ -126,7 +126,9 @@ __global__ __launch_bounds__((IsPair<T>::value ? 512 : 1024), (IsPair<T>::value 
         const int t = 2 * pr + hi;
         tapv[pr] = p.taps[(long long)(t < NTAP ? t : 0) * mid + c0 + frow];
     }
-    const f32x4 sh1 = *reinterpret_cast<const f32x4*>(p.t1 + c0 + 4 * kg);
+    // bf16: the expand GEMM produces t = -log2(e) x directly (silu4_scaled, common.h), the taps carry -ln 2
+    constexpr float ESC = PAIR ? 1.f : -1.4426950408889634f, EINV = PAIR ? 1.f : -0.6931471805599453f;
+    const f32x4 sh1 = *reinterpret_cast<const f32x4*>(p.t1 + c0 + 4 * kg) * ESC;
     const f32x4 t2v = *reinterpret_cast<const f32x4*>(p.t2 + c0 + 4 * kg);
     // two-term mode: the lane's 4 channels of every tap, BN2's scale folded in (float32 vector-ALU depthwise)
     f32x4 wv[PAIR ? NTAP : 1];
@@ -146,7 +148,7 @@ __global__ __launch_bounds__((IsPair<T>::value ? 512 : 1024), (IsPair<T>::value 
                 wf[kc].h[e] = kv ? wh : (bf16_t)0.f;
                 wf[kc].l[e] = kv ? (bf16_t)(w - (float)wh) : (bf16_t)0.f;
             } else {
-                wf[kc].v[e] = kv ? (bf16_t)((float)wf[kc].v[e] * rs1) : (bf16_t)0.f;
+                wf[kc].v[e] = kv ? (bf16_t)((float)wf[kc].v[e] * (rs1 * ESC)) : (bf16_t)0.f;
             }
         }
     }
@@ -154,7 +156,7 @@ __global__ __launch_bounds__((IsPair<T>::value ? 512 : 1024), (IsPair<T>::value 
 #pragma unroll
     for (int pr = 0; pr < NPAIR; ++pr) {
         const bool on = dactive && 2 * pr + hi < NTAP;
-        const float tw_ = tapv[pr] * rs2;
+        const float tw_ = tapv[pr] * (rs2 * EINV);
         const bf16_t th_ = (bf16_t)tw_;
         abits[pr] = on ? (unsigned)__builtin_bit_cast(unsigned short, th_) << (16 * (frow & 1)) : 0u;
         if constexpr (PAIR) abitl[pr] = on ? (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)(tw_ - (float)th_)) << (16 * (frow & 1)) : 0u;
@@ -188,12 +190,15 @@ __global__ __launch_bounds__((IsPair<T>::value ? 512 : 1024), (IsPair<T>::value 
     const int ox0 = strip * p.TWo, tw = min(p.TWo, p.Wo - ox0);
     const int ix0 = ox0 * S - p.pad_l, iy_top = oy_b * S - p.pad_t;
     constexpr int OOB = 0x7FFFFFF0;
-    // expand: inside-the-image mask of the lane's pixel per tile
+    // expand: inside-the-image mask of the lane's pixel per tile (two-term: an AND mask; bf16: silu4_scaled's addend, 1 or +inf)
     unsigned cmask[MT];
+    float caddc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         const int c = 16 * t + frow, ix = ix0 + c;
-        cmask[t] = (c < p.IWs && ix >= 0 && ix < p.W) ? 0xFFFFFFFFu : 0u;
+        const bool inside = c < p.IWs && ix >= 0 && ix < p.W;
+        cmask[t] = inside ? 0xFFFFFFFFu : 0u;
+        caddc[t] = inside ? 1.f : __builtin_inff();
     }
     const int xlane = frow * p.xpitch + kg * PB;                  // B operand of the expand: pixel frow of a tile, piece kg of a chunk
     const int xtile = 16 * p.xpitch;
@@ -292,13 +297,18 @@ __global__ __launch_bounds__((IsPair<T>::value ? 512 : 1024), (IsPair<T>::value 
             // the inside-the-image mask as a bitwise AND with one register per tile (a packed multiply wants the mask duplicated into
             // a register pair per tile, which spilled)
             // (elements are copied to scalars first: __builtin_bit_cast applied to an ext-vector element lvalue read element 0 for all four)
-            const f32x4 a_ = act4_w(acc);
-            const unsigned cm = cmask[t];
-            const float e0 = a_[0], e1 = a_[1], e2 = a_[2], e3 = a_[3];
-            const f32x4 ev = {__builtin_bit_cast(float, __builtin_bit_cast(unsigned, e0) & cm), __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e1) & cm),
-                              __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e2) & cm), __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e3) & cm)};
-            if constexpr (PAIR) *reinterpret_cast<f32x4*>(ring_e + slot_bytes + 16 * PXB * t + kg * 16) = ev;      // float32 ring
-            else row_store4<T>(ring_e + slot_bytes + 16 * PXB * t, 4 * kg, ev);
+            if constexpr (PAIR || (WIDE_ABLATE & 16) != 0) {
+                const f32x4 a_ = act4_w(acc);
+                const unsigned cm = cmask[t];
+                const float e0 = a_[0], e1 = a_[1], e2 = a_[2], e3 = a_[3];
+                const f32x4 ev = {__builtin_bit_cast(float, __builtin_bit_cast(unsigned, e0) & cm), __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e1) & cm),
+                                  __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e2) & cm), __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e3) & cm)};
+                if constexpr (PAIR) *reinterpret_cast<f32x4*>(ring_e + slot_bytes + 16 * PXB * t + kg * 16) = ev;      // float32 ring
+                else row_store4<T>(ring_e + slot_bytes + 16 * PXB * t, 4 * kg, ev);
+            } else {
+                // the border mask rides in the SiLU's addend (+inf -> 0): no mask instructions, one register per tile
+                row_store4<T>(ring_e + slot_bytes + 16 * PXB * t, 4 * kg, silu4_scaled(acc, caddc[t]));
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
