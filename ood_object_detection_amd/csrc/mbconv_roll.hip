@@ -124,8 +124,8 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
         const int t = 2 * pr + hi;
         tapv[pr] = p.taps[(long long)(t < NTAP ? t : 0) * mid + c0 + frow];
     }
-    // bf16: the expand GEMM produces t = -log2(e) x directly (silu4_scaled), the taps carry -ln 2
-    constexpr float ESC = PAIR ? 1.f : -1.4426950408889634f, EINV = PAIR ? 1.f : -0.6931471805599453f;
+    // the expand GEMM produces t = -log2(e) x directly (silu4_scaled, common.h), the taps carry -ln 2
+    constexpr float ESC = -1.4426950408889634f, EINV = -0.6931471805599453f;
     const f32x4 sh1 = *reinterpret_cast<const f32x4*>(p.t1 + c0 + 4 * kg) * ESC;
     const f32x4 t2v = *reinterpret_cast<const f32x4*>(p.t2 + c0 + 4 * kg);
     // two-term mode: the lane's 4 channels of every tap, BN2's scale folded in (float32 vector-ALU depthwise)
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
     if constexpr (PAIR) {
         const f32x4 s2q = *reinterpret_cast<const f32x4*>(p.s2 + c0 + 4 * kg);
 #pragma unroll
-        for (int t = 0; t < NTAP; ++t) wv[t] = *reinterpret_cast<const f32x4*>(p.taps + (long long)t * mid + c0 + 4 * kg) * s2q;
+        for (int t = 0; t < NTAP; ++t) wv[t] = *reinterpret_cast<const f32x4*>(p.taps + (long long)t * mid + c0 + 4 * kg) * (s2q * EINV);
     }
     // BN1's scale of the row's channel is folded into the bf16 weights (the shift is the accumulator's initial value), and so
     // is the SE gate of the producing block along K where that block's project conv was composed into W1
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
         for (int e = 0; e < 8; ++e) {
             const float ge = gated ? (e < 4 ? g0[kc][e & 3] : g1[kc][e & 3]) : 1.f;
             if constexpr (PAIR) {                                 // scale the VALUE in float32, then split again
-                const float w = ((float)wf[kc].h[e] + (float)wf[kc].l[e]) * (rs1 * ge);
+                const float w = ((float)wf[kc].h[e] + (float)wf[kc].l[e]) * (rs1 * ge * ESC);
                 const bf16_t wh = (bf16_t)w;
                 wf[kc].h[e] = kv ? wh : (bf16_t)0.f;
                 wf[kc].l[e] = kv ? (bf16_t)(w - (float)wh) : (bf16_t)0.f;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
     for (int t = 0; t < MT; ++t) {
         const int c = 16 * t + frow, ix = ix0 + c;
         const bool inside = c < p.IWs && ix >= 0 && ix < p.W;
-        cmask[t] = PAIR ? (inside ? 1.f : 0.f) : (inside ? 1.f : __builtin_inff());     // bf16: silu4_scaled's addend
+        cmask[t] = inside ? 1.f : __builtin_inff();              // silu4_scaled's addend
         xoff[t] = inside ? ix * cbytes + kg * PB : OOB;
         xoffl[t] = (inside && (NKC - 1) * CHB + kg * PB < cbytes) ? ix * cbytes + (NKC - 1) * CHB + kg * PB : OOB;
     }
@@ -261,27 +261,22 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
     auto expand_row = [&](int rel, int slot_bytes, const Frag<T> (&src)[MT][NKC]) {
         const int iy = iy_top + rel;
         const bool rowin = iy >= 0 && iy < p.H;                           // wave-uniform
-        if constexpr (PAIR) {
-            const float rmask = rowin ? 1.f : 0.f;                        // rows outside the image: zeros (the padding applies to the expanded map)
-#pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                f32x4 acc = sh1;
-#pragma unroll
-                for (int kc = 0; kc < NKC; ++kc) mma_chunk(wf[kc], src[t][kc], acc);
-                *reinterpret_cast<f32x4*>(ring_e + slot_bytes + 16 * PXB * t + kg * 16) = roll_act(acc) * (cmask[t] * rmask);      // float32 ring
-            }
-        } else if (rowin) {
+        // rows outside the image: zeros (the padding applies to the EXPANDED map); pixels outside it: +inf in the SiLU's addend
+        auto put = [&](int t, const f32x4 v) {
+            if constexpr (PAIR) *reinterpret_cast<f32x4*>(ring_e + slot_bytes + 16 * PXB * t + kg * 16) = v;      // float32 ring
+            else row_store4<T>(ring_e + slot_bytes + 16 * PXB * t, 4 * kg, v);
+        };
+        if (rowin) {
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 f32x4 acc = sh1;
 #pragma unroll
                 for (int kc = 0; kc < ((ROLL_ABLATE & 2) ? 0 : NKC); ++kc) mma_chunk(wf[kc], src[t][kc], acc);
-                const f32x4 v = (ROLL_ABLATE & 16) ? (cmask[t] == 1.f ? acc : f32x4{0.f, 0.f, 0.f, 0.f}) : silu4_scaled(acc, cmask[t]);
-                row_store4<T>(ring_e + slot_bytes + 16 * PXB * t, 4 * kg, v);
+                put(t, (ROLL_ABLATE & 16) ? (cmask[t] == 1.f ? acc : f32x4{0.f, 0.f, 0.f, 0.f}) : silu4_scaled(acc, cmask[t]));
             }
         } else {
 #pragma unroll
-            for (int t = 0; t < MT; ++t) row_store4<T>(ring_e + slot_bytes + 16 * PXB * t, 4 * kg, f32x4{0.f, 0.f, 0.f, 0.f});
+            for (int t = 0; t < MT; ++t) put(t, f32x4{0.f, 0.f, 0.f, 0.f});
         }
     };
 

@@ -126,8 +126,8 @@ __global__ __launch_bounds__((IsPair<T>::value ? 512 : 1024), (IsPair<T>::value 
         const int t = 2 * pr + hi;
         tapv[pr] = p.taps[(long long)(t < NTAP ? t : 0) * mid + c0 + frow];
     }
-    // bf16: the expand GEMM produces t = -log2(e) x directly (silu4_scaled, common.h), the taps carry -ln 2
-    constexpr float ESC = PAIR ? 1.f : -1.4426950408889634f, EINV = PAIR ? 1.f : -0.6931471805599453f;
+    // the expand GEMM produces t = -log2(e) x directly (silu4_scaled, common.h), the taps carry -ln 2
+    constexpr float ESC = -1.4426950408889634f, EINV = -0.6931471805599453f;
     const f32x4 sh1 = *reinterpret_cast<const f32x4*>(p.t1 + c0 + 4 * kg) * ESC;
     const f32x4 t2v = *reinterpret_cast<const f32x4*>(p.t2 + c0 + 4 * kg);
     // two-term mode: the lane's 4 channels of every tap, BN2's scale folded in (float32 vector-ALU depthwise)
@@ -135,7 +135,7 @@ __global__ __launch_bounds__((IsPair<T>::value ? 512 : 1024), (IsPair<T>::value 
     if constexpr (PAIR) {
         const f32x4 s2q = *reinterpret_cast<const f32x4*>(p.s2 + c0 + 4 * kg);
 #pragma unroll
-        for (int t = 0; t < NTAP; ++t) wv[t] = *reinterpret_cast<const f32x4*>(p.taps + (long long)t * mid + c0 + 4 * kg) * s2q;
+        for (int t = 0; t < NTAP; ++t) wv[t] = *reinterpret_cast<const f32x4*>(p.taps + (long long)t * mid + c0 + 4 * kg) * (s2q * EINV);
     }
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
@@ -143,7 +143,7 @@ __global__ __launch_bounds__((IsPair<T>::value ? 512 : 1024), (IsPair<T>::value 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             if constexpr (PAIR) {                                 // scale the VALUE in float32, then split again
-                const float w = ((float)wf[kc].h[e] + (float)wf[kc].l[e]) * rs1;
+                const float w = ((float)wf[kc].h[e] + (float)wf[kc].l[e]) * (rs1 * ESC);
                 const bf16_t wh = (bf16_t)w;
                 wf[kc].h[e] = kv ? wh : (bf16_t)0.f;
                 wf[kc].l[e] = kv ? (bf16_t)(w - (float)wh) : (bf16_t)0.f;
@@ -294,11 +294,11 @@ __global__ __launch_bounds__((IsPair<T>::value ? 512 : 1024), (IsPair<T>::value 
                 for (int kc = 0; kc < NKC; ++kc) xf[kc] = ld_frag<T>(xb + (kc + 1 < NKC ? kc * CHB : xlast));
             }
             __builtin_amdgcn_sched_barrier(0);
-            // the inside-the-image mask as a bitwise AND with one register per tile (a packed multiply wants the mask duplicated into
-            // a register pair per tile, which spilled)
-            // (elements are copied to scalars first: __builtin_bit_cast applied to an ext-vector element lvalue read element 0 for all four)
             if constexpr (PAIR || (WIDE_ABLATE & 16) != 0) {
-                const f32x4 a_ = act4_w(acc);
+                // two-term: pixels beyond the strip's input width read whatever follows the X slot - float32 ring words that can be NaN
+                // patterns as bf16 pairs - and NaN * 0 stays NaN: those lanes are cleared bitwise (one AND mask register per tile)
+                // (elements are copied to scalars first: __builtin_bit_cast applied to an ext-vector element lvalue read element 0 for all four)
+                const f32x4 a_ = (WIDE_ABLATE & 16) ? acc : silu4_scaled(acc, 1.f);
                 const unsigned cm = cmask[t];
                 const float e0 = a_[0], e1 = a_[1], e2 = a_[2], e3 = a_[3];
                 const f32x4 ev = {__builtin_bit_cast(float, __builtin_bit_cast(unsigned, e0) & cm), __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e1) & cm),
@@ -306,7 +306,8 @@ __global__ __launch_bounds__((IsPair<T>::value ? 512 : 1024), (IsPair<T>::value 
                 if constexpr (PAIR) *reinterpret_cast<f32x4*>(ring_e + slot_bytes + 16 * PXB * t + kg * 16) = ev;      // float32 ring
                 else row_store4<T>(ring_e + slot_bytes + 16 * PXB * t, 4 * kg, ev);
             } else {
-                // the border mask rides in the SiLU's addend (+inf -> 0): no mask instructions, one register per tile
+                // bf16: the border mask rides in the SiLU's addend (+inf -> t * 0; what the masked lanes read - zeros from the staging,
+                // or bf16 activations behind the X slot - is finite): no mask instructions, one register per tile
                 row_store4<T>(ring_e + slot_bytes + 16 * PXB * t, 4 * kg, silu4_scaled(acc, caddc[t]));
             }
             __builtin_amdgcn_sched_barrier(0);
