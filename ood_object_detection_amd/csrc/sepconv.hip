@@ -483,6 +483,24 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META && !Is
         mrs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.ood_maxlogit + (long long)b * p.ood_image_stride + L.ood_off), 0,
                                                 H * W * p.num_anchors * 4, 0x00020000);
     }
+    // BST: store offsets of the lane's pieces, the same for every anchor chunk (the chunk's first byte travels in the buffer
+    // operation's scalar offset): 16-byte piece of group J, the three tail dwords of the one group the class count cuts (J* = C / 32,
+    // the same for every lane), the lane's OOD score slot.  A lane outside the map / past the classes holds an out-of-range offset.
+    int o128[BST ? WPT : 1][NP], otail[BST ? WPT : 1][3], oscore[BST ? WPT : 1];
+    const int jstar = C / 32;
+    if constexpr (BST) {
+        constexpr int OOB = 0x7FFFFFF0;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int sb = pix_off[i] * 2 + fpiece * 16;
+#pragma unroll
+            for (int J = 0; J < NP; ++J) o128[i][J] = (pix_in[i] && C - (32 * J + 8 * fpiece) >= 8) ? sb + 64 * J : OOB;
+            const int nvt = C - (32 * jstar + 8 * fpiece);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) otail[i][d] = (pix_in[i] && nvt > 0 && nvt < 8 && 2 * d < nvt) ? sb + 64 * jstar + 4 * d : OOB;
+            oscore[i] = (pix_in[i] && fpiece == 0) ? (pix_off[i] / N) * p.num_anchors * 4 : OOB;
+        }
+    }
     float run_m[WPT], run_s[WPT];                      // running max / sum-exp over the sub-chunks of an anchor
     constexpr float LOG2E = 1.4426950408889634f;
 
@@ -512,7 +530,8 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META && !Is
                 const unsigned keep = (co < n_count && piece * 16 < fbytes) ? 0xFFFFFFFFu : 0u;
                 *reinterpret_cast<u32x4*>(Wt + lds_row(co) * arow + piece * 16) = wpre[q] & u32x4{keep, keep, keep, keep};
             }
-            if (tid < BN) { cs[tid] = tid < n_count ? cpre_s : 1.0f; cs[BN + tid] = tid < n_count ? cpre_t : 0.0f; }
+            // (channels beyond the anchor's classes get a shift of -inf: they drop out of the max and the sum-exp without a mask)
+            if (tid < BN) cs[BN + tid] = tid < n_count ? cpre_t : -INFINITY;
         } else if (prefetch) {
 #pragma unroll
             for (int q = 0; q < WPC; ++q) {
@@ -558,6 +577,55 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META && !Is
             }
         }
 
+        if constexpr (BST) {
+            // Class predict, branch-free (round 4: the general epilogue below ran 407 vector instructions per wave and anchor here,
+            // most of them selects and compares around its store tails and -inf masks).  One chunk = one anchor (classes <= 96), no
+            // scale, no activation: logits = acc + bias as packed adds, 16-byte stores at loop-invariant lane offsets (+ the chunk's
+            // byte offset in the scalar operand), the tail dwords of the one cut group selected by the wave-uniform J*, max / sum-exp
+            // over all 24 lane values (-inf biases beyond the classes), energy from the hardware log2.
+            constexpr float LN2 = 0.6931471805599453f;
+            const int so = n_begin * 2, sa = ch * 4;
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                f32x4 v[NT];
+                u32x4 pk[NP];
+#pragma unroll
+                for (int J = 0; J < NP; ++J) {
+                    const int cb = 32 * J + 8 * fpiece;
+                    v[2 * J] = acc[i][2 * J] + *reinterpret_cast<const f32x4*>(cs + BN + cb);
+                    v[2 * J + 1] = acc[i][2 * J + 1] + *reinterpret_cast<const f32x4*>(cs + BN + cb + 4);
+                    const bf16x8 a8 = {(bf16_t)v[2 * J][0], (bf16_t)v[2 * J][1], (bf16_t)v[2 * J][2], (bf16_t)v[2 * J][3],
+                                       (bf16_t)v[2 * J + 1][0], (bf16_t)v[2 * J + 1][1], (bf16_t)v[2 * J + 1][2], (bf16_t)v[2 * J + 1][3]};
+                    pk[J] = __builtin_bit_cast(u32x4, a8);
+                    __builtin_amdgcn_raw_buffer_store_b128(pk[J], ors, o128[i][J], so, 0);
+                }
+                u32x4 pt = pk[0];
+#pragma unroll
+                for (int J = 1; J < NP; ++J) pt = jstar == J ? pk[J] : pt;          // wave-uniform select
+#pragma unroll
+                for (int d = 0; d < 3; ++d) __builtin_amdgcn_raw_buffer_store_b32(pt[d], ors, otail[i][d], so, 0);
+                float m = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) m = fmaxf(m, fmaxf(fmaxf(v[j][0], v[j][1]), fmaxf(v[j][2], v[j][3])));
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                const float tl = m * LOG2E;
+                f32x2 s2 = {0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const f32x2 e0 = f32x2{v[j][0], v[j][1]} * LOG2E - tl, e1 = f32x2{v[j][2], v[j][3]} * LOG2E - tl;
+                    s2 += f32x2{__builtin_amdgcn_exp2f(e0[0]), __builtin_amdgcn_exp2f(e0[1])};      // exp2(-inf) = 0
+                    s2 += f32x2{__builtin_amdgcn_exp2f(e1[0]), __builtin_amdgcn_exp2f(e1[1])};
+                }
+                float ssum = s2[0] + s2[1];
+                ssum += __shfl_xor(ssum, 16, 64);
+                ssum += __shfl_xor(ssum, 32, 64);
+                const float energy = -(m + LN2 * __builtin_amdgcn_logf(ssum));
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, energy), ers, oscore[i], sa, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m), mrs, oscore[i], sa, 0);
+            }
+            continue;
+        }
         // Epilogue in registers: per 32-channel group J this lane holds channels [32J + 8fp, +8) of its pixel
         float st1[META ? NP : 1][8], st2[META ? NP : 1][8];
         if constexpr (META) {
@@ -753,7 +821,8 @@ int dispatch_sep_f(hipStream_t st, SepArgs& a, int B) {
         if constexpr (sizeof(T) == 2 && NTH == 512) {
             // bf16 with dword-aligned class rows (an even class count): the branch-free chunk loop
             // (and a W chunk every thread can prefetch in two pieces: up to 64 channels - wider heads stay on the general loop)
-            if (a.vec_ok && !a.out_f32 && a.ood_classes % 2 == 0 && a.ood_classes <= 96 && a.F <= 64)
+            // (no BN scale, no activation behind the predict conv: the branch-free epilogue below builds on all of that)
+            if (a.vec_ok && !a.out_f32 && a.ood_classes % 2 == 0 && a.ood_classes <= 96 && a.F <= 64 && a.scale == nullptr && !a.post_act)
                 return launch_sep<T, TH, TW, 96, true, NTH, FT, false, 3, true>(st, a, B);
         }
         return launch_sep<T, TH, TW, 96, true, NTH, FT>(st, a, B);
