@@ -166,6 +166,12 @@ DEV void store_piece(T* dst, const float (&v)[8], int nvalid, bool vec_ok) {
     }
 }
 
+// Timing experiments on the class predict's chunk loop: variant builds only (`make variant TAG=.. UNIT=sepconv VDEFS=-DSEP_ABLATE=n`,
+// never loaded by the package).  1: no logit stores  2: no max / sum-exp / score stores  4: no epilogue at all (accumulators are kept
+// alive by one store that never happens)
+#ifndef SEP_ABLATE
+#define SEP_ABLATE 0
+#endif
 // FT: the channel count when known at compile time (all index arithmetic folds), 0 = read it from the arguments
 // BST (class predict, bf16, dword-aligned rows): every vector-memory operation of the chunk loop is unconditional - W pieces and
 // affine constants are fetched from clamped addresses and masked at their LDS store, logits and OOD scores leave through buffer
@@ -173,7 +179,12 @@ DEV void store_piece(T* dst, const float (&v)[8], int nvalid, bool vec_ok) {
 // next chunk's W prefetch is a counted `vmcnt(N)` that does not drain the chunk's own stores (the exec-mask branches around them
 // made it `vmcnt(0)`: every chunk waited for its 884 MB share to be acknowledged before the next could start).
 template <typename T, int TH, int TW, int BN, bool OOD, int NTH, int FT, bool META = false, int NIN = 3, bool BST = false>
-__global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META && !IsPair<T>::value ? 8 : 4) : 2) void sepconv_kernel(SepArgs p) {
+// (experiment switches, round 4: six waves per SIMD for the class predict - 80 registers, 2 spilled - ran 0.386 against 0.355 ms;
+// 16 x 16 pixel tiles - two MFMA tiles per wave and W chunk, half the barriers per pixel - 0.459 against 0.380 ms.  Defaults = kept.)
+#ifndef SEP_BST_WAVES
+#define SEP_BST_WAVES 4
+#endif
+__global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META && !IsPair<T>::value ? 8 : (BST && FT == 64 ? SEP_BST_WAVES : 4)) : 2) void sepconv_kernel(SepArgs p) {
     constexpr int BM = TH * TW;
     constexpr int HW_ = (TH + 2) * (TW + 2);
     constexpr int NWAVE = NTH / 64;
@@ -494,10 +505,10 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META && !Is
         for (int i = 0; i < WPT; ++i) {
             const int sb = pix_off[i] * 2 + fpiece * 16;
 #pragma unroll
-            for (int J = 0; J < NP; ++J) o128[i][J] = (pix_in[i] && C - (32 * J + 8 * fpiece) >= 8) ? sb + 64 * J : OOB;
+            for (int J = 0; J < NP; ++J) o128[i][J] = (!(SEP_ABLATE & 1) && pix_in[i] && C - (32 * J + 8 * fpiece) >= 8) ? sb + 64 * J : OOB;
             const int nvt = C - (32 * jstar + 8 * fpiece);
 #pragma unroll
-            for (int d = 0; d < 3; ++d) otail[i][d] = (pix_in[i] && nvt > 0 && nvt < 8 && 2 * d < nvt) ? sb + 64 * jstar + 4 * d : OOB;
+            for (int d = 0; d < 3; ++d) otail[i][d] = (!(SEP_ABLATE & 1) && pix_in[i] && nvt > 0 && nvt < 8 && 2 * d < nvt) ? sb + 64 * jstar + 4 * d : OOB;
             oscore[i] = (pix_in[i] && fpiece == 0) ? (pix_off[i] / N) * p.num_anchors * 4 : OOB;
         }
     }
@@ -587,6 +598,13 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META && !Is
             const int so = n_begin * 2, sa = ch * 4;
 #pragma unroll
             for (int i = 0; i < WPT; ++i) {
+                if constexpr ((SEP_ABLATE & 4) != 0) {
+                    f32x4 t_ = acc[i][0];
+#pragma unroll
+                    for (int j = 1; j < NT; ++j) t_ += acc[i][j];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t_[0] + t_[1] + t_[2] + t_[3]), ers, 0x7FFFFFF0, 0, 0);
+                    continue;
+                }
                 f32x4 v[NT];
                 u32x4 pk[NP];
 #pragma unroll
@@ -604,6 +622,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META && !Is
                 for (int J = 1; J < NP; ++J) pt = jstar == J ? pk[J] : pt;          // wave-uniform select
 #pragma unroll
                 for (int d = 0; d < 3; ++d) __builtin_amdgcn_raw_buffer_store_b32(pt[d], ors, otail[i][d], so, 0);
+                if constexpr ((SEP_ABLATE & 2) != 0) continue;
                 float m = -INFINITY;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) m = fmaxf(m, fmaxf(fmaxf(v[j][0], v[j][1]), fmaxf(v[j][2], v[j][3])));
@@ -823,7 +842,10 @@ int dispatch_sep_f(hipStream_t st, SepArgs& a, int B) {
             // (and a W chunk every thread can prefetch in two pieces: up to 64 channels - wider heads stay on the general loop)
             // (no BN scale, no activation behind the predict conv: the branch-free epilogue below builds on all of that)
             if (a.vec_ok && !a.out_f32 && a.ood_classes % 2 == 0 && a.ood_classes <= 96 && a.F <= 64 && a.scale == nullptr && !a.post_act)
-                return launch_sep<T, TH, TW, 96, true, NTH, FT, false, 3, true>(st, a, B);
+#ifndef SEP_BST_TH
+#define SEP_BST_TH 8
+#endif
+                return launch_sep<T, SEP_BST_TH, TW, 96, true, NTH, FT, false, 3, true>(st, a, B);
         }
         return launch_sep<T, TH, TW, 96, true, NTH, FT>(st, a, B);
     }
