@@ -47,6 +47,7 @@ template <int V> struct IntS { static constexpr int value = V; };
 constexpr int SR_TW = 30;                   // output columns per strip: 32 stem columns with the halo = 2 pixel tiles
 constexpr int SR_IPX = 72;                  // input pixels staged per row (2 * 32 + 1 = 65 used), 8 bytes each
 constexpr int SR_IROW = SR_IPX * 8;         // 576 bytes
+constexpr int SR_PAD_PX = 4;                // ring pixels a lane beyond the strip reads past its row (2 taps + the single last tap's partner)
 // IN: 0 float32, 1 bfloat16, 2 uint8 (normalised on the fly).  NJ = C / 16 channel tiles.
 // T: bf16_t, or bf16p_t (dtype 2, two-term bf16: the staged image, the stem weights, the stem ring and Y carry hi + lo and every
 // MFMA becomes three; Wk is then plain float32 [C][32]; the image's hi and lo planes are staged as two sets of input rows)
@@ -57,6 +58,9 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : 4)) void stem_roll_ker
     constexpr int PXB = 16 * (int)sizeof(T);        // bytes of a ring pixel (16 channels)
     constexpr int SR_ROWB = 32 * PXB;               // one stem row of a channel tile in its ring
     constexpr int SR_RING = 3 * SR_ROWB;            // per channel tile: 3 stem rows x 32 px x 16 ch
+    constexpr int SR_PADB = SR_PAD_PX * PXB;        // zeroed pixels behind the wave's last ring (read, never used, by lanes beyond the strip)
+    // the stem GEMM produces t = -log2(e) x directly (silu4_scaled, common.h: scale in the weights / BN shift, -ln 2 in the taps)
+    constexpr float ESC = -1.4426950408889634f, EINV = -0.6931471805599453f;
     constexpr int IPL = PAIR ? 2 : 1;               // staged image planes (hi | hi, lo)
     // readfirstlane: the wave index is wave-uniform, but the compiler cannot know that of threadIdx.x >> 6 - and this kernel's band
     // and strip (hence the scalar offsets of every buffer load and store) derive from it.  Left as a vector value each buffer
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : 4)) void stem_roll_ker
     const int strip = q % p.nstrips, band = q / p.nstrips;
     if (band >= p.nbands) return;                                   // waves are autonomous: no barrier follows
     const int C = p.C;
-    char* const wl = lds + wave * (IPL * 4 * SR_IROW + NJ * SR_RING);
+    char* const wl = lds + wave * (IPL * 4 * SR_IROW + NJ * SR_RING + SR_PADB);
     char* const irows = wl;                                         // [IPL][4][SR_IPX][4] bf16 interleaved input rows
     char* const rings = wl + IPL * 4 * SR_IROW;                     // [NJ][3][32 px][16 ch]
     constexpr int ILO = 4 * SR_IROW;                                // two-term: the lo plane's rows follow the hi plane's
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : 4)) void stem_roll_ker
                 const int slot = 8 * (kg & 1) + e;                  // 0..15 inside the ky: kx = slot / 4, ci = slot % 4
                 const int kx = slot >> 2, ci = slot & 3;
                 const bool real = ky < 3 && kx < 3 && ci < 3;
-                const float w = real ? (float)wrow[(ky * 3 + kx) * 3 + ci] * rs1 : 0.f;
+                const float w = real ? (float)wrow[(ky * 3 + kx) * 3 + ci] * (rs1 * ESC) : 0.f;
                 if constexpr (PAIR) {
                     const bf16_t wh = (bf16_t)w;
                     wf[j][c].h[e] = wh;
@@ -115,15 +119,15 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : 4)) void stem_roll_ker
         if constexpr (PAIR) {
             const f32x4 s2q = *reinterpret_cast<const f32x4*>(p.s2 + 16 * (j + jb) + 4 * kg);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) wv[j][t] = *reinterpret_cast<const f32x4*>(p.taps + (long long)t * C + 16 * (j + jb) + 4 * kg) * s2q;
+            for (int t = 0; t < 9; ++t) wv[j][t] = *reinterpret_cast<const f32x4*>(p.taps + (long long)t * C + 16 * (j + jb) + 4 * kg) * (s2q * EINV);
         }
-        sh1[j] = *reinterpret_cast<const f32x4*>(p.t1 + 16 * (j + jb) + 4 * kg);
+        sh1[j] = *reinterpret_cast<const f32x4*>(p.t1 + 16 * (j + jb) + 4 * kg) * ESC;
         t2v[j] = *reinterpret_cast<const f32x4*>(p.t2 + 16 * (j + jb) + 4 * kg);
 #pragma unroll
         for (int pr = 0; pr < 5; ++pr) {
             const int t = 2 * pr + hi;
             const bool on = dactive && t < 9;
-            const float wv = on ? p.taps[(long long)(t < 9 ? t : 0) * C + ch] * rs2 : 0.f;
+            const float wv = on ? p.taps[(long long)(t < 9 ? t : 0) * C + ch] * (rs2 * EINV) : 0.f;
             abits[j][pr] = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)wv) << (16 * (frow & 1));
         }
     }
@@ -138,20 +142,26 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : 4)) void stem_roll_ker
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int sx = sx0 + 16 * t + frow;
-        cmask[t] = (sx >= 0 && sx < p.Wo) ? 1.f : 0.f;
+        cmask[t] = (sx >= 0 && sx < p.Wo) ? 1.f : __builtin_inff();      // silu4_scaled's addend: +inf -> 0 outside the stem map
     }
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(p.X)) + (long long)b * 3 * p.H * p.W * esz, 0, 3 * p.H * p.W * esz, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char*>(p.Y) + (long long)b * p.Ho * p.Wo * C * (int)sizeof(T), 0, p.Ho * p.Wo * C * (int)sizeof(T), 0x00020000);
     const int plane = p.H * p.W * esz;
-    const char* dl[2];
+    // depthwise ring reads: three lane bases, every tile / tap / phase / channel-tile offset an immediate (mbconv_roll.hip); lanes
+    // beyond the strip read finite ring contents (behind the wave's last ring: the zeroed pad) and are dropped at the store
+    const char* const dl0 = rings + frow * PXB + (PAIR ? kg * 16 : (kg & 1) * (PXB / 2));      // (two-term: a float32 ring, 4 channels per lane)
+    const char* const dsame = dl0 + hi * PXB;
+    const char* const dnw = dl0 + hi * (SR_ROWB - 2 * PXB);
+    const char* const dwr = dl0 + (1 - hi) * 2 * (SR_ROWB + PXB);
+    if (lane * 16 < SR_PADB) *reinterpret_cast<u32x4*>(rings + NJ * SR_RING + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+    static_assert(SR_PADB <= 64 * 16, "one 16-byte store per lane zeroes the pad");
     int yoff[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int oxl = 16 * u + frow;
         const bool ok = oxl < tw;
-        dl[u] = rings + (ok ? oxl * PXB : 0) + (PAIR ? kg * 16 : (kg & 1) * (PXB / 2));      // (two-term: a float32 ring, 4 channels per lane)
         // (two-term: byte offset of the hi half of channels 4 kg .. inside their 8-channel group; channel tile j adds 64 bytes)
         yoff[u] = ok ? (PAIR ? (ox0 + oxl) * C * 4 + ((4 * kg) >> 3) * 32 + ((4 * kg) & 7) * 2 : ((ox0 + oxl) * C + 4 * kg) * 2) : OOB;
     }
@@ -230,7 +240,18 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : 4)) void stem_roll_ker
     // stem row sy -> ring slot `slot` of every channel tile (zeros when sy is outside the stem map: the depthwise conv pads IT)
     auto stem_row = [&](int sy, int slot_bytes) {
         const int iy0 = 2 * sy - p.pad_t;                             // first of its three input rows
-        const float rmask = (sy >= 0 && sy < p.Ho) ? 1.f : 0.f;
+        const bool rowin = sy >= 0 && sy < p.Ho;                        // wave-uniform
+        auto put = [&](int j, int t, const f32x4 v) {
+            if constexpr (PAIR) *reinterpret_cast<f32x4*>(ring_e + j * SR_RING + slot_bytes + 16 * PXB * t + kg * 16) = v;
+            else row_store4<T>(ring_e + j * SR_RING + slot_bytes + 16 * PXB * t, 4 * kg, v);
+        };
+        if (!rowin) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) put(j, t, f32x4{0.f, 0.f, 0.f, 0.f});
+            return;
+        }
         const char* r0 = irows + ((iy0 + (kg >> 1)) & 3) * SR_IROW + xf_lane;          // chunk 0: ky = kg >> 1 (0 | 1)
         const char* r1 = irows + ((iy0 + 2) & 3) * SR_IROW + xf_lane;                  // chunk 1: ky = 2 (upper half: zero weights)
 #pragma unroll
@@ -247,9 +268,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : 4)) void stem_roll_ker
                 f32x4 acc = sh1[j];
                 mma_chunk(wf[j][0], x0, acc);
                 mma_chunk(wf[j][1], x1, acc);
-                const f32x4 v = silu4r(acc) * (cmask[t] * rmask);
-                if constexpr (PAIR) *reinterpret_cast<f32x4*>(ring_e + j * SR_RING + slot_bytes + 16 * PXB * t + kg * 16) = v;
-                else row_store4<T>(ring_e + j * SR_RING + slot_bytes + 16 * PXB * t, 4 * kg, v);
+                put(j, t, silu4_scaled(acc, cmask[t]));
             }
         }
     };
@@ -288,8 +307,10 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : 4)) void stem_roll_ker
         ++snext;
         fetch_rows(2 * (snext + PFD - 1) - p.pad_t + 1, IntS<SLOT>{});   // rows of the step PFD ahead, into the slot just emptied
         __builtin_amdgcn_sched_barrier(0);
-        int hsel = hi;
-        asm volatile("" : "+v"(hsel));
+        auto pair_addr = [&](int ta, int tb, int offa, int offb) -> const char* {      // (mbconv_roll.hip)
+            if (ta / 3 == tb / 3) return dsame + offa;
+            return offb > offa ? dnw + offa : dwr + offb;
+        };
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             f32x4 acc[2] = {t2v[j], t2v[j]};
@@ -302,7 +323,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : 4)) void stem_roll_ker
                     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
                         for (int u = 0; u < 2; ++u)
-                            e[dx][u] = *reinterpret_cast<const f32x4*>(dl[u] + j * SR_RING + ((PH + dy) % 3) * SR_ROWB + dx * PXB);
+                            e[dx][u] = *reinterpret_cast<const f32x4*>(dl0 + u * 16 * PXB + j * SR_RING + ((PH + dy) % 3) * SR_ROWB + dx * PXB);
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
@@ -316,11 +337,11 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? 2 : 4)) void stem_roll_ker
                 const u32x4 fr = {dq == 0 ? bits : 0u, dq == 1 ? bits : 0u, dq == 2 ? bits : 0u, dq == 3 ? bits : 0u};
                 Frag<bf16_t> af;
                 af.v = __builtin_bit_cast(bf16x8, fr);
-                const int ta = 2 * pr, tb = 2 * pr + 1 < 9 ? 2 * pr + 1 : 0;
+                const int ta = 2 * pr, tb = 2 * pr + 1 < 9 ? 2 * pr + 1 : 2 * pr;
                 const int offa = ((PH + ta / 3) % 3) * SR_ROWB + (ta % 3) * PXB, offb = ((PH + tb / 3) % 3) * SR_ROWB + (tb % 3) * PXB;
-                const int off = (hsel ? offb : offa) + j * SR_RING;
+                const char* const src = pair_addr(ta, tb, offa, offb) + j * SR_RING;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) mma_chunk(af, ld_frag<bf16_t>(dl[u] + off), acc[u]);
+                for (int u = 0; u < 2; ++u) mma_chunk(af, ld_frag<bf16_t>(src + u * 16 * PXB), acc[u]);
             }
             }
 #pragma unroll
@@ -387,7 +408,7 @@ SrGeometry pick_stem_roll(int H, int W, int C, bool pair = false, int sym = 0) {
     // with all tiles in one wave: three waves per SIMD but every tile wave staging the input rows again ran 0.82 ms against 0.72)
     const int jsplit = 1;
     g.per_image = (g.nstrips * g.nbands * jsplit + g.wpg - 1) / g.wpg;
-    g.lds = (size_t)g.wpg * ((pair ? 2 : 1) * 4 * SR_IROW + (C / 16 / jsplit) * 3 * 32 * (pair ? 64 : 32));
+    g.lds = (size_t)g.wpg * ((pair ? 2 : 1) * 4 * SR_IROW + (C / 16 / jsplit) * 3 * 32 * (pair ? 64 : 32) + SR_PAD_PX * (pair ? 64 : 32));
     g.use = true;
     return g;
 }
