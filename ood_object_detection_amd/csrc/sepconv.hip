@@ -487,8 +487,10 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META && !Is
     }
     // BST: buffer descriptors of this image's level rows (logits) and of its OOD score rows
     __amdgpu_buffer_rsrc_t ors, ers, mrs;
+    constexpr int OB = IsPair<T>::value ? 4 : 2;          // BST: bytes per stored logit
     if constexpr (BST) {
-        ors = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(out), 0, H * W * N * 2, 0x00020000);
+        // (two-term mode: the predict conv writes float32 logits)
+        ors = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(L.out) + (long long)b * L.out_image_stride * OB, 0, H * W * N * OB, 0x00020000);
         ers = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.ood_energy + (long long)b * p.ood_image_stride + L.ood_off), 0,
                                                 H * W * p.num_anchors * 4, 0x00020000);
         mrs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.ood_maxlogit + (long long)b * p.ood_image_stride + L.ood_off), 0,
@@ -503,12 +505,13 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META && !Is
         constexpr int OOB = 0x7FFFFFF0;
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
-            const int sb = pix_off[i] * 2 + fpiece * 16;
+            const int sb = pix_off[i] * OB + fpiece * 8 * OB;
 #pragma unroll
-            for (int J = 0; J < NP; ++J) o128[i][J] = (!(SEP_ABLATE & 1) && pix_in[i] && C - (32 * J + 8 * fpiece) >= 8) ? sb + 64 * J : OOB;
+            for (int J = 0; J < NP; ++J) o128[i][J] = (!(SEP_ABLATE & 1) && pix_in[i] && C - (32 * J + 8 * fpiece) >= 8) ? sb + 32 * OB * J : OOB;
             const int nvt = C - (32 * jstar + 8 * fpiece);
 #pragma unroll
-            for (int d = 0; d < 3; ++d) otail[i][d] = (!(SEP_ABLATE & 1) && pix_in[i] && nvt > 0 && nvt < 8 && 2 * d < nvt) ? sb + 64 * jstar + 4 * d : OOB;
+            for (int d = 0; d < 3; ++d)                // the cut group's tail, one pair of logits (a dword; float32: two) per store
+                otail[i][d] = (!(SEP_ABLATE & 1) && pix_in[i] && nvt > 0 && nvt < 8 && 2 * d < nvt) ? sb + 32 * OB * jstar + 2 * OB * d : OOB;
             oscore[i] = (pix_in[i] && fpiece == 0) ? (pix_off[i] / N) * p.num_anchors * 4 : OOB;
         }
     }
@@ -595,7 +598,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META && !Is
             // byte offset in the scalar operand), the tail dwords of the one cut group selected by the wave-uniform J*, max / sum-exp
             // over all 24 lane values (-inf biases beyond the classes), energy from the hardware log2.
             constexpr float LN2 = 0.6931471805599453f;
-            const int so = n_begin * 2, sa = ch * 4;
+            const int so = n_begin * OB, sa = ch * 4;
 #pragma unroll
             for (int i = 0; i < WPT; ++i) {
                 if constexpr ((SEP_ABLATE & 4) != 0) {
@@ -606,22 +609,40 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META && !Is
                     continue;
                 }
                 f32x4 v[NT];
-                u32x4 pk[NP];
 #pragma unroll
                 for (int J = 0; J < NP; ++J) {
                     const int cb = 32 * J + 8 * fpiece;
                     v[2 * J] = acc[i][2 * J] + *reinterpret_cast<const f32x4*>(cs + BN + cb);
                     v[2 * J + 1] = acc[i][2 * J + 1] + *reinterpret_cast<const f32x4*>(cs + BN + cb + 4);
-                    const bf16x8 a8 = {(bf16_t)v[2 * J][0], (bf16_t)v[2 * J][1], (bf16_t)v[2 * J][2], (bf16_t)v[2 * J][3],
-                                       (bf16_t)v[2 * J + 1][0], (bf16_t)v[2 * J + 1][1], (bf16_t)v[2 * J + 1][2], (bf16_t)v[2 * J + 1][3]};
-                    pk[J] = __builtin_bit_cast(u32x4, a8);
-                    __builtin_amdgcn_raw_buffer_store_b128(pk[J], ors, o128[i][J], so, 0);
                 }
-                u32x4 pt = pk[0];
+                if constexpr (IsPair<T>::value) {
+                    // float32 logits: two 16-byte stores per group (an out-of-range offset + 16 is out of range too)
 #pragma unroll
-                for (int J = 1; J < NP; ++J) pt = jstar == J ? pk[J] : pt;          // wave-uniform select
+                    for (int J = 0; J < NP; ++J) {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[2 * J]), ors, o128[i][J], so, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[2 * J + 1]), ors, o128[i][J] + 16, so, 0);
+                    }
+                    f32x4 ta = v[0], tb = v[1];
 #pragma unroll
-                for (int d = 0; d < 3; ++d) __builtin_amdgcn_raw_buffer_store_b32(pt[d], ors, otail[i][d], so, 0);
+                    for (int J = 1; J < NP; ++J) { ta = jstar == J ? v[2 * J] : ta; tb = jstar == J ? v[2 * J + 1] : tb; }      // wave-uniform select
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{ta[0], ta[1]}), ors, otail[i][0], so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{ta[2], ta[3]}), ors, otail[i][1], so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{tb[0], tb[1]}), ors, otail[i][2], so, 0);
+                } else {
+                    u32x4 pk[NP];
+#pragma unroll
+                    for (int J = 0; J < NP; ++J) {
+                        const bf16x8 a8 = {(bf16_t)v[2 * J][0], (bf16_t)v[2 * J][1], (bf16_t)v[2 * J][2], (bf16_t)v[2 * J][3],
+                                           (bf16_t)v[2 * J + 1][0], (bf16_t)v[2 * J + 1][1], (bf16_t)v[2 * J + 1][2], (bf16_t)v[2 * J + 1][3]};
+                        pk[J] = __builtin_bit_cast(u32x4, a8);
+                        __builtin_amdgcn_raw_buffer_store_b128(pk[J], ors, o128[i][J], so, 0);
+                    }
+                    u32x4 pt = pk[0];
+#pragma unroll
+                    for (int J = 1; J < NP; ++J) pt = jstar == J ? pk[J] : pt;          // wave-uniform select
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) __builtin_amdgcn_raw_buffer_store_b32(pt[d], ors, otail[i][d], so, 0);
+                }
                 if constexpr ((SEP_ABLATE & 2) != 0) continue;
                 float m = -INFINITY;
 #pragma unroll
@@ -639,7 +660,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? (FT == 64 && !OOD && !META && !Is
                 float ssum = s2[0] + s2[1];
                 ssum += __shfl_xor(ssum, 16, 64);
                 ssum += __shfl_xor(ssum, 32, 64);
-                const float energy = -(m + LN2 * __builtin_amdgcn_logf(ssum));
+                const float energy = IsPair<T>::value ? -(m + logf(ssum)) : -(m + LN2 * __builtin_amdgcn_logf(ssum));
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, energy), ers, oscore[i], sa, 0);
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m), mrs, oscore[i], sa, 0);
             }
@@ -829,6 +850,10 @@ int launch_sep(hipStream_t st, SepArgs& a, int B) {
     return effdet_check_launch();
 }
 
+#ifndef SEP_BST_TH
+#define SEP_BST_TH 8
+#endif
+constexpr int SEP_BST_TH_ = SEP_BST_TH;
 template <typename T, int TH, int TW, int NTH, int FT>
 int dispatch_sep_f(hipStream_t st, SepArgs& a, int B) {
     if (a.ood_classes > 0) {
@@ -837,14 +862,16 @@ int dispatch_sep_f(hipStream_t st, SepArgs& a, int B) {
         if constexpr (FT == 0) {
             if (sep_lds_bytes<T, TH, TW, 96>(a.F) > 160 * 1024) return launch_sep<T, TH, TW, 64, true, NTH, FT>(st, a, B);
         }
+        if constexpr (IsPair<T>::value && NTH == 512) {
+            // two-term mode (float32 logits): the same branch-free chunk loop
+            if (a.out_f32 && a.ood_classes % 2 == 0 && a.ood_classes <= 96 && a.F <= 64 && a.scale == nullptr && !a.post_act)
+                return launch_sep<T, SEP_BST_TH_, TW, 96, true, NTH, FT, false, 3, true>(st, a, B);
+        }
         if constexpr (sizeof(T) == 2 && NTH == 512) {
             // bf16 with dword-aligned class rows (an even class count): the branch-free chunk loop
             // (and a W chunk every thread can prefetch in two pieces: up to 64 channels - wider heads stay on the general loop)
             // (no BN scale, no activation behind the predict conv: the branch-free epilogue below builds on all of that)
             if (a.vec_ok && !a.out_f32 && a.ood_classes % 2 == 0 && a.ood_classes <= 96 && a.F <= 64 && a.scale == nullptr && !a.post_act)
-#ifndef SEP_BST_TH
-#define SEP_BST_TH 8
-#endif
                 return launch_sep<T, SEP_BST_TH, TW, 96, true, NTH, FT, false, 3, true>(st, a, B);
         }
         return launch_sep<T, TH, TW, 96, true, NTH, FT>(st, a, B);

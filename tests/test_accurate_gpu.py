@@ -188,7 +188,7 @@ def test_sepconv_bifpn_node_pair(Fc):
     assert err < TOLP, err
 
 
-@pytest.mark.parametrize('C', [90, 7, 1, 150])
+@pytest.mark.parametrize('C', [90, 7, 1, 150, 2, 20, 32, 64, 96])
 def test_sepconv_head_levels_and_ood_pair(C):
     """all pyramid levels in one launch, per-level affine; class predict writes FLOAT32 logits (dtype 6 = 2 | 4) + OOD epilogue"""
     import _hip

@@ -387,7 +387,7 @@ def test_sepconv_bifpn_node(dtype, Fc):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('C', [90, 7, 1, 150])
+@pytest.mark.parametrize('C', [90, 7, 1, 150, 2, 20, 32, 64, 96])
 def test_sepconv_head_levels_and_ood(dtype, C):
     """all pyramid levels in one launch, per-level affine, class-predict layout + OOD epilogue"""
     import _hip
