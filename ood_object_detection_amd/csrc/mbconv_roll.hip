@@ -512,7 +512,11 @@ RollGeometry pick_roll(int H, int W, int Cin, int mid, int k, int stride, bool p
             if (mt >= 3 && (g.nkc > 1 || (mt == 4 && k == 5))) continue;
         }
         // rough issue cycles per output row of the strip set: expand tiles (MFMAs + epilogue) + depthwise tiles
-        const long long cost = (long long)ns * ((iwa / 16) * stride * (g.nkc * 16 + 48) + ((two + 15) / 16) * (npair * 16 + 56));
+        long long cost = (long long)ns * ((iwa / 16) * stride * (g.nkc * 16 + 48) + ((two + 15) / 16) * (npair * 16 + 56));
+#ifdef ROLL_PAIR_WIDE    /* experiment (variant builds only): two-term mode takes the widest strips its registers allow - measured
+                            round 4: block 1.0 0.794 ms either way (28 or 44 strips x bands per image), 2.0 0.38 vs 0.30 ms */
+        if (pair) cost = ns;
+#endif
         if (best < 0 || cost < best) { best = cost; g.TWo = two; g.nstrips = ns; g.IWs = iws; g.IWa = iwa; }
     }
     if (best < 0) return g;

@@ -1,12 +1,13 @@
 """Every MBConv front launch of a backbone's late stages in isolation: time (HIP events) and a parity check against the same
 arithmetic in torch on the GPU (float32 conv ops; a checker for this tool only - the product never runs them).
-usage: python3 tools/mbconv_layers.py [B] [reps] [shape ...]   shape = H,W,Cin,mid,k,s   (default: d0 / 640 blocks 3.0 ... 6.0)"""
+usage: python3 tools/mbconv_layers.py [B] [reps] [shape ...]   shape = H,W,Cin,mid,k,s   (default: d0 / 640 blocks 3.0 ... 6.0)
+MB_PAIR=1: the two-term (accurate) mode of the same launches (dtype 2)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import torch.nn.functional as F
-from ood_object_detection_amd import _lib
+from ood_object_detection_amd import _lib, pairfmt
 
 D0 = [('3.0', 80, 80, 40, 240, 3, 2), ('3.1', 40, 40, 80, 480, 3, 1), ('3.2', 40, 40, 80, 480, 3, 1), ('4.0', 40, 40, 80, 480, 5, 1),
       ('4.1', 40, 40, 112, 672, 5, 1), ('4.2', 40, 40, 112, 672, 5, 1), ('5.0', 40, 40, 112, 672, 5, 2), ('5.1', 20, 20, 192, 1152, 5, 1),
@@ -18,6 +19,8 @@ if os.environ.get('EFFDET_LIB_VARIANT'):          # A/B and ablation builds (mak
     _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ['EFFDET_LIB_VARIANT'])
 lib = _lib.load()
 dev = 'cuda:0'
+PAIR = os.environ.get('MB_PAIR') == '1'
+DT = 2 if PAIR else 1
 st = torch.cuda.current_stream().cuda_stream
 
 
@@ -33,16 +36,17 @@ for name, H, W, Cin, mid, k, s in shapes:
     g = torch.Generator(device=dev).manual_seed(0)
     x = torch.randn(B, H, W, Cin, device=dev, generator=g).to(torch.bfloat16)
     w1 = (torch.randn(mid, Cin, device=dev, generator=g) * Cin ** -0.5).to(torch.bfloat16)
+    xk, wk = (pairfmt.encode(x.float()), pairfmt.encode(w1.float())) if PAIR else (x, w1)      # what the kernel reads
     s1 = torch.rand(mid, device=dev, generator=g) + 0.5; t1 = torch.randn(mid, device=dev, generator=g) * 0.2
     taps = torch.randn(k * k, mid, device=dev, generator=g) / k
     s2 = torch.rand(mid, device=dev, generator=g) + 0.5; t2 = torch.randn(mid, device=dev, generator=g) * 0.2
     Ho, Wo = (H + s - 1) // s, (W + s - 1) // s
-    y = torch.full((B, Ho, Wo, mid), float('nan'), dtype=torch.bfloat16, device=dev)
-    nt = lib.effdet_mbconv_tiles_per_image(1, H, W, Cin, mid, k, s)
+    y = torch.full((B, Ho, Wo, mid), float('nan'), dtype=torch.float32 if PAIR else torch.bfloat16, device=dev)
+    nt = lib.effdet_mbconv_tiles_per_image(DT, H, W, Cin, mid, k, s)
     part = torch.full((B, nt, mid), float('nan'), dtype=torch.float32, device=dev)
 
     def run():
-        rc = lib.effdet_mbconv_expand_dw(st, 1, x.data_ptr(), y.data_ptr(), w1.data_ptr(), s1.data_ptr(), t1.data_ptr(),
+        rc = lib.effdet_mbconv_expand_dw(st, DT, xk.data_ptr(), y.data_ptr(), wk.data_ptr(), s1.data_ptr(), t1.data_ptr(),
                                          taps.data_ptr(), s2.data_ptr(), t2.data_ptr(), part.data_ptr(), B, H, W, Cin, mid, k, s)
         assert rc == 0, rc
     run()
@@ -59,15 +63,17 @@ for name, H, W, Cin, mid, k, s in shapes:
     nb = min(B, 4)
     xf = x[:nb].float().permute(0, 3, 1, 2)
     e = F.conv2d(xf, w1.float()[:, :, None, None]) * s1[None, :, None, None] + t1[None, :, None, None]
-    e = (e * torch.sigmoid(e)).to(torch.bfloat16).float()
+    e = (e * torch.sigmoid(e))
+    if not PAIR:
+        e = e.to(torch.bfloat16).float()
     wd = taps.t().reshape(mid, 1, k, k)
     o = F.conv2d(same_pad(e, k, s), wd, stride=s, groups=mid) * s2[None, :, None, None] + t2[None, :, None, None]
     ref = o * torch.sigmoid(o)
-    got = y[:nb].float().permute(0, 3, 1, 2)
+    got = (pairfmt.decode(y[:nb]) if PAIR else y[:nb].float()).permute(0, 3, 1, 2)
     err = float((got - ref).abs().max() / ref.abs().max())
     pooled = part[:nb].sum(1) / (Ho * Wo)
     perr = float((pooled - ref.mean((2, 3))).abs().max())
-    nbytes = (x.numel() + y.numel()) * 2
+    nbytes = (x.numel() + y.numel()) * (4 if PAIR else 2)
     print('%-5s H=%d W=%d Cin=%d mid=%d k=%d s=%d B=%d: %.4f ms  %6.0f GB/s  parts=%d  rel err %.4f  pool err %.5f %s' % (
-        name, H, W, Cin, mid, k, s, B, ms, nbytes / ms / 1e6, nt, err, perr, 'OK' if err < 0.03 and perr < 5e-3 else 'MISMATCH'), flush=True)
+        name, H, W, Cin, mid, k, s, B, ms, nbytes / ms / 1e6, nt, err, perr, 'OK' if err < (1e-4 if PAIR else 0.03) and perr < (1e-4 if PAIR else 5e-3) else 'MISMATCH'), flush=True)
 print('sum %.4f ms' % total)
