@@ -54,9 +54,12 @@ template <int V> struct IntC { static constexpr int value = V; };
 
 // Phase ablation for timing experiments: exists only in variant builds (`make variant TAG=.. UNIT=mbconv_roll VDEFS=-DROLL_ABLATE=n`,
 // libeffdet_hip_<TAG>.so, never loaded by the package); the product library is compiled with ROLL_ABLATE = 0.
-// 1: no depthwise arithmetic  2: no expand arithmetic  4: no Y stores  8: no X loads  16: SiLU -> identity
+// 1: no depthwise arithmetic  2: no expand arithmetic  4: no Y stores  8: no X loads  16: SiLU -> identity  32: X loads always hit (row 0)
 #ifndef ROLL_ABLATE
 #define ROLL_ABLATE 0
+#endif
+#ifndef ROLL_SYNC
+#define ROLL_SYNC 0
 #endif
 DEV f32x4 roll_act(const f32x4 x) {
     if constexpr ((ROLL_ABLATE & 16) != 0) return x; else return silu4_fast(x);
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
     auto load_row = [&](int rel, Frag<T> (&dst)[MT][NKC]) {
         int iy = iy_top + rel;
         iy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);             // rows outside the image: any valid row (zeroed by the row mask)
-        const int rowoff = iy * p.W * cbytes;                      // wave-uniform: the buffer op's scalar offset
+        const int rowoff = (ROLL_ABLATE & 32) ? 0 : iy * p.W * cbytes;      // wave-uniform: the buffer op's scalar offset  (ablation 32: every row = row 0, an L1 / L2 hit)
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -316,6 +319,9 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
 #pragma unroll
         for (int r = 0; r < S; ++r) expand_row(next_rel + r, ((PH + KS - S + r) % KS) * rowbytes, xq[SL * S + r]);
         next_rel += S;
+#if ROLL_SYNC
+        __builtin_amdgcn_s_barrier();                                // the workgroup's channel-tile waves ask for the same X row together
+#endif
 #pragma unroll
         for (int r = 0; r < S; ++r) load_row(next_rel + (PFD - 1) * S + r, xq[SL * S + r]);      // past the band's end: clamped rows, never used
         __builtin_amdgcn_sched_barrier(0);
