@@ -80,8 +80,12 @@ constexpr int roll_pad_px(int ks, int s, int mt, int no) {
 // the depthwise taps run on the vector ALU in float32: with two-term operands the diagonal-MFMA form costs 3 x 16 cycles per tap
 // pair and 16 px x 16 ch tile (240 / 624 cycles for 3 x 3 / 5 x 5) against 72 / 200 cycles of packed float32 FMAs, and the
 // expanded values need no splitting at all)
-template <int KS, int S, int NKC, int MT, int NO, typename T>
+// NJ: channel tiles (16 expanded channels each) per wave.  Every tile of a wave uses the SAME X fragments: with NJ = 1 each of the
+// mid / 16 waves of a strip fetches the strip's X rows from L2 itself, which costs the 3 x 3 blocks of the high-resolution stages 20 - 40 %
+// of their time (profiles/r04_roll_ablation.txt); NJ tiles per wave divide the readers (and the X loads / waits per unit of work) by NJ.
+template <int KS, int S, int NKC, int MT, int NO, typename T, int NJ = 1>
 __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT <= 3 ? 3 : 2) : (NKC <= 2 ? 4 : 3))) void mbconv_roll_kernel(RollArgs p) {
+    static_assert(NJ == 1 || !IsPair<T>::value, "several channel tiles per wave: bf16 only");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr bool PAIR = IsPair<T>::value;
     constexpr int PB = OpGeom<T>::PIECE, CHB = OpGeom<T>::CHUNK;     // bytes of a lane's operand piece / of a 32-channel K-chunk
@@ -95,24 +99,29 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
     int q = rr_ % p.per_image;
     const int group = q % p.ngroups; q /= p.ngroups;
     const int strip = q % p.nstrips, band = q / p.nstrips;
-    const int c0 = 16 * (group * p.wpg + wave);
+    const int c0 = 16 * NJ * (group * p.wpg + wave);              // first channel of the wave's NJ tiles
     const int cbytes = p.Cin * (int)sizeof(T), mid = p.mid;
     char* ring = lds + wave * p.ring_bytes;
     constexpr int rowbytes = MT * 16 * PXB;                       // [MT * 16 px][16 ch]
     constexpr int NTAP = KS * KS, NPAIR = (NTAP + 1) / 2;
     constexpr int OTN = NO;
+    constexpr int RB1 = KS * rowbytes + roll_pad_px(KS, S, MT, NO) * PXB;      // one channel tile's ring + its zeroed pad
 
     // ---- per-wave constants.  Every load of the prologue is issued before the first use.
     // W1 rows (A operand of the expand): lane (frow, kg) holds 8 consecutive K of channel c0 + frow per 64-byte chunk
-    Frag<T> wf[NKC];
+    Frag<T> wf[NJ][NKC];
     const bool gated = p.in_gate != nullptr;
-    const float rs1 = p.s1[c0 + frow], rs2 = p.s2[c0 + frow];
+    float rs1[NJ], rs2[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { rs1[j] = p.s1[c0 + 16 * j + frow]; rs2[j] = p.s2[c0 + 16 * j + frow]; }
     f32x4 g0[NKC], g1[NKC];
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
         const int off = kc * CHB + kg * PB;
         const bool kv = off < cbytes;
-        wf[kc] = ld_frag<T>(reinterpret_cast<const char*>(p.W1) + (long long)(c0 + frow) * cbytes + (kv ? off : 0));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            wf[j][kc] = ld_frag<T>(reinterpret_cast<const char*>(p.W1) + (long long)(c0 + 16 * j + frow) * cbytes + (kv ? off : 0));
         if (gated) {
             const float* g = p.in_gate + (long long)b * p.Cin + (kv ? off / (int)sizeof(T) : 0);
             g0[kc] = *reinterpret_cast<const f32x4*>(g); g1[kc] = *reinterpret_cast<const f32x4*>(g + 4);
@@ -121,16 +130,22 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
     const int hi = kg >> 1;
     const bool dactive = (kg & 1) == (frow >> 3);
     const int dq = (frow & 7) >> 1;
-    float tapv[NPAIR];
+    float tapv[NJ][NPAIR];
 #pragma unroll
-    for (int pr = 0; pr < NPAIR; ++pr) {
-        const int t = 2 * pr + hi;
-        tapv[pr] = p.taps[(long long)(t < NTAP ? t : 0) * mid + c0 + frow];
-    }
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int pr = 0; pr < NPAIR; ++pr) {
+            const int t = 2 * pr + hi;
+            tapv[j][pr] = p.taps[(long long)(t < NTAP ? t : 0) * mid + c0 + 16 * j + frow];
+        }
     // the expand GEMM produces t = -log2(e) x directly (silu4_scaled, common.h), the taps carry -ln 2
     constexpr float ESC = -1.4426950408889634f, EINV = -0.6931471805599453f;
-    const f32x4 sh1 = *reinterpret_cast<const f32x4*>(p.t1 + c0 + 4 * kg) * ESC;
-    const f32x4 t2v = *reinterpret_cast<const f32x4*>(p.t2 + c0 + 4 * kg);
+    f32x4 sh1[NJ], t2v[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        sh1[j] = *reinterpret_cast<const f32x4*>(p.t1 + c0 + 16 * j + 4 * kg) * ESC;
+        t2v[j] = *reinterpret_cast<const f32x4*>(p.t2 + c0 + 16 * j + 4 * kg);
+    }
     // two-term mode: the lane's 4 channels of every tap, BN2's scale folded in (float32 vector-ALU depthwise)
     f32x4 wv[PAIR ? NTAP : 1];
     if constexpr (PAIR) {
@@ -141,34 +156,39 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
     // BN1's scale of the row's channel is folded into the bf16 weights (the shift is the accumulator's initial value), and so
     // is the SE gate of the producing block along K where that block's project conv was composed into W1
 #pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
         const bool kv = kc * CHB + kg * PB < cbytes;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float ge = gated ? (e < 4 ? g0[kc][e & 3] : g1[kc][e & 3]) : 1.f;
             if constexpr (PAIR) {                                 // scale the VALUE in float32, then split again
-                const float w = ((float)wf[kc].h[e] + (float)wf[kc].l[e]) * (rs1 * ge * ESC);
+                const float w = ((float)wf[j][kc].h[e] + (float)wf[j][kc].l[e]) * (rs1[j] * ge * ESC);
                 const bf16_t wh = (bf16_t)w;
-                wf[kc].h[e] = kv ? wh : (bf16_t)0.f;
-                wf[kc].l[e] = kv ? (bf16_t)(w - (float)wh) : (bf16_t)0.f;
+                wf[j][kc].h[e] = kv ? wh : (bf16_t)0.f;
+                wf[j][kc].l[e] = kv ? (bf16_t)(w - (float)wh) : (bf16_t)0.f;
             } else {
-                wf[kc].v[e] = kv ? (bf16_t)((float)wf[kc].v[e] * (rs1 * ge * ESC)) : (bf16_t)0.f;
+                wf[j][kc].v[e] = kv ? (bf16_t)((float)wf[j][kc].v[e] * (rs1[j] * ge * ESC)) : (bf16_t)0.f;
             }
         }
     }
     // diagonal tap operands: the lane's single non-zero dword of diag(w[t0]) | diag(w[t1]), BN2's scale folded in
-    unsigned abits[NPAIR], abitl[PAIR ? NPAIR : 1];
+    unsigned abits[NJ][NPAIR], abitl[PAIR ? NPAIR : 1];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int pr = 0; pr < NPAIR; ++pr) {
         const bool on = dactive && 2 * pr + hi < NTAP;
-        const float tw_ = tapv[pr] * (rs2 * EINV);
+        const float tw_ = tapv[j][pr] * (rs2[j] * EINV);
         const bf16_t th_ = (bf16_t)tw_;
-        abits[pr] = on ? (unsigned)__builtin_bit_cast(unsigned short, th_) << (16 * (frow & 1)) : 0u;
+        abits[j][pr] = on ? (unsigned)__builtin_bit_cast(unsigned short, th_) << (16 * (frow & 1)) : 0u;
         if constexpr (PAIR) abitl[pr] = on ? (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)(tw_ - (float)th_)) << (16 * (frow & 1)) : 0u;
     }
-    // the lane's diagonal operand of tap pair pr, expanded from its one non-zero dword (two-term: one per term)
-    auto diag = [&](int pr) {
-        unsigned bits = abits[pr];
+    // the lane's diagonal operand of tap pair pr of channel tile j, expanded from its one non-zero dword (two-term: one per term)
+    auto diag = [&](int pr, int j = 0) {
+        unsigned bits = abits[j][pr];
+        if constexpr (NJ > 1) asm volatile("" : "+v"(bits));      // several tiles: expanded at use (NJ x 5 resident operands would not fit)
         if constexpr (KS == 5) asm volatile("" : "+v"(bits));     // 13 resident operands (52 registers) do not fit: expanded at use
         const u32x4 fr = {dq == 0 ? bits : 0u, dq == 1 ? bits : 0u, dq == 2 ? bits : 0u, dq == 3 ? bits : 0u};
         Frag<T> af;
@@ -219,8 +239,10 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
     {   // the pad behind the last ring slot: read (never used) by lanes beyond the strip - must be finite
         constexpr int PADB = roll_pad_px(KS, S, MT, NO) * PXB;
 #pragma unroll
-        for (int o = 0; o < PADB; o += 64 * 16)
-            if (o + lane * 16 < PADB) *reinterpret_cast<u32x4*>(ring + KS * rowbytes + o + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int o = 0; o < PADB; o += 64 * 16)
+                if (o + lane * 16 < PADB) *reinterpret_cast<u32x4*>(ring + j * RB1 + KS * rowbytes + o + lane * 16) = u32x4{0u, 0u, 0u, 0u};
     }
     int yoff[OTN];
 #pragma unroll
@@ -265,21 +287,25 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
         const int iy = iy_top + rel;
         const bool rowin = iy >= 0 && iy < p.H;                           // wave-uniform
         // rows outside the image: zeros (the padding applies to the EXPANDED map); pixels outside it: +inf in the SiLU's addend
-        auto put = [&](int t, const f32x4 v) {
-            if constexpr (PAIR) *reinterpret_cast<f32x4*>(ring_e + slot_bytes + 16 * PXB * t + kg * 16) = v;      // float32 ring
-            else row_store4<T>(ring_e + slot_bytes + 16 * PXB * t, 4 * kg, v);
+        auto put = [&](int j, int t, const f32x4 v) {
+            if constexpr (PAIR) *reinterpret_cast<f32x4*>(ring_e + j * RB1 + slot_bytes + 16 * PXB * t + kg * 16) = v;      // float32 ring
+            else row_store4<T>(ring_e + j * RB1 + slot_bytes + 16 * PXB * t, 4 * kg, v);
         };
         if (rowin) {
 #pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                f32x4 acc = sh1;
+            for (int t = 0; t < MT; ++t)
 #pragma unroll
-                for (int kc = 0; kc < ((ROLL_ABLATE & 2) ? 0 : NKC); ++kc) mma_chunk(wf[kc], src[t][kc], acc);
-                put(t, (ROLL_ABLATE & 16) ? (cmask[t] == 1.f ? acc : f32x4{0.f, 0.f, 0.f, 0.f}) : silu4_scaled(acc, cmask[t]));
-            }
+                for (int j = 0; j < NJ; ++j) {                         // every channel tile multiplies the same X fragments
+                    f32x4 acc = sh1[j];
+#pragma unroll
+                    for (int kc = 0; kc < ((ROLL_ABLATE & 2) ? 0 : NKC); ++kc) mma_chunk(wf[j][kc], src[t][kc], acc);
+                    put(j, t, (ROLL_ABLATE & 16) ? (cmask[t] == 1.f ? acc : f32x4{0.f, 0.f, 0.f, 0.f}) : silu4_scaled(acc, cmask[t]));
+                }
         } else {
 #pragma unroll
-            for (int t = 0; t < MT; ++t) put(t, f32x4{0.f, 0.f, 0.f, 0.f});
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) put(j, t, f32x4{0.f, 0.f, 0.f, 0.f});
         }
     };
 
@@ -296,7 +322,11 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), yrs, yo, yrow_, 0);
         }
     };
-    float pl[4] = {0.f, 0.f, 0.f, 0.f};
+    float pl[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pl[j][r] = 0.f;
     int next_rel = 0;
     // prologue: the first KS - S rows of the band's window (ring slots 0 .. KS-S-1), loaded and expanded on the spot
 #pragma unroll 1
@@ -338,7 +368,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
             // per output tile; ring offsets are immediates (PH is a template constant), one window row of taps per batch
             f32x4 acc[OTN];
 #pragma unroll
-            for (int u = 0; u < OTN; ++u) acc[u] = t2v;
+            for (int u = 0; u < OTN; ++u) acc[u] = t2v[0];
 #pragma unroll
             for (int dy = 0; dy < KS; ++dy) {
                 f32x4 e[KS][OTN];
@@ -359,7 +389,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
                 const int yo = yoff[u];
                 const float vm = yo == OOB ? 0.f : 1.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pl[r] += ov[r] * vm;
+                for (int r = 0; r < 4; ++r) pl[0][r] += ov[r] * vm;
                 store_out(ov, yo, yrow);
             }
         } else if constexpr (KS == 5) {
@@ -370,7 +400,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
             // two pairs that straddle rows select between two offsets
             f32x4 acc[OTN];
 #pragma unroll
-            for (int u = 0; u < OTN; ++u) acc[u] = t2v;
+            for (int u = 0; u < OTN; ++u) acc[u] = t2v[0];
             constexpr int G = 8 / OTN < NPAIR ? 8 / OTN : NPAIR;      // (two-term: the same count of twice as large fragments, with twice the registers)      // 8 B-operand fragments in flight: the X rows prefetched for the next step keep 24 - 32 registers
 #pragma unroll
             for (int p0 = 0; p0 < NPAIR; p0 += G) {
@@ -403,22 +433,24 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
                 const int yo = yoff[u];
                 const float vm = yo == OOB ? 0.f : 1.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pl[r] += ov[r] * vm;
+                for (int r = 0; r < 4; ++r) pl[0][r] += ov[r] * vm;
                 store_out(ov, yo, yrow);
             }
         } else {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int u0 = 0; u0 < OTN; u0 += OT) {
             {
                 f32x4 acc[OT];
 #pragma unroll
-                for (int u = 0; u < OT; ++u) acc[u] = t2v;
+                for (int u = 0; u < OT; ++u) acc[u] = t2v[j];
 #pragma unroll
                 for (int pr = 0; pr < NPAIR; ++pr) {
-                    const Frag<T> af = diag(pr);
+                    const Frag<T> af = diag(pr, j);
                     const int ta = 2 * pr, tb = 2 * pr + 1 < NTAP ? 2 * pr + 1 : 2 * pr;        // constants after unrolling
                     const int offa = ((PH + ta / KS) % KS) * rowbytes + (ta % KS) * PXB, offb = ((PH + tb / KS) % KS) * rowbytes + (tb % KS) * PXB;
-                    const char* const src = pair_addr(ta, tb, offa, offb);
+                    const char* const src = pair_addr(ta, tb, offa, offb) + j * RB1;
 #pragma unroll
                     for (int u = 0; u < OT; ++u) {
                         if (u0 + u < OTN && !(ROLL_ABLATE & 1)) mma_chunk(af, ld_frag<T>(src + (u0 + u) * TILEB), acc[u]);
@@ -433,8 +465,8 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
                         const int yo = yoff[u0 + u < OTN ? u0 + u : 0];
                         const float vm = yo == OOB ? 0.f : 1.f;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) pl[r] += ov[r] * vm;
-                        store_out(ov, yo, yrow);
+                        for (int r = 0; r < 4; ++r) pl[j][r] += ov[r] * vm;
+                        store_out(ov, yo + 32 * j, yrow);            // channel tile j: + 16 channels (an out-of-range offset stays out of range)
                     }
                 }
             }
@@ -472,19 +504,29 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
     }
     if (p.pool_partial != nullptr) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = pl[r];
-            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            pl[r] = v;
-        }
-        if (frow == 0) {
-            float* dst = p.pool_partial + ((long long)b * (p.nstrips * p.nbands) + band * p.nstrips + strip) * mid + c0 + 4 * kg;
-            *reinterpret_cast<f32x4*>(dst) = f32x4{pl[0], pl[1], pl[2], pl[3]};
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = pl[j][r];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                pl[j][r] = v;
+            }
+            if (frow == 0) {
+                float* dst = p.pool_partial + ((long long)b * (p.nstrips * p.nbands) + band * p.nstrips + strip) * mid + c0 + 16 * j + 4 * kg;
+                *reinterpret_cast<f32x4*>(dst) = f32x4{pl[j][0], pl[j][1], pl[j][2], pl[j][3]};
+            }
         }
     }
 }
 
-struct RollGeometry { bool use; int TWo, nstrips, IWs, IWa, band_rows, nbands, wpg, ngroups, ring_bytes, nkc; size_t lds; };
+struct RollGeometry { bool use; int TWo, nstrips, IWs, IWa, band_rows, nbands, wpg, ngroups, ring_bytes, nkc, nj; size_t lds; };
+// Channel tiles per wave (kernel parameter NJ).  Measured at d0 / 640 / batch 64 (profiles/r04_roll_nj.txt): two tiles per wave take
+// block 1.0 (320 x 320, 32 -> 96 channels, 3 x 3 / s2: 64 bytes of X per pixel) from 0.360 to 0.328 ms; the 16- and 24-channel inputs of
+// the other 3 x 3 blocks gain nothing, three tiles per wave (128 registers, spills in the 48-pixel strips) lose 6 - 15 %.  So: two tiles
+// where a stride-2 3 x 3 block reads at least 64 bytes per input pixel and the tile count is even; ROLL_NJ_MAX widens that for A/B builds.
+#ifndef ROLL_NJ_MAX
+#define ROLL_NJ_MAX 0
+#endif
 
 // Geometry depends on the map and channel sizes only - never on the batch - so that an image's result (including the order
 // in which its SE pool partials are summed) is the same at every batch size.
@@ -526,9 +568,15 @@ RollGeometry pick_roll(int H, int W, int Cin, int mid, int k, int stride, bool p
         if (best < 0 || cost < best) { best = cost; g.TWo = two; g.nstrips = ns; g.IWs = iws; g.IWa = iwa; }
     }
     if (best < 0) return g;
-    g.ring_bytes = (k * g.IWa + roll_pad_px(k, stride, g.IWa / 16, (g.TWo + 15) / 16)) * (pair ? 64 : 32);      // KS slots + the zeroed pad
-    // waves per workgroup: a divisor of the channel-tile count that packs the CU's 16 wave slots
-    const int tiles = mid / 16;
+    g.nj = 1;
+    if (!pair && k == 3 && g.nkc == 1) {
+        if (ROLL_NJ_MAX == 0) { if (stride == 2 && Cin >= 32 && (mid / 16) % 2 == 0) g.nj = 2; }
+        else for (int n = 2; n <= ROLL_NJ_MAX; ++n) if ((mid / 16) % n == 0) g.nj = n;
+    }
+    // per wave: nj x (KS slots + the zeroed pad)
+    g.ring_bytes = g.nj * (k * g.IWa + roll_pad_px(k, stride, g.IWa / 16, (g.TWo + 15) / 16)) * (pair ? 64 : 32);
+    // waves per workgroup: a divisor of the wave count per strip that packs the CU's 16 wave slots
+    const int tiles = mid / 16 / g.nj;
     int bestfill = -1;
     for (int d = 1; d <= 8; ++d) {
         if (tiles % d) continue;
@@ -544,25 +592,25 @@ RollGeometry pick_roll(int H, int W, int Cin, int mid, int k, int stride, bool p
     return g;
 }
 
-template <int KS, int S, int NKC, typename T>
+template <int KS, int S, int NKC, typename T, int NJ = 1>
 void (*roll_kernel_for(int mt, int no))(RollArgs) {
     // MT = ceil(IWs / 16) input tiles, NO = ceil(TWo / 16) output tiles: stride 1 -> NO in {MT - 1, MT}; stride 2 -> MT in {2 NO - 1 .. 2 NO + 1}
     if constexpr (S == 1) {
-        if (mt == 2) return no == 1 ? mbconv_roll_kernel<KS, S, NKC, 2, 1, T> : no == 2 ? mbconv_roll_kernel<KS, S, NKC, 2, 2, T> : nullptr;
+        if (mt == 2) return no == 1 ? mbconv_roll_kernel<KS, S, NKC, 2, 1, T, NJ> : no == 2 ? mbconv_roll_kernel<KS, S, NKC, 2, 2, T, NJ> : nullptr;
         if constexpr (NKC <= 4) {
-            if (mt == 3) return no == 2 ? mbconv_roll_kernel<KS, S, NKC, 3, 2, T> : no == 3 ? mbconv_roll_kernel<KS, S, NKC, 3, 3, T> : nullptr;
+            if (mt == 3) return no == 2 ? mbconv_roll_kernel<KS, S, NKC, 3, 2, T, NJ> : no == 3 ? mbconv_roll_kernel<KS, S, NKC, 3, 3, T, NJ> : nullptr;
         }
         if constexpr (NKC <= 3 && KS == 3) {
-            if (mt == 4) return no == 3 ? mbconv_roll_kernel<KS, S, NKC, 4, 3, T> : no == 4 ? mbconv_roll_kernel<KS, S, NKC, 4, 4, T> : nullptr;
+            if (mt == 4) return no == 3 ? mbconv_roll_kernel<KS, S, NKC, 4, 3, T, NJ> : no == 4 ? mbconv_roll_kernel<KS, S, NKC, 4, 4, T, NJ> : nullptr;
         }
     } else {
         if constexpr (NKC <= 4) {
-            if (mt == 2) return no == 1 ? mbconv_roll_kernel<KS, S, NKC, 2, 1, T> : nullptr;
+            if (mt == 2) return no == 1 ? mbconv_roll_kernel<KS, S, NKC, 2, 1, T, NJ> : nullptr;
         }
         if constexpr (NKC == 1) {
-            if (mt == 3) return no == 1 ? mbconv_roll_kernel<KS, S, NKC, 3, 1, T> : no == 2 ? mbconv_roll_kernel<KS, S, NKC, 3, 2, T> : nullptr;
+            if (mt == 3) return no == 1 ? mbconv_roll_kernel<KS, S, NKC, 3, 1, T, NJ> : no == 2 ? mbconv_roll_kernel<KS, S, NKC, 3, 2, T, NJ> : nullptr;
             if constexpr (KS == 3) {
-                if (mt == 4) return no == 2 ? mbconv_roll_kernel<KS, S, NKC, 4, 2, T> : nullptr;
+                if (mt == 4) return no == 2 ? mbconv_roll_kernel<KS, S, NKC, 4, 2, T, NJ> : nullptr;
             }
         }
     }
@@ -574,7 +622,15 @@ int launch_roll_ks(hipStream_t st, const RollArgs& r, const RollGeometry& g) {
     void (*kern)(RollArgs) = nullptr;
     const int mt = g.IWa / 16, no = (g.TWo + 15) / 16;
     switch (g.nkc) {
-        case 1: kern = roll_kernel_for<KS, S, 1, T>(mt, no); break;
+        case 1:
+            if constexpr (KS == 3 && !IsPair<T>::value) {
+                if (g.nj == 2) { kern = roll_kernel_for<KS, S, 1, T, 2>(mt, no); break; }
+#if ROLL_NJ_MAX >= 3
+                if (g.nj == 3) { kern = roll_kernel_for<KS, S, 1, T, 3>(mt, no); break; }
+#endif
+            }
+            if (g.nj != 1) return EFFDET_EINVAL;
+            kern = roll_kernel_for<KS, S, 1, T>(mt, no); break;
         case 2: kern = roll_kernel_for<KS, S, 2, T>(mt, no); break;
         default: break;
     }
