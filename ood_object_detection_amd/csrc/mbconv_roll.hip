@@ -588,6 +588,7 @@ RollGeometry pick_roll(int H, int W, int Cin, int mid, int k, int stride, bool p
     g.band_rows = (Ho + g.nbands - 1) / g.nbands;
     g.nbands = (Ho + g.band_rows - 1) / g.band_rows;
     g.lds = (size_t)g.wpg * g.ring_bytes;
+    if (g.lds > 160 * 1024) return g;                           // (cannot happen for the strip widths above; a launch would fail)
     g.use = true;
     return g;
 }
