@@ -84,8 +84,7 @@ constexpr int roll_pad_px(int ks, int s, int mt, int no) {
 // mid / 16 waves of a strip fetches the strip's X rows from L2 itself, which costs the 3 x 3 blocks of the high-resolution stages 20 - 40 %
 // of their time (profiles/r04_roll_ablation.txt); NJ tiles per wave divide the readers (and the X loads / waits per unit of work) by NJ.
 template <int KS, int S, int NKC, int MT, int NO, typename T, int NJ = 1>
-__global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT <= 3 ? 3 : 2) : (NKC <= 2 ? 4 : 3))) void mbconv_roll_kernel(RollArgs p) {
-    static_assert(NJ == 1 || !IsPair<T>::value, "several channel tiles per wave: bf16 only");
+__global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT <= 3 && NJ == 1 ? 3 : 2) : (NKC <= 2 ? 4 : 3))) void mbconv_roll_kernel(RollArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr bool PAIR = IsPair<T>::value;
     constexpr int PB = OpGeom<T>::PIECE, CHB = OpGeom<T>::CHUNK;     // bytes of a lane's operand piece / of a 32-channel K-chunk
@@ -100,6 +99,10 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
     const int group = q % p.ngroups; q /= p.ngroups;
     const int strip = q % p.nstrips, band = q / p.nstrips;
     const int c0 = 16 * NJ * (group * p.wpg + wave);              // first channel of the wave's NJ tiles
+    // an odd tile count leaves the strip's last wave with fewer tiles: njw of them are real (wave-uniform); the others read tile 0's
+    // constants and skip all their work and stores
+    const int njw = NJ == 1 ? 1 : min(NJ, p.mid / 16 - NJ * (group * p.wpg + wave));
+    auto cj = [&](int j) { return c0 + (j < njw ? 16 * j : 0); };
     const int cbytes = p.Cin * (int)sizeof(T), mid = p.mid;
     char* ring = lds + wave * p.ring_bytes;
     constexpr int rowbytes = MT * 16 * PXB;                       // [MT * 16 px][16 ch]
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
     const bool gated = p.in_gate != nullptr;
     float rs1[NJ], rs2[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) { rs1[j] = p.s1[c0 + 16 * j + frow]; rs2[j] = p.s2[c0 + 16 * j + frow]; }
+    for (int j = 0; j < NJ; ++j) { rs1[j] = p.s1[cj(j) + frow]; rs2[j] = p.s2[cj(j) + frow]; }
     f32x4 g0[NKC], g1[NKC];
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
         const bool kv = off < cbytes;
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-            wf[j][kc] = ld_frag<T>(reinterpret_cast<const char*>(p.W1) + (long long)(c0 + 16 * j + frow) * cbytes + (kv ? off : 0));
+            wf[j][kc] = ld_frag<T>(reinterpret_cast<const char*>(p.W1) + (long long)(cj(j) + frow) * cbytes + (kv ? off : 0));
         if (gated) {
             const float* g = p.in_gate + (long long)b * p.Cin + (kv ? off / (int)sizeof(T) : 0);
             g0[kc] = *reinterpret_cast<const f32x4*>(g); g1[kc] = *reinterpret_cast<const f32x4*>(g + 4);
@@ -136,22 +139,25 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
 #pragma unroll
         for (int pr = 0; pr < NPAIR; ++pr) {
             const int t = 2 * pr + hi;
-            tapv[j][pr] = p.taps[(long long)(t < NTAP ? t : 0) * mid + c0 + 16 * j + frow];
+            tapv[j][pr] = p.taps[(long long)(t < NTAP ? t : 0) * mid + cj(j) + frow];
         }
     // the expand GEMM produces t = -log2(e) x directly (silu4_scaled, common.h), the taps carry -ln 2
     constexpr float ESC = -1.4426950408889634f, EINV = -0.6931471805599453f;
     f32x4 sh1[NJ], t2v[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        sh1[j] = *reinterpret_cast<const f32x4*>(p.t1 + c0 + 16 * j + 4 * kg) * ESC;
-        t2v[j] = *reinterpret_cast<const f32x4*>(p.t2 + c0 + 16 * j + 4 * kg);
+        sh1[j] = *reinterpret_cast<const f32x4*>(p.t1 + cj(j) + 4 * kg) * ESC;
+        t2v[j] = *reinterpret_cast<const f32x4*>(p.t2 + cj(j) + 4 * kg);
     }
     // two-term mode: the lane's 4 channels of every tap, BN2's scale folded in (float32 vector-ALU depthwise)
-    f32x4 wv[PAIR ? NTAP : 1];
+    f32x4 wv[PAIR ? NJ : 1][PAIR ? NTAP : 1];
     if constexpr (PAIR) {
-        const f32x4 s2q = *reinterpret_cast<const f32x4*>(p.s2 + c0 + 4 * kg);
 #pragma unroll
-        for (int t = 0; t < NTAP; ++t) wv[t] = *reinterpret_cast<const f32x4*>(p.taps + (long long)t * mid + c0 + 4 * kg) * (s2q * EINV);
+        for (int j = 0; j < NJ; ++j) {
+            const f32x4 s2q = *reinterpret_cast<const f32x4*>(p.s2 + cj(j) + 4 * kg);
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t) wv[j][t] = *reinterpret_cast<const f32x4*>(p.taps + (long long)t * mid + cj(j) + 4 * kg) * (s2q * EINV);
+        }
     }
     // BN1's scale of the row's channel is folded into the bf16 weights (the shift is the accumulator's initial value), and so
     // is the SE gate of the producing block along K where that block's project conv was composed into W1
@@ -296,6 +302,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
             for (int t = 0; t < MT; ++t)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {                         // every channel tile multiplies the same X fragments
+                    if (j >= njw) continue;
                     f32x4 acc = sh1[j];
 #pragma unroll
                     for (int kc = 0; kc < ((ROLL_ABLATE & 2) ? 0 : NKC); ++kc) mma_chunk(wf[j][kc], src[t][kc], acc);
@@ -366,9 +373,12 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
         if constexpr (PAIR) {
             // float32 depthwise on the vector ALU: per tap one 16-byte ring read (4 channels of the lane's pixel) and two packed FMAs
             // per output tile; ring offsets are immediates (PH is a template constant), one window row of taps per batch
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+            if (j >= njw) continue;
             f32x4 acc[OTN];
 #pragma unroll
-            for (int u = 0; u < OTN; ++u) acc[u] = t2v[0];
+            for (int u = 0; u < OTN; ++u) acc[u] = t2v[j];
 #pragma unroll
             for (int dy = 0; dy < KS; ++dy) {
                 f32x4 e[KS][OTN];
@@ -376,11 +386,11 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
                 for (int dx = 0; dx < KS; ++dx)
 #pragma unroll
                     for (int u = 0; u < OTN; ++u)
-                        e[dx][u] = *reinterpret_cast<const f32x4*>(dl0 + u * TILEB + ((PH + dy) % KS) * rowbytes + dx * PXB);
+                        e[dx][u] = *reinterpret_cast<const f32x4*>(dl0 + j * RB1 + u * TILEB + ((PH + dy) % KS) * rowbytes + dx * PXB);
 #pragma unroll
                 for (int dx = 0; dx < KS; ++dx)
 #pragma unroll
-                    for (int u = 0; u < OTN; ++u) acc[u] = e[dx][u] * wv[dy * KS + dx] + acc[u];
+                    for (int u = 0; u < OTN; ++u) acc[u] = e[dx][u] * wv[j][dy * KS + dx] + acc[u];
                 __builtin_amdgcn_sched_barrier(0);              // rows stay rows: hoisting every read of the window would spill
             }
 #pragma unroll
@@ -389,8 +399,9 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
                 const int yo = yoff[u];
                 const float vm = yo == OOB ? 0.f : 1.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pl[0][r] += ov[r] * vm;
-                store_out(ov, yo, yrow);
+                for (int r = 0; r < 4; ++r) pl[j][r] += ov[r] * vm;
+                store_out(ov, yo + 64 * j, yrow);               // channel tile j: two 8-channel groups of 32 bytes further
+            }
             }
         } else if constexpr (KS == 5) {
             // 5 x 5 (round 3, as in mbconv_wide.hip): every tap pair is expanded ONCE per row and applied to all NO tiles (the row used
@@ -441,7 +452,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int u0 = 0; u0 < OTN; u0 += OT) {
-            {
+            if (j < njw) {
                 f32x4 acc[OT];
 #pragma unroll
                 for (int u = 0; u < OT; ++u) acc[u] = t2v[j];
@@ -511,7 +522,7 @@ __global__ __launch_bounds__(512, (IsPair<T>::value ? (KS == 3 && NKC == 1 && MT
                 v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
                 pl[j][r] = v;
             }
-            if (frow == 0) {
+            if (frow == 0 && j < njw) {
                 float* dst = p.pool_partial + ((long long)b * (p.nstrips * p.nbands) + band * p.nstrips + strip) * mid + c0 + 16 * j + 4 * kg;
                 *reinterpret_cast<f32x4*>(dst) = f32x4{pl[j][0], pl[j][1], pl[j][2], pl[j][3]};
             }
@@ -526,6 +537,9 @@ struct RollGeometry { bool use; int TWo, nstrips, IWs, IWa, band_rows, nbands, w
 // where a stride-2 3 x 3 block reads at least 64 bytes per input pixel and the tile count is even; ROLL_NJ_MAX widens that for A/B builds.
 #ifndef ROLL_NJ_MAX
 #define ROLL_NJ_MAX 0
+#endif
+#ifndef ROLL_NJ_PAIR
+#define ROLL_NJ_PAIR 1
 #endif
 
 // Geometry depends on the map and channel sizes only - never on the batch - so that an image's result (including the order
@@ -569,18 +583,21 @@ RollGeometry pick_roll(int H, int W, int Cin, int mid, int k, int stride, bool p
     }
     if (best < 0) return g;
     g.nj = 1;
-    if (!pair && k == 3 && g.nkc == 1) {
-        if (ROLL_NJ_MAX == 0) { if (stride == 2 && Cin >= 32 && (mid / 16) % 2 == 0) g.nj = 2; }
+    if (k == 3 && g.nkc == 1) {
+        // two-term mode (twice the X bytes per pixel): two tiles per wave wherever there are at least two (3 x 3, one K chunk), an odd
+        // count leaves the last wave of a strip with one; bf16: stride-2 blocks reading >= 64 bytes per input pixel
+        if (ROLL_NJ_MAX == 0) { if (pair ? (ROLL_NJ_PAIR && mid / 16 >= 2) : (stride == 2 && Cin >= 32 && (mid / 16) % 2 == 0)) g.nj = 2; }
         else for (int n = 2; n <= ROLL_NJ_MAX; ++n) if ((mid / 16) % n == 0) g.nj = n;
     }
     // per wave: nj x (KS slots + the zeroed pad)
     g.ring_bytes = g.nj * (k * g.IWa + roll_pad_px(k, stride, g.IWa / 16, (g.TWo + 15) / 16)) * (pair ? 64 : 32);
     // waves per workgroup: a divisor of the wave count per strip that packs the CU's 16 wave slots
-    const int tiles = mid / 16 / g.nj;
+    const int tiles = (mid / 16 + g.nj - 1) / g.nj;              // waves per strip
     int bestfill = -1;
     for (int d = 1; d <= 8; ++d) {
         if (tiles % d) continue;
-        const int fill = (16 / d) * d;
+        const int slots = (pair && g.nj > 1) ? 8 : 16;            // (two tiles per wave in two-term mode: 170 - 250 registers, two waves per SIMD)
+        const int fill = (slots / d) * d;
         if (fill > bestfill || (fill == bestfill && d > g.wpg)) { bestfill = fill; g.wpg = d; }
     }
     g.ngroups = tiles / g.wpg;
@@ -624,7 +641,7 @@ int launch_roll_ks(hipStream_t st, const RollArgs& r, const RollGeometry& g) {
     const int mt = g.IWa / 16, no = (g.TWo + 15) / 16;
     switch (g.nkc) {
         case 1:
-            if constexpr (KS == 3 && !IsPair<T>::value) {
+            if constexpr (KS == 3) {
                 if (g.nj == 2) { kern = roll_kernel_for<KS, S, 1, T, 2>(mt, no); break; }
 #if ROLL_NJ_MAX >= 3
                 if (g.nj == 3) { kern = roll_kernel_for<KS, S, 1, T, 3>(mt, no); break; }
