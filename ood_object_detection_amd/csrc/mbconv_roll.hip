@@ -574,7 +574,10 @@ RollGeometry pick_roll(int H, int W, int Cin, int mid, int k, int stride, bool p
             if (mt >= 3 && (g.nkc > 1 || (mt == 4 && k == 5))) continue;
         }
         // rough issue cycles per output row of the strip set: expand tiles (MFMAs + epilogue) + depthwise tiles
-        long long cost = (long long)ns * ((iwa / 16) * stride * (g.nkc * 16 + 48) + ((two + 15) / 16) * (npair * 16 + 56));
+        // (round 4: constants re-derived from the row loop's listing after its diet - an expand tile is 1 MFMA per K chunk + 8 exp / rcp +
+        // packed multiplies / converts ~ 110 cycles, a 3 x 3 depthwise tile 5 MFMAs + the same SiLU + pool / store ~ 155; the old 64 : 136
+        // put block 1.1 on five 48-pixel strips, 0.288 ms, where three 64-pixel strips run 0.262: profiles/r04_roll_nj.txt)
+        long long cost = (long long)ns * ((iwa / 16) * stride * (g.nkc * 16 + 94) + ((two + 15) / 16) * (npair * 19 + 60));
 #ifdef ROLL_PAIR_WIDE    /* experiment (variant builds only): two-term mode takes the widest strips its registers allow - measured
                             round 4: block 1.0 0.794 ms either way (28 or 44 strips x bands per image), 2.0 0.38 vs 0.30 ms */
         if (pair) cost = ns;
